@@ -1,0 +1,177 @@
+/*
+ * oracle/oracle.h -- CPU restatement of the SSRLCV hot path (TEST INFRASTRUCTURE ONLY).
+ *
+ * This library is the parity oracle for the MI355X build.  It restates, in plain C and
+ * single precision, the arithmetic of the reference's CUDA kernels in the order the
+ * reference performs it.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it; the product path (ssrlcv_amd/) never does.
+ *
+ * Every function cites the reference file:line it follows (paths relative to the
+ * reference checkout).  Compiled with -ffp-contract=off; the places where nvcc's default
+ * -fmad=true would fuse a multiply-add inside an accumulation loop use fmaf() explicitly
+ * and say so.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   P1+P2 (bundles + two-view triangulation)  pinned by Pipeline2View/0_* fixtures
+ *   P3   (N-view triangulation)               pinned by Pipeline3View/0_* fixtures (ill-conditioned, ~1e-3 km)
+ *   M6/M7 (match-set assembly)                pinned structurally by the MultiMatch/KeyPoint fixtures
+ *   filters                                   pinned by Pipeline{2,3}View/1_* fixtures
+ *   S1-S14, M1-M4                             pinned jointly (consistency) by pixels fixtures + seed features + 0_KeyPoint fixtures
+ *   P1c (pushbroom), P5 (SVD pseudo-inverse)  PARITY UNPINNED (no reference fixture reaches them)
+ */
+#ifndef SSRLCV_ORACLE_H
+#define SSRLCV_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- POD layouts (must match include/ssrlcv_hip.h; CUDA vector-type alignment) ---- */
+typedef struct { float x, y; } __attribute__((aligned(8))) o_float2;
+typedef struct { float x, y, z; } o_float3;
+typedef struct { float x, y, z, w; } __attribute__((aligned(16))) o_float4;
+typedef struct { uint32_t x, y; } __attribute__((aligned(8))) o_uint2;
+
+/* include/Image.cuh:40-57 (80 bytes) */
+typedef struct {
+  o_float3 cam_pos;
+  o_float3 cam_rot;
+  o_float2 fov;
+  float foc;
+  o_float2 dpix;
+  long long timeStamp;
+  o_float3 ecef_offset;
+  uint8_t no_rot;
+  o_uint2 size;
+} o_camera;
+
+/* include/Image.cuh:62-79 (72 bytes) */
+typedef struct {
+  o_float3 start_pos;
+  o_float3 end_pos;
+  o_float2 projection_center;
+  float axis_radius;
+  float roll;
+  float altitude;
+  float foc;
+  float fov;
+  float gsd;
+  o_float2 dpix;
+  o_uint2 size;
+} o_pushbroom;
+
+/* include/MatchFactory.cuh:23-72 */
+typedef struct { int parentId; o_float2 loc; } o_keypoint;           /* 16 B */
+typedef struct { uint32_t numKeyPoints; int index; } o_multimatch;   /*  8 B */
+typedef struct { uint8_t invalid; o_keypoint keyPoints[2]; } o_match;          /* 40 B */
+typedef struct { uint8_t invalid; o_keypoint keyPoints[2]; float distance; } o_dmatch; /* 48 B */
+typedef struct { o_uint2 a, b; } o_uint2_pair;                       /* 16 B */
+
+/* include/PointCloudFactory.cuh:25-40 */
+typedef struct { o_float3 vec, pnt; } o_line;                        /* 24 B */
+typedef struct { uint32_t numLines; int index; uint8_t invalid; } o_bundle;    /* 12 B */
+
+/* include/Feature.cuh:31-94 : Feature<SIFT_Descriptor>, 152 B */
+typedef struct {
+  int parent;
+  o_float2 loc;
+  float sigma;
+  float theta;
+  uint8_t values[128];
+} o_feature;
+
+/* include/FeatureFactory.cuh:64-75 : ScaleSpace::SSKeyPoint, 32 B */
+typedef struct {
+  int octave;
+  int blur;
+  o_float2 loc;
+  float intensity;
+  float sigma;
+  float theta;
+  uint8_t discard;
+} o_sskeypoint;
+
+/* ------------------------------- point cloud (P) ------------------------------------ */
+/* src/PointCloudFactory.cu:4166-4199 generateBundle; cameras[].dpix is rewritten like the kernel does */
+void oracle_generate_bundles(uint32_t numBundles, const o_multimatch* matches, const o_keypoint* keyPoints,
+                             o_camera* cameras, o_bundle* bundles, o_line* lines);
+/* src/PointCloudFactory.cu:4201-4283 generatePushbroomBundle  (PARITY UNPINNED) */
+void oracle_generate_pushbroom_bundles(uint32_t numBundles, const o_multimatch* matches, const o_keypoint* keyPoints,
+                                       const o_pushbroom* pushbrooms, o_bundle* bundles, o_line* lines);
+/* src/PointCloudFactory.cu:4457-4869 computeTwoViewTriangulate family.
+ * errors (nullable) per-bundle ||s1-s2||^2; cutoff (nullable) -> bundles[i].invalid = error > *cutoff;
+ * points nullable (void variants).  Returns the error sum accumulated sequentially in index order. */
+float oracle_two_view_triangulate(uint32_t n, const o_line* lines, o_bundle* bundles, o_float3* points,
+                                  float* errors, const float* cutoff);
+/* src/PointCloudFactory.cu:4880-5293 computeNViewTriangulate family */
+float oracle_n_view_triangulate(uint32_t n, const o_line* lines, o_bundle* bundles, o_float3* points,
+                                float* errors, const float* cutoff);
+/* src/Image.cu:445-472 Image::setFloatVector (6 params: pos xyz, rot xyz) then generateBundle + void two-view error:
+ * the evaluation BundleAdjustTwoView repeats 612x per iteration (src/PointCloudFactory.cu:1059-1504). */
+float oracle_ba_eval(uint32_t numBundles, const o_multimatch* matches, const o_keypoint* keyPoints,
+                     const o_camera* cameras, uint32_t numCameras, const float* params6);
+
+/* ------------------------------- matching (M) ---------------------------------------- */
+/* src/Feature.cu:36-42 */
+float oracle_dist_protocol(const uint8_t* a, const uint8_t* b, float bestMatch);
+/* src/MatchFactory.cu:1432-1460 */
+void oracle_seed_distances(uint32_t nq, const o_feature* query, uint32_t ns, const o_feature* seed, float* out);
+/* src/Image.cu:498-539 */
+void oracle_projection_matrix(const o_camera* cam, o_float4 P[3]);
+/* mode: 0 brute force (MatchFactory.cu:2073-2125 / 1874-1919), 1 double constrained (:2194-2291 / :1981-2072).
+ * seed nullable. best_index out (-1 none), best_dist out (distance the kernel ends with). */
+void oracle_match_core(int mode, uint32_t nq, const o_feature* query, uint32_t nt, const o_feature* target,
+                       const o_camera* queryCam, const o_float4* targetP, float epsilon, float delta,
+                       float absoluteThreshold, int* best_index, float* best_dist);
+/* DMatch output incl. seed ratio test with relativeThreshold^2 (MatchFactory.cu:2107-2122, 2273-2288) */
+void oracle_match_dmatch(int mode, uint32_t queryID, uint32_t nq, const o_feature* query, uint32_t targetID, uint32_t nt,
+                         const o_feature* target, const o_camera* queryCam, const o_float4* targetP, float epsilon,
+                         float delta, const float* seedDistances, float relativeThreshold, float absoluteThreshold,
+                         o_dmatch* out);
+/* uint2_pair output, seed ratio test with relativeThreshold NOT squared (MatchFactory.cu:2898-2912) */
+void oracle_match_pairs(int mode, uint32_t queryID, uint32_t nq, const o_feature* query, uint32_t targetID, uint32_t nt,
+                        const o_feature* target, const o_camera* queryCam, const o_float4* targetP, float epsilon,
+                        float delta, const float* seedDistances, float relativeThreshold, float absoluteThreshold,
+                        o_uint2_pair* out);
+
+/* src/MatchFactory.cu:1240-1277 getEpipolarEndpoints (exposed for kernel-level tests) */
+void oracle_epipolar_endpoints(const o_camera* qc, const o_float4* P, const o_float2* loc, float delta, o_float2* p1,
+                               o_float2* p2);
+/* src/MatchFactory.cu:943-1020: host adjacency merge of generateMatchesExhaustive.  pairs = validated uint2_pair
+ * lists concatenated in the reference's pair order; returns #multi-matches, outputs malloc'd (oracle_free). */
+int oracle_exhaustive_merge(uint32_t numImages, const uint32_t* numFeatures, uint32_t numPairs,
+                            const uint32_t* pair_counts, const o_uint2_pair* pairs, o_multimatch** mm_out,
+                            o_uint2** members_out, uint32_t* numMembers);
+void oracle_free(void* p);
+
+/* ------------------------------- SIFT (S) -------------------------------------------- */
+typedef struct oracle_sift oracle_sift;   /* opaque scale-space + keypoint state */
+/* src/SIFT_FeatureFactory.cu:17-31,55-169 sparse branch.  Returns number of features; *out is malloc'd. */
+int oracle_sift_generate(const uint8_t* pixels, uint32_t width, uint32_t height, uint32_t maxOrientations,
+                         float orientationThreshold, float orientationContribWidth, float descriptorContribWidth,
+                         o_feature** out);
+/* staged access for kernel-level parity tests */
+oracle_sift* oracle_sift_create(const uint8_t* pixels, uint32_t width, uint32_t height);
+void oracle_sift_destroy(oracle_sift* s);
+/* copies level data; kind 0 = normalised gaussian level b (0..5), 1 = raw DoG level b (0..4), 2 = twice-normalised DoG */
+int oracle_sift_level(const oracle_sift* s, int kind, int octave, int blur, float* out, uint32_t* w, uint32_t* h);
+void oracle_sift_minmax(const oracle_sift* s, int kind, int octave, int blur, float* mn, float* mx);
+void oracle_sift_octave_info(const oracle_sift* s, int octave, uint32_t* w, uint32_t* h, float* pixelWidth,
+                             float* sigmas6);
+/* Blur::Blur tap generation (src/FeatureFactory.cu:15-18,29-33); returns odd tap count */
+int oracle_gauss_kernel(float sigma, float pixelWidth, float* weights);
+/* fillDescriptors(SSKeyPoint) for one keypoint on a (twice-normalised) DoG level */
+void oracle_fill_descriptor(const float* level, uint32_t W, uint32_t H, float pixelWidth, float lambda,
+                            const o_sskeypoint* kp, o_feature* feat);
+/* full keypoint + descriptor stage on an existing scale space; *out malloc'd (oracle_free) */
+int oracle_sift_features(oracle_sift* s, uint32_t maxOrientations, float orientationThreshold,
+                         float orientationContribWidth, float descriptorContribWidth, o_feature** out);
+/* runs findKeyPoints + checkKeyPoints (+ orientations if with_theta); returns count; out malloc'd */
+int oracle_sift_keypoints(oracle_sift* s, int stage, o_sskeypoint** out, int blurIndices[4][6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
