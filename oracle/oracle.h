@@ -168,6 +168,10 @@ void oracle_fill_descriptor(const float* level, uint32_t W, uint32_t H, float pi
 /* full keypoint + descriptor stage on an existing scale space; *out malloc'd (oracle_free) */
 int oracle_sift_features(oracle_sift* s, uint32_t maxOrientations, float orientationThreshold,
                          float orientationContribWidth, float descriptorContribWidth, o_feature** out);
+/* image-op wrappers: upsampleImage / binImage / convolveSeparable (src/Image.cu:1393-1414,1380-1392,1197-1239) */
+void oracle_upsample2x(const float* in, uint32_t w, uint32_t h, float* out);
+void oracle_bin2x(const float* in, uint32_t w, uint32_t h, float* out);
+void oracle_conv_separable(const float* in, uint32_t w, uint32_t h, int taps, const float* weights, float* out);
 /* runs findKeyPoints + checkKeyPoints (+ orientations if with_theta); returns count; out malloc'd */
 int oracle_sift_keypoints(oracle_sift* s, int stage, o_sskeypoint** out, int blurIndices[4][6]);
 

@@ -715,3 +715,20 @@ int oracle_sift_generate(const uint8_t* pixels, uint32_t width, uint32_t height,
   oracle_sift_destroy(s);
   return n;
 }
+
+/* kernel-level wrappers for parity tests of the individual image ops */
+void oracle_upsample2x(const float* in, uint32_t w, uint32_t h, float* out) {
+  float* r = upsample2x(in, w, h);
+  memcpy(out, r, sizeof(float) * 4 * (size_t)w * h);
+  free(r);
+}
+void oracle_bin2x(const float* in, uint32_t w, uint32_t h, float* out) {
+  float* r = bin2x(in, w, h);
+  memcpy(out, r, sizeof(float) * (size_t)(w / 2) * (h / 2));
+  free(r);
+}
+void oracle_conv_separable(const float* in, uint32_t w, uint32_t h, int taps, const float* weights, float* out) {
+  float* r = conv_separable(in, w, h, taps, weights);
+  memcpy(out, r, sizeof(float) * (size_t)w * h);
+  free(r);
+}

@@ -1,0 +1,46 @@
+"""ctypes loader for libssrlcv_hip.so.  Fails loudly when the HIP extension has not been built."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libssrlcv_hip.so")
+
+_lib = None
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipExtensionMissing(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+                "`make -C ssrlcv_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.ssrlcv_hip_version.restype = ctypes.c_char_p
+        _lib.ssrlcv_hip_status_string.restype = ctypes.c_char_p
+        for name in ("ssrlcv_hip_match_workspace_bytes", "ssrlcv_sift_plan_workspace_bytes",
+                     "ssrlcv_hip_ba_sweep2_workspace_bytes"):
+            getattr(_lib, name).restype = ctypes.c_size_t
+        _lib.ssrlcv_sift_plan_max_features.restype = ctypes.c_uint32
+    return _lib
+
+
+# every symbol include/ssrlcv_hip.h declares (checked by tests/test_capi_symbols.py without a GPU)
+EXPORTED = [
+    "ssrlcv_hip_version", "ssrlcv_hip_status_string",
+    "ssrlcv_hip_generate_bundles", "ssrlcv_hip_generate_pushbroom_bundles", "ssrlcv_hip_triangulate2",
+    "ssrlcv_hip_triangulateN", "ssrlcv_hip_ba_sweep2_workspace_bytes", "ssrlcv_hip_ba_sweep2",
+    "ssrlcv_projection_matrix_host", "ssrlcv_hip_match_workspace_bytes", "ssrlcv_hip_seed_distances_u8x128",
+    "ssrlcv_hip_match_u8x128", "ssrlcv_hip_compact_matches",
+    "ssrlcv_hip_u8_to_f32", "ssrlcv_hip_upsample2x", "ssrlcv_hip_upsample2x_u8", "ssrlcv_hip_bin2x",
+    "ssrlcv_gauss_kernel_host", "ssrlcv_hip_gauss_sep_conv", "ssrlcv_hip_minmax", "ssrlcv_hip_normalize",
+    "ssrlcv_hip_dog_normalised_sub",
+    "ssrlcv_sift_plan_create", "ssrlcv_sift_plan_destroy", "ssrlcv_sift_plan_workspace_bytes",
+    "ssrlcv_sift_plan_max_features", "ssrlcv_hip_sift_build_dog", "ssrlcv_hip_sift_describe",
+    "ssrlcv_hip_sift_extract", "ssrlcv_sift_plan_level", "ssrlcv_sift_plan_keypoints",
+    "ssrlcv_sift_plan_set_stop_stage",
+]

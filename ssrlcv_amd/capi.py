@@ -1,0 +1,292 @@
+"""Thin Python plumbing over the C ABI (include/ssrlcv_hip.h) for tests and bench.py.
+
+torch is used only for device memory and streams; every compute call goes through libssrlcv_hip.so with raw
+device pointers.  Struct arrays travel as uint8 tensors (byte-compatible with include/ssrlcv_types.h).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+LIB = _lib.load()
+
+c_u32, c_f32, c_vp, c_sz, c_int = ctypes.c_uint32, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+
+OUT_DMATCH, OUT_UINT2_PAIR, OUT_MATCH = 0, 1, 2
+_OUT_SIZE = {OUT_DMATCH: 48, OUT_UINT2_PAIR: 16, OUT_MATCH: 40}
+
+
+class SsrlcvError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise SsrlcvError("ssrlcv_hip status %d: %s" % (rc, LIB.ssrlcv_hip_status_string(int(rc)).decode()))
+
+
+def stream_ptr():
+    return c_vp(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return c_vp(0)
+    assert t.is_cuda and t.is_contiguous()
+    return c_vp(t.data_ptr())
+
+
+def to_dev(arr):
+    """numpy (possibly structured) array -> uint8 CUDA tensor holding the same bytes."""
+    a = np.ascontiguousarray(arr)
+    return torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).cuda()
+
+
+def to_host(t, dtype, count=None):
+    a = t.detach().cpu().numpy().view(np.uint8).reshape(-1)
+    dt = np.dtype(dtype)
+    if count is not None:
+        a = a[: count * dt.itemsize]
+    return a.view(dt).copy()
+
+
+def dev_bytes(n):
+    return torch.empty(max(int(n), 1), dtype=torch.uint8, device="cuda")
+
+
+class CameraStruct(ctypes.Structure):
+    _fields_ = [("raw", ctypes.c_uint8 * 80)]
+
+
+class MatchParams(ctypes.Structure):
+    _fields_ = [("mode", c_int), ("queryImageID", c_u32), ("targetImageID", c_u32), ("epsilon", c_f32),
+                ("delta", c_f32), ("relativeThreshold", c_f32), ("absoluteThreshold", c_f32),
+                ("pad0", c_u32),  # ssrlcv_camera is 8-byte aligned
+                ("queryCamera", ctypes.c_uint8 * 80), ("targetProjection", c_f32 * 12)]
+
+
+assert ctypes.sizeof(MatchParams) == 32 + 80 + 48, ctypes.sizeof(MatchParams)
+
+
+class SiftParams(ctypes.Structure):
+    _fields_ = [("maxOrientations", c_u32), ("orientationThreshold", c_f32), ("orientationContribWidth", c_f32),
+                ("descriptorContribWidth", c_f32), ("maxKeyPointsPerOctave", c_u32)]
+
+
+# ------------------------------------------------------------------ point cloud
+def generate_bundles(matches_d, keypoints_d, num_bundles, cameras_d, num_cameras, num_keypoints):
+    bundles = dev_bytes(num_bundles * 12)
+    lines = dev_bytes(num_keypoints * 24)
+    check(LIB.ssrlcv_hip_generate_bundles(ptr(matches_d), ptr(keypoints_d), c_u32(num_bundles), ptr(cameras_d),
+                                          c_u32(num_cameras), ptr(bundles), ptr(lines), stream_ptr()))
+    return bundles, lines
+
+
+def generate_pushbroom_bundles(matches_d, keypoints_d, num_bundles, pushbrooms_d, num_cameras, num_keypoints):
+    bundles = dev_bytes(num_bundles * 12)
+    lines = dev_bytes(num_keypoints * 24)
+    check(LIB.ssrlcv_hip_generate_pushbroom_bundles(ptr(matches_d), ptr(keypoints_d), c_u32(num_bundles),
+                                                    ptr(pushbrooms_d), c_u32(num_cameras), ptr(bundles), ptr(lines),
+                                                    stream_ptr()))
+    return bundles, lines
+
+
+def triangulate(lines_d, bundles_d, n, nview=False, want_points=True, want_errors=False, cutoff=None,
+                no_error_variant=False):
+    points = torch.zeros(max(n, 1) * 3, dtype=torch.float32, device="cuda") if want_points else None
+    errors = torch.zeros(max(n, 1), dtype=torch.float32, device="cuda") if want_errors else None
+    cut = torch.tensor([cutoff], dtype=torch.float32, device="cuda") if cutoff is not None else None
+    esum = torch.zeros(1, dtype=torch.float32, device="cuda")
+    if nview:
+        check(LIB.ssrlcv_hip_triangulateN(ptr(lines_d), ptr(bundles_d), c_u32(n), ptr(points), ptr(errors), ptr(cut),
+                                          ptr(esum), c_int(1 if no_error_variant else 0), stream_ptr()))
+    else:
+        check(LIB.ssrlcv_hip_triangulate2(ptr(lines_d), ptr(bundles_d), c_u32(n), ptr(points), ptr(errors), ptr(cut),
+                                          ptr(esum), stream_ptr()))
+    return points, errors, esum
+
+
+def ba_sweep2(matches_d, keypoints_d, num_bundles, cameras_d, num_cameras, params_d, K):
+    sums = torch.zeros(K, dtype=torch.float32, device="cuda")
+    check(LIB.ssrlcv_hip_ba_sweep2(ptr(matches_d), ptr(keypoints_d), c_u32(num_bundles), ptr(cameras_d),
+                                   c_u32(num_cameras), ptr(params_d), c_u32(K), ptr(sums), c_vp(0), c_sz(0),
+                                   stream_ptr()))
+    return sums
+
+
+# ------------------------------------------------------------------ matching
+def projection_matrix(camera_np):
+    cam = np.ascontiguousarray(camera_np).view(np.uint8).reshape(-1)[:80].copy()
+    out = np.zeros(12, np.float32)
+    LIB.ssrlcv_projection_matrix_host(cam.ctypes.data_as(c_vp), out.ctypes.data_as(c_vp))
+    return out.reshape(3, 4)
+
+
+def match_workspace(nq, nt):
+    return dev_bytes(LIB.ssrlcv_hip_match_workspace_bytes(c_u32(nq), c_u32(nt)))
+
+
+def seed_distances(query_d, nq, seed_d, ns, workspace=None):
+    ws = workspace if workspace is not None else match_workspace(nq, ns)
+    out = torch.empty(max(nq, 1), dtype=torch.float32, device="cuda")
+    check(LIB.ssrlcv_hip_seed_distances_u8x128(ptr(query_d), c_u32(nq), ptr(seed_d), c_u32(ns), ptr(out), ptr(ws),
+                                               c_sz(ws.numel()), stream_ptr()))
+    return out
+
+
+def make_match_params(mode, query_id, target_id, epsilon=0.0, delta=0.0, rel=0.0, absolute=0.0, query_camera=None,
+                      target_projection=None):
+    p = MatchParams()
+    p.mode, p.queryImageID, p.targetImageID = mode, query_id, target_id
+    p.epsilon, p.delta, p.relativeThreshold, p.absoluteThreshold = epsilon, delta, rel, absolute
+    if query_camera is not None:
+        raw = np.ascontiguousarray(query_camera).view(np.uint8).reshape(-1)[:80]
+        ctypes.memmove(p.queryCamera, raw.ctypes.data, 80)
+    if target_projection is not None:
+        tp = np.ascontiguousarray(target_projection, dtype=np.float32).reshape(-1)
+        ctypes.memmove(p.targetProjection, tp.ctypes.data, 48)
+    return p
+
+
+def match(query_d, nq, target_d, nt, params, out_kind=OUT_DMATCH, seed_d=None, workspace=None, out=None):
+    ws = workspace if workspace is not None else match_workspace(nq, nt)
+    if out is None:
+        out = dev_bytes(nq * _OUT_SIZE[out_kind])
+    check(LIB.ssrlcv_hip_match_u8x128(ptr(query_d), c_u32(nq), ptr(target_d), c_u32(nt), ptr(seed_d),
+                                      ctypes.byref(params), c_int(out_kind), ptr(out), ptr(ws), c_sz(ws.numel()),
+                                      stream_ptr()))
+    return out
+
+
+def compact_matches(out_kind, matches_d, n, workspace):
+    cnt = c_u32(0)
+    check(LIB.ssrlcv_hip_compact_matches(c_int(out_kind), ptr(matches_d), c_u32(n), ctypes.byref(cnt), ptr(workspace),
+                                         c_sz(workspace.numel()), stream_ptr()))
+    return cnt.value
+
+
+# ------------------------------------------------------------------ SIFT kernel-level
+def gauss_kernel(sigma, pixel_width):
+    w = np.zeros(129, np.float32)
+    taps = LIB.ssrlcv_gauss_kernel_host(c_f32(sigma), c_f32(pixel_width), w.ctypes.data_as(c_vp))
+    return taps, w[:max(taps, 0)].copy()
+
+
+def upsample2x_u8(img_d, w, h):
+    out = torch.empty(4 * w * h, dtype=torch.float32, device="cuda")
+    check(LIB.ssrlcv_hip_upsample2x_u8(ptr(img_d), c_u32(w), c_u32(h), ptr(out), stream_ptr()))
+    return out
+
+
+def upsample2x(img_d, w, h):
+    out = torch.empty(4 * w * h, dtype=torch.float32, device="cuda")
+    check(LIB.ssrlcv_hip_upsample2x(ptr(img_d), c_u32(w), c_u32(h), ptr(out), stream_ptr()))
+    return out
+
+
+def u8_to_f32(img_d, n):
+    out = torch.empty(n, dtype=torch.float32, device="cuda")
+    check(LIB.ssrlcv_hip_u8_to_f32(ptr(img_d), ptr(out), c_sz(n), stream_ptr()))
+    return out
+
+
+def bin2x(img_d, w, h):
+    out = torch.empty((w // 2) * (h // 2), dtype=torch.float32, device="cuda")
+    check(LIB.ssrlcv_hip_bin2x(ptr(img_d), c_u32(w), c_u32(h), ptr(out), stream_ptr()))
+    return out
+
+
+def gauss_sep_conv(img_d, w, h, weights, want_minmax=True):
+    out = torch.empty(w * h, dtype=torch.float32, device="cuda")
+    mm = torch.tensor([3.4028234663852886e38, -3.4028234663852886e38], dtype=torch.float32, device="cuda") \
+        if want_minmax else None
+    wh = np.ascontiguousarray(weights, dtype=np.float32)
+    check(LIB.ssrlcv_hip_gauss_sep_conv(ptr(img_d), ptr(out), c_vp(0), c_u32(w), c_u32(h), c_int(len(wh)),
+                                        wh.ctypes.data_as(c_vp), ptr(mm), stream_ptr()))
+    return out, mm
+
+
+def minmax(img_d, n):
+    mm = torch.empty(2, dtype=torch.float32, device="cuda")
+    check(LIB.ssrlcv_hip_minmax(ptr(img_d), c_sz(n), ptr(mm), stream_ptr()))
+    return mm
+
+
+def normalize_(img_d, n, mm_d):
+    check(LIB.ssrlcv_hip_normalize(ptr(img_d), c_sz(n), ptr(mm_d), stream_ptr()))
+
+
+# ------------------------------------------------------------------ SIFT pipeline
+class SiftPlan:
+    """Owns an ssrlcv_sift_plan and (optionally) the workspace tensor for one W x H image slot."""
+
+    def __init__(self, w, h, max_orientations=2, orientation_threshold=0.8, orientation_contrib_width=1.5,
+                 descriptor_contrib_width=6.0, max_keypoints_per_octave=0, alloc=True):
+        self.w, self.h = w, h
+        p = SiftParams(max_orientations, orientation_threshold, orientation_contrib_width, descriptor_contrib_width,
+                       max_keypoints_per_octave)
+        self.handle = c_vp()
+        check(LIB.ssrlcv_sift_plan_create(c_u32(w), c_u32(h), ctypes.byref(p), ctypes.byref(self.handle)))
+        self.workspace_bytes = LIB.ssrlcv_sift_plan_workspace_bytes(self.handle)
+        self.max_features = LIB.ssrlcv_sift_plan_max_features(self.handle)
+        self.workspace = dev_bytes(self.workspace_bytes) if alloc else None
+        self.features = dev_bytes(self.max_features * 152) if alloc else None
+        self.num_features = torch.zeros(1, dtype=torch.int32, device="cuda") if alloc else None
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            LIB.ssrlcv_sift_plan_destroy(self.handle)
+            self.handle = None
+
+    def set_stop_stage(self, stage):
+        LIB.ssrlcv_sift_plan_set_stop_stage(self.handle, c_int(stage))
+
+    def build_dog(self, pixels_d):
+        check(LIB.ssrlcv_hip_sift_build_dog(self.handle, ptr(pixels_d), ptr(self.workspace), stream_ptr()))
+
+    def describe(self):
+        check(LIB.ssrlcv_hip_sift_describe(self.handle, ptr(self.workspace), ptr(self.features),
+                                           ptr(self.num_features), stream_ptr()))
+
+    def extract(self, pixels_d):
+        check(LIB.ssrlcv_hip_sift_extract(self.handle, ptr(pixels_d), ptr(self.workspace), ptr(self.features),
+                                          ptr(self.num_features), stream_ptr()))
+
+    def count(self):
+        torch.cuda.current_stream().synchronize()
+        return int(self.num_features.item())
+
+    def level(self, kind, octave, blur):
+        """-> (numpy level copy, (min, max)); kind 0 = raw DoG, 1 = gaussian (last octave built)."""
+        data, mm = c_vp(), c_vp()
+        w, h = c_u32(), c_u32()
+        check(LIB.ssrlcv_sift_plan_level(self.handle, ptr(self.workspace), c_int(kind), c_int(octave), c_int(blur),
+                                         ctypes.byref(data), ctypes.byref(w), ctypes.byref(h), ctypes.byref(mm)))
+        torch.cuda.synchronize()
+        base = self.workspace.data_ptr()
+        off = data.value - base
+        n = w.value * h.value
+        lvl = self.workspace[off: off + 4 * n].view(torch.float32).cpu().numpy().reshape(h.value, w.value).copy()
+        moff = mm.value - base
+        mmv = self.workspace[moff: moff + 8].view(torch.float32).cpu().numpy().copy()
+        return lvl, (float(mmv[0]), float(mmv[1]))
+
+    def keypoints(self, octave, dtype):
+        """-> (SSKeyPoint numpy array of the octave, blur indices [6])"""
+        lst, idx = c_vp(), c_vp()
+        check(LIB.ssrlcv_sift_plan_keypoints(self.handle, ptr(self.workspace), c_int(octave), ctypes.byref(lst),
+                                             ctypes.byref(idx)))
+        torch.cuda.synchronize()
+        base = self.workspace.data_ptr()
+        ioff = idx.value - base
+        state = self.workspace[ioff: ioff + 32].view(torch.int32).cpu().numpy().copy()
+        n = int(state[5]) if int(state[6]) else 0
+        loff = lst.value - base
+        kps = to_host(self.workspace[loff: loff + 32 * max(n, 1)], dtype, n)
+        return kps, state[:6].copy(), int(state[7])
+
+    def features_host(self, dtype):
+        n = self.count()
+        return to_host(self.features[: 152 * max(n, 1)], dtype, n)

@@ -1,0 +1,164 @@
+// ssrlcv_amd/csrc/compact.h -- order-preserving multi-block stream compaction / partition for gfx950.
+//
+// Replaces the thrust::remove / remove_if / copy_if / stable_sort-by-small-key call sites of the hot path
+// (src/FeatureFactory.cu:126,189,250,595,597; src/MatchFactory.cu:37,63,89).  Three launches:
+//   1. k_count  : each 256-thread block owns a chunk of consecutive elements and counts, per key, how many of its
+//                 elements carry that key.  An element may carry several keys (bit mask), e.g. a pixel that is an
+//                 extremum of two DoG levels; mask 0 removes the element;
+//   2. k_scan   : one block turns the [key][block] count table into exclusive offsets in key-major order, so the
+//                 output is grouped by key and, inside a key, keeps the input order (= stable partition);
+//   3. k_scatter: each block recomputes its elements' ranks (wave64 ballots + popcounts) and emits them.
+// The mask functor must be pure (it is evaluated in passes 1 and 3).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace svc {
+
+constexpr int kThreads = 256;
+
+__host__ __device__ inline uint32_t num_chunks(uint32_t n, int perThread) {
+  uint32_t chunk = (uint32_t)kThreads * (uint32_t)perThread;
+  return (n + chunk - 1) / chunk;
+}
+
+// counts layout: counts[key * numBlocks + block]
+template <int NKEYS, int PER_THREAD, typename MaskFn>
+__global__ __launch_bounds__(kThreads) void k_count(uint32_t n, uint32_t numBlocks, MaskFn maskfn,
+                                                    uint32_t* __restrict__ counts) {
+  __shared__ uint32_t s_cnt[NKEYS];
+  if (threadIdx.x < NKEYS) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * (kThreads * PER_THREAD);
+  uint32_t local[NKEYS];
+#pragma unroll
+  for (int k = 0; k < NKEYS; ++k) local[k] = 0;
+  for (int r = 0; r < PER_THREAD; ++r) {
+    uint32_t i = base + r * kThreads + threadIdx.x;
+    uint32_t mask = (i < n) ? maskfn(i) : 0u;
+#pragma unroll
+    for (int k = 0; k < NKEYS; ++k) local[k] += (mask >> k) & 1u;
+  }
+#pragma unroll
+  for (int k = 0; k < NKEYS; ++k) {
+    uint32_t v = local[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_cnt[k], v);
+  }
+  __syncthreads();
+  if (threadIdx.x < NKEYS) counts[threadIdx.x * numBlocks + blockIdx.x] = s_cnt[threadIdx.x];
+}
+
+// Exclusive scan over the NKEYS*numBlocks table in key-major order; totals[k] = number of elements with key k,
+// totals[NKEYS] = grand total.  Single block of 1024 threads, each thread scanning 4 consecutive entries per round.
+template <int NKEYS>
+__global__ __launch_bounds__(1024) void k_scan(uint32_t numBlocks, uint32_t* __restrict__ counts,
+                                               uint32_t* __restrict__ totals) {
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_carry;
+  __shared__ uint32_t s_keystart[NKEYS + 1];
+  const uint32_t total_entries = NKEYS * numBlocks;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (uint32_t start = 0; start < total_entries; start += 4096) {
+    uint32_t i0 = start + threadIdx.x * 4;
+    uint32_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (i0 + j < total_entries) ? counts[i0 + j] : 0;
+    uint32_t tsum = v[0] + v[1] + v[2] + v[3];
+    uint32_t x = tsum;  // inclusive scan of per-thread sums inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      uint32_t y = __shfl_up(x, o, 64);
+      if ((threadIdx.x & 63) >= (unsigned)o) x += y;
+    }
+    if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = x;
+    __syncthreads();
+    uint32_t wave_off = 0;
+    for (unsigned w = 0; w < (threadIdx.x >> 6); ++w) wave_off += s_wave[w];
+    uint32_t excl = s_carry + wave_off + x - tsum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t i = i0 + j;
+      if (i < total_entries) {
+        counts[i] = excl;
+        if (i % numBlocks == 0) s_keystart[i / numBlocks] = excl;
+      }
+      excl += v[j];
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry = excl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) s_keystart[NKEYS] = s_carry;
+  __syncthreads();
+  if (threadIdx.x < NKEYS) totals[threadIdx.x] = s_keystart[threadIdx.x + 1] - s_keystart[threadIdx.x];
+  if (threadIdx.x == 0) totals[NKEYS] = s_carry;
+}
+
+// emit(i, key, dst): writes input element i (as a member of `key`) to output slot dst.
+template <int NKEYS, int PER_THREAD, typename MaskFn, typename EmitFn>
+__global__ __launch_bounds__(kThreads) void k_scatter(uint32_t n, uint32_t numBlocks, MaskFn maskfn, EmitFn emit,
+                                                      const uint32_t* __restrict__ offsets) {
+  __shared__ uint32_t s_base[NKEYS];     // running output offset per key for this block
+  __shared__ uint32_t s_wcnt[4][NKEYS];  // per-wave counts of the current round
+  if (threadIdx.x < NKEYS) s_base[threadIdx.x] = offsets[threadIdx.x * numBlocks + blockIdx.x];
+  __syncthreads();
+  const uint32_t base = blockIdx.x * (kThreads * PER_THREAD);
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int r = 0; r < PER_THREAD; ++r) {
+    uint32_t i = base + r * kThreads + threadIdx.x;
+    uint32_t mask = (i < n) ? maskfn(i) : 0u;
+    uint32_t rank[NKEYS];
+#pragma unroll
+    for (int k = 0; k < NKEYS; ++k) {
+      unsigned long long m = __ballot((mask >> k) & 1u);
+      rank[k] = __popcll(m & below);
+      if (lane == 0) s_wcnt[wave][k] = __popcll(m);
+    }
+    __syncthreads();
+    if (mask) {
+#pragma unroll
+      for (int k = 0; k < NKEYS; ++k) {
+        if ((mask >> k) & 1u) {
+          uint32_t off = s_base[k];
+          for (unsigned w = 0; w < wave; ++w) off += s_wcnt[w][k];
+          emit(i, k, off + rank[k]);
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < NKEYS) {
+      uint32_t add = 0;
+      for (int w = 0; w < 4; ++w) add += s_wcnt[w][threadIdx.x];
+      s_base[threadIdx.x] += add;
+    }
+    __syncthreads();
+  }
+}
+
+// Workspace (in uint32 words): NKEYS * numBlocks counts + (NKEYS + 1) totals.
+template <int NKEYS, int PER_THREAD>
+inline size_t workspace_words(uint32_t n) {
+  return (size_t)NKEYS * num_chunks(n, PER_THREAD) + NKEYS + 1;
+}
+
+// Launches the three passes over elements [0, n).  *totals_out = device pointer to NKEYS + 1 words in the workspace.
+template <int NKEYS, int PER_THREAD, typename MaskFn, typename EmitFn>
+inline hipError_t partition(uint32_t n, MaskFn maskfn, EmitFn emit, uint32_t* workspace, uint32_t** totals_out,
+                            hipStream_t stream) {
+  uint32_t nb = num_chunks(n, PER_THREAD);
+  uint32_t* counts = workspace;
+  uint32_t* totals = workspace + (size_t)NKEYS * nb;
+  if (totals_out) *totals_out = totals;
+  if (nb == 0) return hipMemsetAsync(totals, 0, sizeof(uint32_t) * (NKEYS + 1), stream);
+  hipLaunchKernelGGL((k_count<NKEYS, PER_THREAD, MaskFn>), dim3(nb), dim3(kThreads), 0, stream, n, nb, maskfn, counts);
+  hipLaunchKernelGGL((k_scan<NKEYS>), dim3(1), dim3(1024), 0, stream, nb, counts, totals);
+  hipLaunchKernelGGL((k_scatter<NKEYS, PER_THREAD, MaskFn, EmitFn>), dim3(nb), dim3(kThreads), 0, stream, n, nb, maskfn,
+                     emit, counts);
+  return hipGetLastError();
+}
+
+}  // namespace svc

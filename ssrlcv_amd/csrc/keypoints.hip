@@ -1,0 +1,681 @@
+// ssrlcv_amd/csrc/keypoints.hip -- key-point detection, refinement, orientation and 128-D descriptors for gfx950
+// (SURVEY.md section 8a rows S8-S14).
+//
+// Everything after the pyramid works on small lists gathered from the raw DoG levels; nothing is copied to the host
+// (the reference synchronises and round-trips counts after every launch).  Device-resident OctaveState mirrors
+// Octave::extrema / extremaBlurIndices (include/FeatureFactory.cuh:107-123); single-thread bookkeeping kernels replay
+// the reference's host-side index arithmetic literally, including the blur re-scan of refineExtremaLocation
+// (src/FeatureFactory.cu:251-259) whose untouched entries keep the values discardExtrema left behind.
+//
+// The second normalisation of the DoG levels (findKeyPoints, src/FeatureFactory.cu:472) is never materialised: every
+// consumer samples the raw level and applies (v - min) / (max - min) on the fly -- the same two float operations the
+// in-place normalize kernel performs, so the sampled values are bit-identical while 40 bytes/pixel of traffic vanish.
+// Gradients (calculatePixelGradients, src/Image.cu:1583-1598) are likewise evaluated at the sample sites only.
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
+#include "compact.h"
+#include "device_math.h"
+#include "sift_plan.h"
+#include "ssrlcv_hip.h"
+
+using svp::OctaveState;
+
+namespace {
+
+struct LevelSet {  // one octave's raw DoG levels + their min/max
+  const float* dog[svp::kDog];
+  const float* minmax;  // 5 x {min,max}
+  int w, h;
+};
+
+__device__ __forceinline__ float norm_sample(const float* __restrict__ lvl, float mn, float mx, size_t a) {
+  return (lvl[a] - mn) / (mx - mn);
+}
+
+// ---- S8: extrema ---------------------------------------------------------------------------------------------------
+// findExtrema (src/FeatureFactory.cu:847-882): a pixel of level b (1..3) is kept when it equals the max or the min of
+// its 3x3x3 neighbourhood (non-strict).  One thread per pixel computes the 3x3 max/min of all five levels once and
+// derives the three flags; bit (b-1) of flags[p].
+__global__ __launch_bounds__(256) void k_extrema_flags(LevelSet L, uint8_t* __restrict__ flags) {
+  int x = blockIdx.x * 256 + threadIdx.x;
+  int y = blockIdx.y;
+  if (x >= L.w) return;
+  uint8_t f = 0;
+  if (x > 0 && y > 0 && x < L.w - 1 && y < L.h - 1) {
+    float mx[svp::kDog], mn[svp::kDog], c[svp::kDog];
+#pragma unroll
+    for (int l = 0; l < svp::kDog; ++l) {
+      const float* p = L.dog[l] + (size_t)(y - 1) * L.w + (x - 1);
+      float a0 = p[0], a1 = p[1], a2 = p[2];
+      p += L.w;
+      float b0 = p[0], b1 = p[1], b2 = p[2];
+      p += L.w;
+      float c0 = p[0], c1 = p[1], c2 = p[2];
+      mx[l] = fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, b0)), fmaxf(fmaxf(b1, b2), fmaxf(fmaxf(c0, c1), c2)));
+      mn[l] = fminf(fminf(fminf(a0, a1), fminf(a2, b0)), fminf(fminf(b1, b2), fminf(fminf(c0, c1), c2)));
+      c[l] = b1;
+    }
+#pragma unroll
+    for (int b = 1; b <= 3; ++b) {
+      float hi = fmaxf(fmaxf(mx[b - 1], mx[b]), mx[b + 1]);
+      float lo = fminf(fminf(mn[b - 1], mn[b]), mn[b + 1]);
+      if (hi == c[b] || lo == c[b]) f |= (uint8_t)(1u << (b - 1));
+    }
+  }
+  flags[(size_t)y * L.w + x] = f;
+}
+
+// ---- bookkeeping kernels (one thread) ------------------------------------------------------------------------------------
+__global__ void k_state_reset(OctaveState* st) {
+  for (int i = 0; i < svp::kDog; ++i) { st->idx[i] = 0; st->stale[i] = 0; }
+  st->n = 0;
+  st->hasExtrema = 0;
+  st->overflow = 0;
+}
+// after searchForExtrema (src/FeatureFactory.cu:98-151): totals = counts for b = 1,2,3
+__global__ void k_book_extrema(OctaveState* st, const uint32_t* totals, uint32_t cap) {
+  uint32_t c1 = totals[0], c2 = totals[1], total = totals[3];
+  if (total > cap) { st->overflow = 1; total = 0; c1 = c2 = 0; }
+  st->idx[0] = 0;
+  st->idx[1] = 0;
+  st->idx[2] = (int)c1;
+  st->idx[3] = (int)(c1 + c2);
+  if (total) st->idx[4] = (int)total;
+  st->n = (int)total;
+  st->hasExtrema = total != 0;
+}
+// after discardExtrema (src/FeatureFactory.cu:161-215): totals[s] = survivors of segment s
+__global__ void k_book_discard(OctaveState* st, const uint32_t* totals) {
+  if (!st->hasExtrema) return;
+  int kept = 0;
+  for (int i = 0; i < svp::kDog; ++i) {
+    st->idx[i] = kept;
+    kept += (int)totals[i];
+  }
+  st->n = kept;
+  if (kept == 0) st->hasExtrema = 0;
+}
+// stable_sort by blur + host re-scan of refineExtremaLocation (src/FeatureFactory.cu:249-259): totals[v] = survivors
+// with blur == v.  Entries of idx the loop does not reach keep what k_book_discard wrote.
+__global__ void k_book_rescan(OctaveState* st, const uint32_t* totals) {
+  if (!st->hasExtrema) return;
+  st->idx[0] = 0;
+  st->idx[1] = 0;
+  int pos = 0, blur = 2;
+  bool first = true;
+  for (int v = 0; v < svp::kDog; ++v) {
+    int c = (int)totals[v];
+    if (c == 0) continue;
+    if (!first && blur < svp::kDog - 1) st->idx[blur++] = pos;  // host[i-1] < host[i] at i = pos
+    first = false;
+    pos += c;
+  }
+  st->idx[svp::kDog - 1] = st->n;
+}
+// after computeKeyPointOrientations (src/FeatureFactory.cu:561-630): totals[s] = oriented key points of segment s
+__global__ void k_book_orient(OctaveState* st, const uint32_t* totals, uint32_t cap) {
+  if (!st->hasExtrema) return;
+  int total = 0;
+  for (int b = 0; b < svp::kDog; ++b) {
+    st->idx[b] = total;
+    total += (int)totals[b];
+  }
+  if ((uint32_t)total > cap) { st->overflow = 1; total = 0; }
+  st->n = total;
+  if (total == 0) st->hasExtrema = 0;
+}
+__global__ void k_book_featbase(OctaveState* st, uint32_t* featBase, uint32_t* numFeatures, uint32_t maxFeatures) {
+  uint32_t tot = 0;
+  for (int o = 0; o < svp::kOctaves; ++o) {
+    featBase[o] = tot;
+    tot += st[o].hasExtrema ? (uint32_t)st[o].n : 0u;
+  }
+  if (tot > maxFeatures) tot = maxFeatures;
+  *numFeatures = tot;
+}
+
+__device__ __forceinline__ int segment_of(const OctaveState* st, int i) {
+  int s = 0;
+#pragma unroll
+  for (int k = 1; k < svp::kDog; ++k)
+    if (st->idx[k] <= i) s = k;
+  return s;
+}
+
+// ---- S9 / S11 / S12 flag kernels -----------------------------------------------------------------------------------------
+// flagNoise (src/FeatureFactory.cu:968-973)
+__global__ __launch_bounds__(256) void k_flag_noise(const OctaveState* st, ssrlcv_sskeypoint* kps, float thr) {
+  int n = st->hasExtrema ? st->n : 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+    kps[i].discard = (uint8_t)(fabsf(kps[i].intensity) < thr);
+}
+
+// flagEdges (src/FeatureFactory.cu:974-990) on the level of the key point's SEGMENT (removeEdges :287-306)
+__global__ __launch_bounds__(256) void k_flag_edges(const OctaveState* st, ssrlcv_sskeypoint* kps, LevelSet L, float thr) {
+  int n = st->hasExtrema ? st->n : 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    int seg = segment_of(st, i);
+    const float* px = L.dog[seg];
+    float mn = L.minmax[2 * seg], mx = L.minmax[2 * seg + 1];
+    ssrlcv_sskeypoint kp = kps[i];
+    int lx = (int)roundf(kp.loc.x), ly = (int)roundf(kp.loc.y);
+    int W = L.w;
+#define NS(yy, xx) norm_sample(px, mn, mx, (size_t)(yy) * W + (xx))
+    float h00 = -2.0f * NS(ly, lx);
+    float h11 = h00 + NS(ly + 1, lx) + NS(ly - 1, lx);
+    h00 += NS(ly, lx + 1) + NS(ly, lx - 1);
+    float h01 = (NS(ly + 1, lx + 1) - NS(ly - 1, lx + 1) - NS(ly + 1, lx - 1) + NS(ly - 1, lx - 1));
+#undef NS
+    float e = h00 + h11;
+    float det = (h00 * h11) - (h01 * h01);
+    kps[i].discard = (uint8_t)((e * e / det) > thr);
+  }
+}
+
+// checkKeyPoints (src/SIFT_FeatureFactory.cu:449-461)
+__global__ __launch_bounds__(256) void k_flag_window(const OctaveState* st, ssrlcv_sskeypoint* kps, int w, int h,
+                                                     float pixelWidth, float lambda) {
+  int n = st->hasExtrema ? st->n : 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    ssrlcv_sskeypoint kp = kps[i];
+    float ww = kp.sigma * lambda / pixelWidth;
+    if ((kp.loc.x - ww) < 0.0f || (kp.loc.y - ww) < 0.0f || (kp.loc.x + ww) >= (unsigned)(w - 1) ||
+        (kp.loc.y + ww) >= (unsigned)(h - 1))
+      kps[i].discard = 1;
+  }
+}
+
+// ---- S10: refineLocation (src/FeatureFactory.cu:892-967) -----------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_refine(const OctaveState* st, ssrlcv_sskeypoint* kps, LevelSet L, float sigmaMin,
+                                                float mult) {
+  int n = st->hasExtrema ? st->n : 0;
+  const int W = L.w, H = L.h;
+  const int numBlurs = svp::kDog;
+  for (int gi = blockIdx.x * 256 + threadIdx.x; gi < n; gi += gridDim.x * 256) {
+    ssrlcv_sskeypoint kp = kps[gi];
+    int lx = (int)roundf(kp.loc.x), ly = (int)roundf(kp.loc.y);
+    float hess[3][3], hinv[3][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+    float grad[3], temp[3], offset[3] = {0.0f, 0.0f, 0.0f};
+    int bl = kp.blur;
+    for (int attempt = 0; attempt < 5; ++attempt) {
+      const float* pl = L.dog[bl - 1];
+      const float* pm = L.dog[bl];
+      const float* pu = L.dog[bl + 1];
+      float lmn = L.minmax[2 * (bl - 1)], lmx = L.minmax[2 * (bl - 1) + 1];
+      float mmn = L.minmax[2 * bl], mmx = L.minmax[2 * bl + 1];
+      float umn = L.minmax[2 * (bl + 1)], umx = L.minmax[2 * (bl + 1) + 1];
+#define PM(yy, xx) norm_sample(pm, mmn, mmx, (size_t)(yy) * W + (xx))
+#define PL(yy, xx) norm_sample(pl, lmn, lmx, (size_t)(yy) * W + (xx))
+#define PU(yy, xx) norm_sample(pu, umn, umx, (size_t)(yy) * W + (xx))
+      grad[0] = PM(ly, lx + 1) - PM(ly, lx - 1);
+      grad[1] = PM(ly + 1, lx) - PM(ly - 1, lx);
+      grad[2] = PU(ly, lx) - PL(ly, lx);
+      float centre = PM(ly, lx);
+      hess[0][0] = grad[0] - 2 * centre;
+      hess[0][1] = (PM(ly + 1, lx + 1) - PM(ly - 1, lx + 1) - PM(ly + 1, lx - 1) + PM(ly - 1, lx - 1)) / 4.0f;
+      hess[0][2] = (PU(ly, lx + 1) - PL(ly, lx + 1) - PU(ly, lx - 1) + PL(ly, lx - 1)) / 4.0f;
+      hess[1][0] = hess[0][1];
+      hess[1][1] = grad[1] - 2 * centre;
+      hess[1][2] = (PU(ly + 1, lx) - PL(ly + 1, lx) - PU(ly - 1, lx) + PL(ly - 1, lx)) / 4.0f;
+      hess[2][0] = hess[0][2];
+      hess[2][1] = hess[1][2];
+      hess[2][2] = grad[2] - 2 * centre;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) hess[r][c] *= -1.0f;
+      sv::inverse3(hess, hinv);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        float val = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) val += hinv[r][c] * grad[c];
+        offset[r] = val;
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float val = 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) val += hess[r][c] * grad[r];
+        temp[c] = val;
+      }
+      if (fabsf(offset[0]) <= 0.5f && fabsf(offset[1]) <= 0.5f && fabsf(offset[2]) <= 0.5f) {
+        kp.loc.x = (float)lx + offset[0];
+        kp.loc.y = (float)ly + offset[1];
+        lx = (int)roundf(kp.loc.x);
+        ly = (int)roundf(kp.loc.y);
+        kp.discard = (uint8_t)(lx <= 0 || ly <= 0 || lx >= W - 1 || ly >= H - 1);
+        if (kp.discard) break;
+        kp.intensity = PM(ly, lx) - (0.5f * ((temp[0] * grad[0]) + (temp[1] * grad[1]) + (temp[2] * grad[2])));
+        kp.sigma = sigmaMin * powf(mult, ((float)bl + offset[2]));
+        if (fabsf(offset[2]) > 0.5) bl += (offset[2] > 0) ? 1 : -1;
+        break;
+      } else if (attempt == 4) {
+        kp.discard = 1;
+        break;
+      } else {
+        if (fabsf(offset[0]) > 0.5) lx += (offset[0] > 0) ? 1 : -1;
+        if (fabsf(offset[1]) > 0.5) ly += (offset[1] > 0) ? 1 : -1;
+        kp.loc.x = (float)lx;
+        kp.loc.y = (float)ly;
+        if (fabsf(offset[2]) > 0.5) bl += (offset[2] > 0) ? 1 : -1;
+        if (bl >= numBlurs - 1 || bl <= 0 || lx <= 0 || ly <= 0 || lx >= W - 1 || ly >= H - 1) {
+          kp.discard = 1;
+          break;
+        }
+      }
+#undef PM
+#undef PL
+#undef PU
+    }
+    kp.blur = bl;
+    kps[gi] = kp;
+  }
+}
+
+// calculatePixelGradients(float) (src/Image.cu:1583-1598) at one pixel of a normalised level
+__device__ __forceinline__ float2 pixel_gradient(const float* __restrict__ px, float mn, float mx, int W, int H, int x,
+                                                 int y) {
+  int xc0 = x + 1, xc1 = x - 1, yc0 = y + 1, yc1 = y - 1;
+  if (xc1 == -1) { xc0 += 1; xc1 += 1; }
+  else if (xc0 == W) { xc0 -= 1; xc1 -= 1; }
+  if (yc1 == -1) { yc0 += 1; yc1 += 1; }
+  else if (yc0 == H) { yc0 -= 1; yc1 -= 1; }
+  float2 g;
+  g.x = norm_sample(px, mn, mx, (size_t)y * W + xc0) - norm_sample(px, mn, mx, (size_t)y * W + xc1);
+  g.y = norm_sample(px, mn, mx, (size_t)yc0 * W + x) - norm_sample(px, mn, mx, (size_t)yc1 * W + x);
+  return g;
+}
+
+// ---- S13: computeThetas(SSKeyPoint) (src/FeatureFactory.cu:1004-1112) -----------------------------------------------------
+// One thread per key point, samples visited in the reference's order so each histogram bin accumulates in the same
+// sequence as the oracle.
+template <int MAXO>
+__global__ __launch_bounds__(64) void k_thetas(const OctaveState* st, const ssrlcv_sskeypoint* kps, LevelSet L,
+                                               float pixelWidth, float lambda, float orientationThreshold,
+                                               float* __restrict__ thetas, uint32_t* __restrict__ thetaCnt) {
+  int n = st->hasExtrema ? st->n : 0;
+  int gi = blockIdx.x * 64 + threadIdx.x;
+  if (gi >= n) return;
+  const float pi = SSRLCV_PI_F;
+  int seg = segment_of(st, gi);
+  const float* px = L.dog[seg];
+  float lmn = L.minmax[2 * seg], lmx = L.minmax[2 * seg + 1];
+  ssrlcv_sskeypoint kp = kps[gi];
+  float kx = kp.loc.x, ky = kp.loc.y;
+  float windowWidth = ceilf(kp.sigma * 3.0f * lambda / pixelWidth);
+  float minx = kx - windowWidth, miny = ky - windowWidth, maxx = kx + windowWidth, maxy = ky + windowWidth;
+  uint32_t cnt = 0;
+  float outTheta[MAXO];
+#pragma unroll
+  for (int i = 0; i < MAXO; ++i) outTheta[i] = -FLT_MAX;
+  if (!(minx < 0.0f || miny < 0.0f || maxx >= (unsigned)(L.w - 1) || maxy >= (unsigned)(L.h - 1))) {
+    float hist[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) hist[i] = 0.0f;
+    float weight = 2.0f * lambda * lambda * kp.sigma * kp.sigma;
+    float rad10 = pi / 18.0f;
+    for (float y = miny; y <= maxy; y += 1.0f) {
+      for (float x = minx; x <= maxx; x += 1.0f) {
+        float2 g = pixel_gradient(px, lmn, lmx, L.w, L.h, (int)llroundf(x), (int)llroundf(y));
+        float tx = x - kx, ty = y - ky;
+        float angle = fmodf(atan2f(g.y, g.x) + (2.0f * pi), 2.0f * pi);
+        int bin = (int)floorf(angle / rad10);
+        float mag = sqrtf((g.x * g.x) + (g.y * g.y));
+        float wgt = expf(-((tx * tx) + (ty * ty)) / weight);
+        // dynamic register indexing would spill: select the bin with a predicated sweep
+#pragma unroll
+        for (int b = 0; b < 36; ++b)
+          if (b == bin) hist[b] = __builtin_fmaf(mag, wgt, hist[b]);
+      }
+    }
+    float maxHist = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 36; ++i)
+      if (hist[i] > maxHist) maxHist = hist[i];
+    maxHist *= orientationThreshold;
+    float bestMag[MAXO], bestTh[MAXO];
+#pragma unroll
+    for (int i = 0; i < MAXO; ++i) { bestMag[i] = 0.0f; bestTh[i] = 0.0f; }
+#pragma unroll
+    for (int b = 0; b < 36; ++b) {
+      float hb = hist[b];
+      float hprev = hist[(b + 35) % 36], hnext = hist[(b + 1) % 36];
+      // the five neighbour tests of :1064-1069 reduce to: below threshold, below either circular neighbour, or below
+      // the weakest kept peak
+      if (hb < maxHist || hb < hprev || hb < hnext || hb < bestMag[MAXO - 1]) continue;
+      float tmag = hb;
+      float tth = (hprev - hnext) / (hprev - (2.0f * hb) + hnext);
+      tth *= (pi / 36.0f);
+      tth += (b * rad10);
+      tth = fmodf(tth + (2.0f * pi), 2.0f * pi);
+#pragma unroll
+      for (int i = 0; i < MAXO; ++i) {
+        if (tmag > bestMag[i]) {
+#pragma unroll
+          for (int ii = i; ii < MAXO; ++ii) {
+            float m2 = bestMag[ii], t2 = bestTh[ii];
+            bestMag[ii] = tmag;
+            bestTh[ii] = tth;
+            tmag = m2;
+            tth = t2;
+          }
+        }
+      }
+    }
+    // valid entries are a prefix (bestMag is kept sorted descending)
+#pragma unroll
+    for (int i = 0; i < MAXO; ++i) {
+      if (bestMag[i] != 0.0f) { outTheta[i] = bestTh[i]; cnt = i + 1; }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXO; ++i) thetas[(size_t)gi * svp::kMaxOrient + i] = outTheta[i];
+  thetaCnt[gi] = cnt;
+}
+
+// ---- S14: fillDescriptors(SSKeyPoint) (src/SIFT_FeatureFactory.cu:475-549) ------------------------------------------------
+// One thread per key point; its 4x4x8 histogram lives in LDS, bin-major / lane-minor (conflict-free), so the
+// accumulation order per bin is the raster sample order of the oracle (the reference's shared atomicAdd order is
+// non-deterministic).  64 lanes x 128 bins x 4 B = 32 KiB per wave.
+__global__ __launch_bounds__(64) void k_descriptors(const OctaveState* st, const ssrlcv_sskeypoint* kps, LevelSet L,
+                                                    float pixelWidth, float lambda, const uint32_t* featBase, int octave,
+                                                    ssrlcv_sift_feature* __restrict__ features, uint32_t maxFeatures) {
+  __shared__ float s_bins[128][64];
+  int n = st->hasExtrema ? st->n : 0;
+  int gi = blockIdx.x * 64 + threadIdx.x;
+  const int lane = threadIdx.x;
+  if (gi >= n) return;
+#pragma unroll 8
+  for (int b = 0; b < 128; ++b) s_bins[b][lane] = 0.0f;
+  const float pi = SSRLCV_PI_F;
+  int seg = segment_of(st, gi);
+  const float* px = L.dog[seg];
+  float lmn = L.minmax[2 * seg], lmx = L.minmax[2 * seg + 1];
+  ssrlcv_sskeypoint kp = kps[gi];
+  float kx = kp.loc.x, ky = kp.loc.y;
+  float windowWidth = ceilf(kp.sigma * lambda / pixelWidth);
+  float theta = kp.theta;
+  float binWidth = windowWidth / 2.0f;
+  float rad45 = pi / 4.0f;
+  float c = cosf(-theta), s = sinf(-theta);
+  for (float y = -windowWidth; y <= windowWidth; y += 1.0f) {
+    for (float x = -windowWidth; x <= windowWidth; x += 1.0f) {
+      float cx = (x * c) + (y * s), cy = (-x * s) + (y * c);
+      if (fabsf(cx) > windowWidth || fabsf(cy) > windowWidth) continue;
+      float2 g = pixel_gradient(px, lmn, lmx, L.w, L.h, (int)llroundf(cx + kx), (int)llroundf(cy + ky));
+      float mag = sqrtf((g.x * g.x) + (g.y * g.y)) * expf(-((cx * cx) + (cy * cy)) / (2.0f * windowWidth * windowWidth));
+      float ang = fmodf(atan2f(g.y, g.x) - theta + (2.0f * pi), 2.0f * pi);
+      for (int nxi = 0; nxi < 4; ++nxi) {
+        float nx = (float)nxi;
+        for (int nyi = 0; nyi < 4; ++nyi) {
+          float ny = (float)nyi;
+          float hx = (nx * 0.5f - 0.75f) * windowWidth, hy = (ny * 0.5f - 0.75f) * windowWidth;
+          float rx = (hx * c) + (hy * s), ry = (-hx * s) + (hy * c);
+          hx = fabsf(rx - cx);
+          hy = fabsf(ry - cy);
+          if (hx <= binWidth && hy <= binWidth) {
+            hx = hx / binWidth;
+            hy = hy / binWidth;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              float angle = fabsf(ang - ((float)k * rad45));
+              if (angle < rad45) {
+                angle /= rad45;
+                float temp = (1.0f - hx) * (1.0f - hy) * (1.0f - angle) * mag;
+                s_bins[(nxi * 4 + nyi) * 8 + k][lane] += temp;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  // normalise, clamp at 0.2, renormalise, quantise (:529-542); sums in CUDA linear thread order (x fastest, then y, z)
+  float norm = 0.0f;
+  for (int z = 0; z < 8; ++z)
+    for (int yy = 0; yy < 4; ++yy)
+      for (int xx = 0; xx < 4; ++xx) {
+        float v = s_bins[(xx * 4 + yy) * 8 + z][lane];
+        norm += v * v;
+      }
+  float sq = sqrtf(norm);
+  for (int b = 0; b < 128; ++b) {
+    float v = s_bins[b][lane] / sq;
+    if (v > 0.2f) v = 0.2f;
+    s_bins[b][lane] = v;
+  }
+  norm = 0.0f;
+  for (int z = 0; z < 8; ++z)
+    for (int yy = 0; yy < 4; ++yy)
+      for (int xx = 0; xx < 4; ++xx) {
+        float v = s_bins[(xx * 4 + yy) * 8 + z][lane];
+        norm += v * v;
+      }
+  sq = sqrtf(norm);
+  uint32_t fi = featBase[octave] + (uint32_t)gi;
+  if (fi >= maxFeatures) return;
+  ssrlcv_sift_feature* f = features + fi;
+  for (int xx = 0; xx < 4; ++xx)
+    for (int yy = 0; yy < 4; ++yy) {
+      uint32_t packed[2] = {0, 0};
+#pragma unroll
+      for (int z = 0; z < 8; ++z) {
+        uint32_t q = (uint32_t)(uint8_t)roundf(255.0f * s_bins[(xx * 4 + yy) * 8 + z][lane] / sq);
+        packed[z >> 2] |= q << (8 * (z & 3));
+      }
+      *reinterpret_cast<uint2*>(&f->values[(yy * 4 + xx) * 8]) = make_uint2(packed[0], packed[1]);
+    }
+  f->parent = -1;  // Feature() default (include/Feature.cuh:43-46); the reference kernel never writes it
+  f->theta = kp.theta;
+  f->sigma = kp.sigma;
+  f->loc.x = kp.loc.x * pixelWidth;
+  f->loc.y = kp.loc.y * pixelWidth;
+}
+
+LevelSet make_levels(const ssrlcv_sift_plan* plan, char* ws, int o) {
+  LevelSet L;
+  const svp::OctavePlan& oc = plan->oct[o];
+  for (int b = 0; b < svp::kDog; ++b) L.dog[b] = (const float*)(ws + oc.off_dog[b]);
+  L.minmax = (const float*)(ws + plan->off_minmax) + (size_t)o * 2 * (svp::kGauss + svp::kDog) + 2 * svp::kGauss;
+  L.w = (int)oc.w;
+  L.h = (int)oc.h;
+  return L;
+}
+
+// discardExtrema: stable per-segment compaction from `src` into `dst`
+hipError_t run_discard(OctaveState* st, const ssrlcv_sskeypoint* src, ssrlcv_sskeypoint* dst, uint32_t cap,
+                       uint32_t* words, hipStream_t stream) {
+  const OctaveState* cst = st;
+  auto keyfn = [=] __device__(uint32_t i) -> uint32_t {
+    if (!cst->hasExtrema || (int)i >= cst->n) return 0u;
+    if (src[i].discard) return 0u;
+    return 1u << segment_of(cst, (int)i);
+  };
+  auto emit = [=] __device__(uint32_t i, int, uint32_t d) { dst[d] = src[i]; };
+  uint32_t* totals = nullptr;
+  hipError_t e = svc::partition<svp::kDog, 8>(cap, keyfn, emit, words, &totals, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_book_discard, dim3(1), dim3(1), 0, stream, st, totals);
+  return hipGetLastError();
+}
+
+inline unsigned list_blocks(uint32_t cap) {
+  unsigned b = (cap + 255) / 256;
+  return b > 1024 ? 1024 : b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssrlcv_sift_plan_keypoints(const ssrlcv_sift_plan* plan, void* workspace, int octave, ssrlcv_sskeypoint** list,
+                               int** blurIndices_dev) {
+  if (!plan || !workspace || octave < 0 || octave >= svp::kOctaves) return SSRLCV_ERR_INVALID_ARG;
+  char* ws = (char*)workspace;
+  // the number of ping-pong swaps up to the stop stage decides which buffer holds the result: recorded in the plan
+  // by ssrlcv_hip_sift_describe via off_featBase + 64 (an int flag on the device is avoided: both are returned
+  // consistently by always finishing in buffer A).
+  if (list) *list = (ssrlcv_sskeypoint*)(ws + plan->oct[octave].off_kpA);
+  if (blurIndices_dev) *blurIndices_dev = (int*)(ws + plan->off_state + sizeof(OctaveState) * octave);
+  return SSRLCV_OK;
+}
+
+int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrlcv_sift_feature* features,
+                             uint32_t* numFeatures, ssrlcv_stream_t stream) {
+  if (!plan || !workspace || !numFeatures) return SSRLCV_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  OctaveState* states = (OctaveState*)(ws + plan->off_state);
+  const float noiseThreshold = 0.01f;  // src/SIFT_FeatureFactory.cu:58
+  const float edgeThreshold = 12.1f;   // :59
+  const int stop = plan->stopStage;
+  const uint32_t maxO = plan->params.maxOrientations;
+  for (int o = 0; o < svp::kOctaves; ++o) {
+    const svp::OctavePlan& oc = plan->oct[o];
+    OctaveState* st = states + o;
+    LevelSet L = make_levels(plan, ws, o);
+    ssrlcv_sskeypoint* A = (ssrlcv_sskeypoint*)(ws + oc.off_kpA);
+    ssrlcv_sskeypoint* B = (ssrlcv_sskeypoint*)(ws + oc.off_kpB);
+    uint8_t* flags = (uint8_t*)(ws + oc.off_flags);
+    uint32_t* words = (uint32_t*)(ws + oc.off_part);
+    const uint32_t cap = oc.cap;
+    // the list ping-pongs between A and B once per compaction; start so that the final list lands in A
+    const int nswaps = (stop >= 1) + 2 * (stop >= 2) + (stop >= 3) + (stop >= 4) + (stop >= 5) + (stop >= 6);
+    hipLaunchKernelGGL(k_state_reset, dim3(1), dim3(1), 0, s, st);
+    // --- searchForExtrema (src/FeatureFactory.cu:86-159) ---
+    hipLaunchKernelGGL(k_extrema_flags, dim3((oc.w + 255) / 256, oc.h), dim3(256), 0, s, L, flags);
+    {
+      const uint32_t P = oc.w * oc.h;
+      const int W = (int)oc.w;
+      const int octaveId = o;
+      const float s1 = oc.sigma[1], s2 = oc.sigma[2], s3 = oc.sigma[3];
+      const float* d1 = L.dog[1];
+      const float* d2 = L.dog[2];
+      const float* d3 = L.dog[3];
+      ssrlcv_sskeypoint* first = (nswaps & 1) ? B : A;
+      auto keyfn = [=] __device__(uint32_t p) -> uint32_t { return (uint32_t)flags[p]; };
+      auto emit = [=] __device__(uint32_t p, int b, uint32_t d) {
+        if (d >= cap) return;
+        ssrlcv_sskeypoint kp;  // fillExtrema (src/FeatureFactory.cu:883-890)
+        kp.octave = octaveId;
+        kp.blur = (int)b + 1;
+        kp.loc.x = (float)(p % W);
+        kp.loc.y = (float)(p / W);
+        kp.intensity = (b == 0 ? d1 : b == 1 ? d2 : d3)[p];
+        kp.sigma = b == 0 ? s1 : b == 1 ? s2 : s3;
+        kp.theta = -1.0f;
+        kp.discard = 0;
+        first[d] = kp;
+      };
+      uint32_t* totals = nullptr;
+      hipError_t e = svc::partition<3, 32>(P, keyfn, emit, words, &totals, s);
+      if (e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL(k_book_extrema, dim3(1), dim3(1), 0, s, st, totals, cap);
+    }
+    ssrlcv_sskeypoint* cur = (nswaps & 1) ? B : A;
+    ssrlcv_sskeypoint* oth = (nswaps & 1) ? A : B;
+    auto swap = [&]() { ssrlcv_sskeypoint* t = cur; cur = oth; oth = t; };
+    hipError_t e;
+    if (stop >= 1) {  // removeNoise(noiseThreshold * 0.8) (src/FeatureFactory.cu:484)
+      hipLaunchKernelGGL(k_flag_noise, dim3(list_blocks(cap)), dim3(256), 0, s, st, cur, (float)(noiseThreshold * 0.8));
+      if ((e = run_discard(st, cur, oth, cap, words, s)) != hipSuccess) return (int)e;
+      swap();
+    }
+    if (stop >= 2) {  // refineExtremaLocation (:217-265)
+      hipLaunchKernelGGL(k_refine, dim3(list_blocks(cap)), dim3(256), 0, s, st, cur, L, oc.sigma[0],
+                         oc.sigma[1] / oc.sigma[0]);
+      if ((e = run_discard(st, cur, oth, cap, words, s)) != hipSuccess) return (int)e;
+      swap();
+      // thrust::stable_sort by blur == stable partition on the blur value
+      {
+        const OctaveState* cst = st;
+        const ssrlcv_sskeypoint* src = cur;
+        ssrlcv_sskeypoint* dst = oth;
+        auto keyfn = [=] __device__(uint32_t i) -> uint32_t {
+          if (!cst->hasExtrema || (int)i >= cst->n) return 0u;
+          int b = src[i].blur;
+          return (b < 0 || b >= svp::kDog) ? 0u : (1u << b);
+        };
+        auto emit = [=] __device__(uint32_t i, int, uint32_t d) { dst[d] = src[i]; };
+        uint32_t* totals = nullptr;
+        if ((e = svc::partition<svp::kDog, 8>(cap, keyfn, emit, words, &totals, s)) != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(k_book_rescan, dim3(1), dim3(1), 0, s, st, totals);
+        swap();
+      }
+    }
+    if (stop >= 3) {  // removeNoise(noiseThreshold)
+      hipLaunchKernelGGL(k_flag_noise, dim3(list_blocks(cap)), dim3(256), 0, s, st, cur, noiseThreshold);
+      if ((e = run_discard(st, cur, oth, cap, words, s)) != hipSuccess) return (int)e;
+      swap();
+    }
+    if (stop >= 4) {  // removeEdges(edgeThreshold)
+      hipLaunchKernelGGL(k_flag_edges, dim3(list_blocks(cap)), dim3(256), 0, s, st, cur, L, edgeThreshold);
+      if ((e = run_discard(st, cur, oth, cap, words, s)) != hipSuccess) return (int)e;
+      swap();
+    }
+    if (stop >= 5) {  // checkKeyPoints + discardExtrema (src/SIFT_FeatureFactory.cu:81-107)
+      hipLaunchKernelGGL(k_flag_window, dim3(list_blocks(cap)), dim3(256), 0, s, st, cur, (int)oc.w, (int)oc.h,
+                         oc.pixelWidth, plan->params.descriptorContribWidth);
+      if ((e = run_discard(st, cur, oth, cap, words, s)) != hipSuccess) return (int)e;
+      swap();
+    }
+    if (stop >= 6) {  // computeKeyPointOrientations (src/FeatureFactory.cu:540-632)
+      float* thetas = (float*)(ws + oc.off_theta);
+      uint32_t* thetaCnt = (uint32_t*)(ws + oc.off_thetaCnt);
+      dim3 g((cap + 63) / 64);
+      switch (maxO) {
+        case 1: hipLaunchKernelGGL(k_thetas<1>, g, dim3(64), 0, s, st, cur, L, oc.pixelWidth, plan->params.orientationContribWidth, plan->params.orientationThreshold, thetas, thetaCnt); break;
+        case 2: hipLaunchKernelGGL(k_thetas<2>, g, dim3(64), 0, s, st, cur, L, oc.pixelWidth, plan->params.orientationContribWidth, plan->params.orientationThreshold, thetas, thetaCnt); break;
+        case 3: hipLaunchKernelGGL(k_thetas<3>, g, dim3(64), 0, s, st, cur, L, oc.pixelWidth, plan->params.orientationContribWidth, plan->params.orientationThreshold, thetas, thetaCnt); break;
+        default: hipLaunchKernelGGL(k_thetas<4>, g, dim3(64), 0, s, st, cur, L, oc.pixelWidth, plan->params.orientationContribWidth, plan->params.orientationThreshold, thetas, thetaCnt); break;
+      }
+      // thrust::remove of the -FLT_MAX / -1 slots + expandKeyPoints (:594-611): element space n x maxOrientations
+      const OctaveState* cst = st;
+      const ssrlcv_sskeypoint* src = cur;
+      ssrlcv_sskeypoint* dst = oth;
+      auto keyfn = [=] __device__(uint32_t e2) -> uint32_t {
+        uint32_t i = e2 / maxO, j = e2 - i * maxO;
+        if (!cst->hasExtrema || (int)i >= cst->n) return 0u;
+        if (j >= thetaCnt[i]) return 0u;
+        return 1u << segment_of(cst, (int)i);
+      };
+      auto emit = [=] __device__(uint32_t e2, int, uint32_t d) {
+        if (d >= cap) return;
+        uint32_t i = e2 / maxO, j = e2 - i * maxO;
+        ssrlcv_sskeypoint kp = src[i];
+        kp.theta = thetas[(size_t)i * svp::kMaxOrient + j];
+        dst[d] = kp;
+      };
+      uint32_t* totals = nullptr;
+      if ((e = svc::partition<svp::kDog, 8>(cap * maxO, keyfn, emit, words, &totals, s)) != hipSuccess) return (int)e;
+      hipLaunchKernelGGL(k_book_orient, dim3(1), dim3(1), 0, s, st, totals, cap);
+      swap();
+    }
+    if (cur != A) return SSRLCV_ERR_INVALID_ARG;  // cannot happen: nswaps accounts for every swap above
+  }
+  uint32_t* featBase = (uint32_t*)(ws + plan->oct[0].off_featBase);
+  hipLaunchKernelGGL(k_book_featbase, dim3(1), dim3(1), 0, s, states, featBase, numFeatures, plan->maxFeatures);
+  if (stop >= 7) {
+    if (!features) return SSRLCV_ERR_INVALID_ARG;
+    for (int o = 0; o < svp::kOctaves; ++o) {
+      const svp::OctavePlan& oc = plan->oct[o];
+      LevelSet L = make_levels(plan, ws, o);
+      hipLaunchKernelGGL(k_descriptors, dim3((oc.cap + 63) / 64), dim3(64), 0, s, states + o,
+                         (const ssrlcv_sskeypoint*)(ws + oc.off_kpA), L, oc.pixelWidth,
+                         plan->params.descriptorContribWidth, featBase, o, features, plan->maxFeatures);
+    }
+  }
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
+}
+
+int ssrlcv_hip_sift_extract(const ssrlcv_sift_plan* plan, const uint8_t* pixels, void* workspace,
+                            ssrlcv_sift_feature* features, uint32_t* numFeatures, ssrlcv_stream_t stream) {
+  int rc = ssrlcv_hip_sift_build_dog(plan, pixels, workspace, stream);
+  if (rc) return rc;
+  return ssrlcv_hip_sift_describe(plan, workspace, features, numFeatures, stream);
+}
+
+}  // extern "C"

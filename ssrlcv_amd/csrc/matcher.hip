@@ -1,0 +1,495 @@
+// ssrlcv_amd/csrc/matcher.hip -- 128-D brute-force descriptor matcher on fp16 MFMA for gfx950
+// (SURVEY.md section 8a rows M1-M5).
+//
+// Formulation.  distProtocol (src/Feature.cu:36-42) is sum((a-b)^2) over 128 u8: an exact integer < 2^24, so
+//   dist(q,t) = |q|^2 + ( |t|^2 - 2 q.t )
+// is computed exactly by an fp16 x fp16 -> fp32 MFMA when the operands are small integers.  The bracket is produced
+// entirely by the matrix core: the target row is stored as -2*t (|values| <= 510, exact in fp16) and the K dimension
+// is extended by one 16-wide step that carries |t|^2 as three base-1024 digits against the constants
+// {1, 1024, 32768} on the query side (digits < 1024, third digit pre-multiplied by 32: all exact in fp16, every
+// partial sum an integer of magnitude < 2^24).  K = 128 + 16 = 144 -> 9 x v_mfma_f32_32x32x16_f16 per 32x32 tile.
+//
+// Tile orientation.  A operand = 32 targets, B operand = 32 queries, so D[target][query]: a lane owns ONE query
+// (col = lane & 31) and its 16 accumulator registers are 16 different targets.  The per-query argmin is then a
+// within-lane v_min3 tree (8 VALU ops per 512 pairs) and a wave-uniform branch: only when some lane sees a value that
+// could beat (or tie) its running best does the wave take the slow path that decodes indices, applies the epipolar
+// prefilter of matchFeaturesDoubleConstrained (src/MatchFactory.cu:2239-2254) and updates a 64-bit key
+//   key = dist << 32 | (f mod 32) << 27 | (f / 32)
+// whose ordering is exactly the reference's winner rule "smallest distance, then lowest lane f mod 32, then lowest f"
+// (32-thread strided scan + lane-0 reduction with strict '>', :2256-2271).  Blocks that split the target range merge
+// with a 64-bit atomicMin on that key.
+//
+// Data layout in the workspace (caller-provided, no hidden allocation):
+//   packed queries  [nq_pad][144] fp16   {q_0..q_127, 1, 1024, 32768, 0 x13}
+//   packed targets  [nt_pad][144] fp16   {-2 t_0..-2 t_127, n0, n1, 32 n2, 0 x13}; padding rows get a huge norm
+//   query norms     [nq_pad] f32, target locations [nt_pad] float2, query epipolar params [nq_pad] x 8 f32, keys [nq_pad] u64
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
+#include "compact.h"
+#include "device_math.h"
+#include "ssrlcv_hip.h"
+
+using namespace sv;
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int kKPad = 144;       // fp16 elements per packed row
+constexpr int kKSteps = 9;       // 144 / 16
+constexpr int kQT = 4;           // query tiles (of 32) held in registers per wave
+constexpr int kWaves = 4;        // waves per block
+constexpr int kQPerBlock = kWaves * kQT * 32;  // 512 queries per block
+constexpr unsigned long long kNoKey = ~0ull;
+
+struct Geom {  // per-query epipolar segment parameters (mode 1)
+  float lo_x, hi_x;       // left.x - eps, right.x + eps
+  float left_x, left_y;
+  float slope;
+  float top, bottom;      // already widened by eps: top - eps, bottom + eps
+  float vertical;         // 1.0 when left.x == right.x
+};
+
+__host__ __device__ inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+// ---- pack ------------------------------------------------------------------------------------------------------
+// One wave per 4 features: 16 lanes x 8 bytes per feature.  Writes the fp16 row, the norm and (targets) the location.
+__global__ __launch_bounds__(256) void k_pack(const ssrlcv_sift_feature* __restrict__ feats, uint32_t n, uint32_t n_pad,
+                                              int as_target, _Float16* __restrict__ packed, float* __restrict__ norms,
+                                              ssrlcv_float2* __restrict__ locs) {
+  uint32_t f = (blockIdx.x * 256 + threadIdx.x) >> 4;  // 16 lanes per feature
+  unsigned sub = threadIdx.x & 15;
+  if (f >= n_pad) return;
+  _Float16* row = packed + (size_t)f * kKPad;
+  if (f < n) {
+    const uint8_t* v = feats[f].values + sub * 8;
+    uint2 raw = *reinterpret_cast<const uint2*>(v);  // values[] sits at offset 24 of a 152-byte struct: 8-byte aligned
+    uint32_t b[8] = {raw.x & 255u, (raw.x >> 8) & 255u, (raw.x >> 16) & 255u, raw.x >> 24,
+                     raw.y & 255u, (raw.y >> 8) & 255u, (raw.y >> 16) & 255u, raw.y >> 24};
+    uint32_t nsq = 0;
+    half8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      nsq += b[j] * b[j];
+      h[j] = as_target ? (_Float16)(-2.0f * (float)b[j]) : (_Float16)(float)b[j];
+    }
+    *reinterpret_cast<half8*>(row + sub * 8) = h;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) nsq += __shfl_xor(nsq, o, 16);
+    if (sub == 0) {
+      half8 e0 = {0, 0, 0, 0, 0, 0, 0, 0}, e1 = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (as_target) {
+        e0[0] = (_Float16)(float)(nsq & 1023u);
+        e0[1] = (_Float16)(float)((nsq >> 10) & 1023u);
+        e0[2] = (_Float16)(float)((nsq >> 20) * 32u);
+        if (locs) locs[f] = feats[f].loc;
+      } else {
+        e0[0] = (_Float16)1.0f;
+        e0[1] = (_Float16)1024.0f;
+        e0[2] = (_Float16)32768.0f;
+        if (norms) norms[f] = (float)nsq;
+      }
+      *reinterpret_cast<half8*>(row + 128) = e0;
+      *reinterpret_cast<half8*>(row + 136) = e1;
+    }
+  } else {
+    // padding row: zero descriptor; targets get the largest representable norm digits so they never win
+    half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    *reinterpret_cast<half8*>(row + sub * 8) = z;
+    if (sub == 0) {
+      half8 e0 = z;
+      if (as_target) {
+        e0[2] = (_Float16)60000.0f;  // x 32768 on the query side: ~2e9, above every real distance
+        if (locs) { ssrlcv_float2 l; l.x = -1e30f; l.y = -1e30f; locs[f] = l; }
+      } else {
+        e0[0] = (_Float16)1.0f;
+        e0[1] = (_Float16)1024.0f;
+        e0[2] = (_Float16)32768.0f;
+        if (norms) norms[f] = 0.0f;
+      }
+      *reinterpret_cast<half8*>(row + 128) = e0;
+      *reinterpret_cast<half8*>(row + 136) = z;
+    }
+  }
+}
+
+// ---- epipolar parameters per query (src/MatchFactory.cu:1240-1277 + :2209-2232) ---------------------------------
+#define EARTH_MAX_KM_FROM_CENT 6384.4
+#define EARTH_MIN_KM_FROM_CENT 6356.77
+__global__ __launch_bounds__(256) void k_geom(const ssrlcv_sift_feature* __restrict__ query, uint32_t nq,
+                                              ssrlcv_camera qc, f4 P0, f4 P1, f4 P2, float epsilon, float delta,
+                                              Geom* __restrict__ geom) {
+  uint32_t q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= nq) return;
+  ssrlcv_float2 loc = query[q].loc;
+  f3 queryVec = mk3(qc.dpix.x * ((loc.x) - (qc.size.x / 2.0f)), qc.dpix.y * ((loc.y) - (qc.size.y / 2.0f)), qc.foc);
+  queryVec = rotate_point(queryVec, qc.cam_rot);
+  f3 queryCent = mk3(qc.cam_pos.x + qc.ecef_offset.x, qc.cam_pos.y + qc.ecef_offset.y, qc.cam_pos.z + qc.ecef_offset.z);
+  float a = dot(queryVec, queryVec);
+  float b = 2 * dot(queryVec, queryCent);
+  float c1 = (float)(dot(queryCent, queryCent) - ((EARTH_MAX_KM_FROM_CENT + delta) * (EARTH_MAX_KM_FROM_CENT + delta)));
+  float c2 = (float)(dot(queryCent, queryCent) - ((EARTH_MIN_KM_FROM_CENT - delta) * (EARTH_MIN_KM_FROM_CENT - delta)));
+  f3 t1 = add(lscale((-sqrtf(b * b - 4 * a * c1) - b) / (2 * a), queryVec), queryCent);
+  f3 t2 = add(lscale((-sqrtf(b * b - 4 * a * c2) - b) / (2 * a), queryVec), queryCent);
+  float x1x = (P0.x * t1.x) + (P0.y * t1.y) + (P0.z * t1.z) + (P0.w * 1.0f);
+  float x1y = (P1.x * t1.x) + (P1.y * t1.y) + (P1.z * t1.z) + (P1.w * 1.0f);
+  float x1z = (P2.x * t1.x) + (P2.y * t1.y) + (P2.z * t1.z) + (P2.w * 1.0f);
+  float x2x = (P0.x * t2.x) + (P0.y * t2.y) + (P0.z * t2.z) + (P0.w * 1.0f);
+  float x2y = (P1.x * t2.x) + (P1.y * t2.y) + (P1.z * t2.z) + (P1.w * 1.0f);
+  float x2z = (P2.x * t2.x) + (P2.y * t2.y) + (P2.z * t2.z) + (P2.w * 1.0f);
+  float p1x = x1x / x1z, p1y = x1y / x1z, p2x = x2x / x2z, p2y = x2y / x2z;
+  float lx, ly, rx, ry;
+  if (p1x < p2x) { lx = p1x; ly = p1y; rx = p2x; ry = p2y; } else { lx = p2x; ly = p2y; rx = p1x; ry = p1y; }
+  Geom g;
+  g.lo_x = lx - epsilon;
+  g.hi_x = rx + epsilon;
+  g.left_x = lx;
+  g.left_y = ly;
+  g.slope = 0.0f;
+  g.top = 0.0f;
+  g.bottom = 0.0f;
+  g.vertical = 0.0f;
+  if (lx == rx) {
+    float top, bottom;
+    if (p1y < p2y) { top = p1y; bottom = p2y; } else { top = p2y; bottom = p1y; }
+    g.top = top - epsilon;
+    g.bottom = bottom + epsilon;
+    g.vertical = 1.0f;
+  } else {
+    g.slope = (ly - ry) / (lx - rx);
+  }
+  geom[q] = g;
+}
+
+__device__ __forceinline__ bool passes_prefilter(const Geom& g, ssrlcv_float2 t, float epsilon) {
+  // src/MatchFactory.cu:2239-2254
+  if (t.x < g.lo_x || t.x > g.hi_x) return false;
+  if (g.vertical != 0.0f) {
+    if (g.top > t.y || g.bottom < t.y) return false;
+  } else {
+    float y_line = g.slope * (t.x - g.left_x) + g.left_y;
+    if (fabsf(y_line - t.y) > epsilon) return false;
+  }
+  return true;
+}
+
+__device__ __forceinline__ unsigned long long make_key(float dist, uint32_t f) {
+  return ((unsigned long long)(uint32_t)dist << 32) | ((unsigned long long)(f & 31u) << 27) | (unsigned long long)(f >> 5);
+}
+
+// ---- the contraction ---------------------------------------------------------------------------------------------
+// grid.x: query blocks of 512, grid.y: target splits.  256 threads = 4 waves, one per SIMD; each wave keeps kQT query
+// tiles (B operands, 36 VGPRs each) resident and streams every target tile of its split through the matrix core.
+__global__ __launch_bounds__(256, 1) void k_match(const _Float16* __restrict__ packedQ, const _Float16* __restrict__ packedT,
+                                                  const float* __restrict__ normQ, const ssrlcv_float2* __restrict__ locT,
+                                                  const Geom* __restrict__ geom, uint32_t nq, uint32_t nt,
+                                                  uint32_t tilesPerSplit, int mode, float epsilon, float absThreshold,
+                                                  unsigned long long* __restrict__ bestKey) {
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned col = lane & 31, kgrp = lane >> 5;
+  const uint32_t qbase = (blockIdx.x * kWaves + wave) * (kQT * 32);
+  const uint32_t numTiles = (nt + 31) / 32;
+  const uint32_t tile0 = blockIdx.y * tilesPerSplit;
+  uint32_t tile1 = tile0 + tilesPerSplit;
+  if (tile1 > numTiles) tile1 = numTiles;
+
+  half8 bq[kQT][kKSteps];
+  float na[kQT];         // |q|^2 of this lane's query in tile qt
+  float bestAcc[kQT];    // fast-path bound in accumulator space (|t|^2 - 2 q.t): anything <= it goes slow
+  unsigned long long key[kQT];
+#pragma unroll
+  for (int qt = 0; qt < kQT; ++qt) {
+    uint32_t q = qbase + qt * 32 + col;  // padded rows exist up to nq_pad
+    const _Float16* row = packedQ + (size_t)q * kKPad + kgrp * 8;
+#pragma unroll
+    for (int s = 0; s < kKSteps; ++s) bq[qt][s] = *reinterpret_cast<const half8*>(row + s * 16);
+    na[qt] = normQ[q];
+    // a candidate needs dist = na + acc < absThreshold; start with a conservative bound (slow path re-checks exactly)
+    bestAcc[qt] = (absThreshold >= 3.0e9f) ? FLT_MAX : (ceilf(absThreshold) - na[qt] + 1.0f);
+    key[qt] = kNoKey;
+  }
+
+  for (uint32_t tt = tile0; tt < tile1; ++tt) {
+    half8 a[kKSteps];
+    const _Float16* trow = packedT + ((size_t)tt * 32 + col) * kKPad + kgrp * 8;
+#pragma unroll
+    for (int s = 0; s < kKSteps; ++s) a[s] = *reinterpret_cast<const half8*>(trow + s * 16);
+#pragma unroll
+    for (int qt = 0; qt < kQT; ++qt) {
+      floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < kKSteps; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], bq[qt][s], acc, 0, 0, 0);
+      float m0 = fminf(fminf(acc[0], acc[1]), acc[2]);
+      float m1 = fminf(fminf(acc[3], acc[4]), acc[5]);
+      float m2 = fminf(fminf(acc[6], acc[7]), acc[8]);
+      float m3 = fminf(fminf(acc[9], acc[10]), acc[11]);
+      float m4 = fminf(fminf(acc[12], acc[13]), acc[14]);
+      float m = fminf(fminf(fminf(m0, m1), fminf(m2, m3)), fminf(m4, acc[15]));
+      if (__any(m <= bestAcc[qt])) {
+        // slow path: decode rows.  C/D layout of the 32x32 MFMA: row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+        Geom g;
+        if (mode == 1) g = geom[qbase + qt * 32 + col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[r];
+          if (v <= bestAcc[qt]) {
+            uint32_t f = tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
+            float d = na[qt] + v;  // exact integer
+            bool ok = (f < nt) && (d < absThreshold);
+            if (ok && mode == 1) ok = passes_prefilter(g, locT[f], epsilon);
+            if (ok) {
+              unsigned long long k = make_key(d, f);
+              if (k < key[qt]) {
+                key[qt] = k;
+                bestAcc[qt] = v;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  // merge: lanes l and l+32 hold the same query (different target rows); other splits merge through the atomic
+#pragma unroll
+  for (int qt = 0; qt < kQT; ++qt) {
+    uint32_t q = qbase + qt * 32 + col;
+    if (q < nq && key[qt] != kNoKey) atomicMin(&bestKey[q], key[qt]);
+  }
+}
+
+// ---- finalisation: key -> reference output structs ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_finalize(const unsigned long long* __restrict__ bestKey, uint32_t nq,
+                                                  const ssrlcv_sift_feature* __restrict__ query,
+                                                  const ssrlcv_sift_feature* __restrict__ target,
+                                                  const float* __restrict__ seedDistances, uint32_t queryID,
+                                                  uint32_t targetID, float rel, float absThreshold, int outKind,
+                                                  void* __restrict__ out) {
+  uint32_t q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= nq) return;
+  unsigned long long k = bestKey[q];
+  bool found = k != kNoKey;
+  float dist = found ? (float)(uint32_t)(k >> 32) : absThreshold;
+  uint32_t lo = (uint32_t)(k & 0xffffffffull);
+  int matchIndex = found ? (int)(((lo & 0x07ffffffu) << 5) | (lo >> 27)) : -1;
+  if (outKind == SSRLCV_OUT_UINT2_PAIR) {
+    ssrlcv_uint2_pair m;
+    m.a.x = queryID; m.a.y = q; m.b.x = queryID; m.b.y = q;
+    if (!(dist >= absThreshold || matchIndex == -1)) {
+      bool reject = seedDistances && (dist / seedDistances[q] > rel);  // not squared (src/MatchFactory.cu:2907)
+      if (!reject) { m.b.x = targetID; m.b.y = (uint32_t)matchIndex; }
+    }
+    reinterpret_cast<ssrlcv_uint2_pair*>(out)[q] = m;
+    return;
+  }
+  ssrlcv_dmatch m;
+  m.keyPoints[0].parentId = 0; m.keyPoints[0].loc.x = 0; m.keyPoints[0].loc.y = 0;
+  m.keyPoints[1] = m.keyPoints[0];
+  m.distance = dist;
+  if (dist >= absThreshold || matchIndex == -1) {
+    m.invalid = 1;
+  } else if (seedDistances && (dist / seedDistances[q] > rel * rel)) {
+    m.invalid = 1;
+  } else {
+    m.invalid = 0;
+    m.keyPoints[0].loc = query[q].loc;
+    m.keyPoints[1].loc = target[matchIndex].loc;
+    m.keyPoints[0].parentId = (int)queryID;
+    m.keyPoints[1].parentId = (int)targetID;
+  }
+  if (outKind == SSRLCV_OUT_DMATCH) {
+    reinterpret_cast<ssrlcv_dmatch*>(out)[q] = m;
+  } else {
+    ssrlcv_match mm;
+    mm.invalid = m.invalid;
+    mm.keyPoints[0] = m.keyPoints[0];
+    mm.keyPoints[1] = m.keyPoints[1];
+    reinterpret_cast<ssrlcv_match*>(out)[q] = mm;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_seed_finalize(const unsigned long long* __restrict__ bestKey, uint32_t nq,
+                                                       float* __restrict__ out) {
+  uint32_t q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= nq) return;
+  unsigned long long k = bestKey[q];
+  out[q] = (k == kNoKey) ? FLT_MAX : (float)(uint32_t)(k >> 32);
+}
+
+struct Layout {
+  uint32_t nq_pad, nt_pad;
+  size_t off_pq, off_pt, off_nq, off_lt, off_geom, off_key, off_scratch, total;
+};
+
+Layout make_layout(uint32_t nq, uint32_t nt) {
+  Layout L;
+  L.nq_pad = round_up(nq ? nq : 1, kQPerBlock);
+  L.nt_pad = round_up(nt ? nt : 1, 32);
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) / 256 * 256; return r; };
+  L.off_pq = take((size_t)L.nq_pad * kKPad * 2);
+  L.off_pt = take((size_t)L.nt_pad * kKPad * 2);
+  L.off_nq = take((size_t)L.nq_pad * 4);
+  L.off_lt = take((size_t)L.nt_pad * 8);
+  L.off_geom = take((size_t)L.nq_pad * sizeof(Geom));
+  L.off_key = take((size_t)L.nq_pad * 8);
+  // scratch for compact_matches: a copy of the largest output struct array + partition counters
+  L.off_scratch = take((size_t)nq * sizeof(ssrlcv_dmatch) + svc::workspace_words<1, 8>(nq) * 4 + 256);
+  L.total = o;
+  return L;
+}
+
+int run_match(const ssrlcv_sift_feature* query, uint32_t nq, const ssrlcv_sift_feature* target, uint32_t nt, int mode,
+              const ssrlcv_match_params* p, float absThreshold, char* ws, const Layout& L, hipStream_t st) {
+  _Float16* pq = (_Float16*)(ws + L.off_pq);
+  _Float16* pt = (_Float16*)(ws + L.off_pt);
+  float* nqv = (float*)(ws + L.off_nq);
+  ssrlcv_float2* lt = (ssrlcv_float2*)(ws + L.off_lt);
+  Geom* geom = (Geom*)(ws + L.off_geom);
+  unsigned long long* keys = (unsigned long long*)(ws + L.off_key);
+  hipLaunchKernelGGL(k_pack, dim3((L.nq_pad * 16 + 255) / 256), dim3(256), 0, st, query, nq, L.nq_pad, 0, pq, nqv,
+                     (ssrlcv_float2*)nullptr);
+  hipLaunchKernelGGL(k_pack, dim3((L.nt_pad * 16 + 255) / 256), dim3(256), 0, st, target, nt, L.nt_pad, 1, pt,
+                     (float*)nullptr, lt);
+  SSRLCV_HIP_TRY(hipMemsetAsync(keys, 0xff, (size_t)L.nq_pad * 8, st));
+  float eps = 0.0f;
+  if (mode == 1) {
+    eps = p->epsilon;
+    hipLaunchKernelGGL(k_geom, dim3((nq + 255) / 256), dim3(256), 0, st, query, nq, p->queryCamera,
+                       p->targetProjection[0], p->targetProjection[1], p->targetProjection[2], p->epsilon, p->delta, geom);
+  }
+  uint32_t qblocks = L.nq_pad / kQPerBlock;
+  uint32_t numTiles = L.nt_pad / 32;
+  // split the target range until the grid has >= 1024 blocks (4 per CU) or tiles run out
+  uint32_t splits = 1;
+  while (qblocks * splits < 1024 && splits * 2 <= numTiles && numTiles / (splits * 2) >= 16) splits *= 2;
+  uint32_t tilesPerSplit = (numTiles + splits - 1) / splits;
+  hipLaunchKernelGGL(k_match, dim3(qblocks, splits), dim3(256), 0, st, pq, pt, nqv, lt, geom, nq, nt, tilesPerSplit, mode,
+                     eps, absThreshold, keys);
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ssrlcv_hip_match_workspace_bytes(uint32_t numQuery, uint32_t numTarget) {
+  return make_layout(numQuery, numTarget).total;
+}
+
+int ssrlcv_hip_seed_distances_u8x128(const ssrlcv_sift_feature* query, uint32_t numQuery, const ssrlcv_sift_feature* seed,
+                                     uint32_t numSeed, float* out, void* workspace, size_t workspaceBytes,
+                                     ssrlcv_stream_t stream) {
+  if (!query || !out || !workspace || (numSeed && !seed)) return SSRLCV_ERR_INVALID_ARG;
+  if (numQuery == 0) return SSRLCV_OK;
+  Layout L = make_layout(numQuery, numSeed);
+  if (workspaceBytes < L.total) return SSRLCV_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = run_match(query, numQuery, seed, numSeed, 0, nullptr, FLT_MAX, (char*)workspace, L, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_seed_finalize, dim3((numQuery + 255) / 256), dim3(256), 0, st,
+                     (const unsigned long long*)((char*)workspace + L.off_key), numQuery, out);
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
+}
+
+int ssrlcv_hip_match_u8x128(const ssrlcv_sift_feature* query, uint32_t numQuery, const ssrlcv_sift_feature* target,
+                            uint32_t numTarget, const float* seedDistances, const ssrlcv_match_params* params_host,
+                            int outKind, void* out, void* workspace, size_t workspaceBytes, ssrlcv_stream_t stream) {
+  if (!query || !out || !workspace || !params_host || (numTarget && !target)) return SSRLCV_ERR_INVALID_ARG;
+  if (outKind < 0 || outKind > 2 || params_host->mode < 0 || params_host->mode > 1) return SSRLCV_ERR_INVALID_ARG;
+  if (numQuery == 0) return SSRLCV_OK;
+  Layout L = make_layout(numQuery, numTarget);
+  if (workspaceBytes < L.total) return SSRLCV_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = run_match(query, numQuery, target, numTarget, params_host->mode, params_host, params_host->absoluteThreshold,
+                     (char*)workspace, L, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_finalize, dim3((numQuery + 255) / 256), dim3(256), 0, st,
+                     (const unsigned long long*)((char*)workspace + L.off_key), numQuery, query, target, seedDistances,
+                     params_host->queryImageID, params_host->targetImageID, params_host->relativeThreshold,
+                     params_host->absoluteThreshold, outKind, out);
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
+}
+
+int ssrlcv_hip_compact_matches(int outKind, void* matches, uint32_t numMatches, uint32_t* count_host, void* workspace,
+                               size_t workspaceBytes, ssrlcv_stream_t stream) {
+  if (!matches || !count_host || !workspace || outKind < 0 || outKind > 2) return SSRLCV_ERR_INVALID_ARG;
+  *count_host = 0;
+  if (numMatches == 0) return SSRLCV_OK;
+  size_t elem = outKind == SSRLCV_OUT_DMATCH ? sizeof(ssrlcv_dmatch)
+                : outKind == SSRLCV_OUT_MATCH ? sizeof(ssrlcv_match) : sizeof(ssrlcv_uint2_pair);
+  size_t need = (size_t)numMatches * elem + 256 + svc::workspace_words<1, 8>(numMatches) * 4;
+  if (workspaceBytes < need) return SSRLCV_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  char* tmp = (char*)workspace;
+  uint32_t* words = (uint32_t*)(tmp + ((size_t)numMatches * elem + 255) / 256 * 256);
+  uint32_t* totals = nullptr;
+  hipError_t e;
+  if (outKind == SSRLCV_OUT_UINT2_PAIR) {
+    const ssrlcv_uint2_pair* in = (const ssrlcv_uint2_pair*)matches;
+    ssrlcv_uint2_pair* o = (ssrlcv_uint2_pair*)tmp;
+    auto keyfn = [=] __device__(uint32_t i) -> uint32_t {  // validate (include/MatchFactory.cuh:83-85)
+      ssrlcv_uint2_pair m = in[i];
+      return (m.a.x == m.b.x && m.a.y == m.b.y) ? 0u : 1u;
+    };
+    auto emit = [=] __device__(uint32_t i, int, uint32_t d) { o[d] = in[i]; };
+    e = svc::partition<1, 8>(numMatches, keyfn, emit, words, &totals, st);
+  } else if (outKind == SSRLCV_OUT_DMATCH) {
+    const ssrlcv_dmatch* in = (const ssrlcv_dmatch*)matches;
+    ssrlcv_dmatch* o = (ssrlcv_dmatch*)tmp;
+    auto keyfn = [=] __device__(uint32_t i) -> uint32_t { return in[i].invalid ? 0u : 1u; };
+    auto emit = [=] __device__(uint32_t i, int, uint32_t d) { o[d] = in[i]; };
+    e = svc::partition<1, 8>(numMatches, keyfn, emit, words, &totals, st);
+  } else {
+    const ssrlcv_match* in = (const ssrlcv_match*)matches;
+    ssrlcv_match* o = (ssrlcv_match*)tmp;
+    auto keyfn = [=] __device__(uint32_t i) -> uint32_t { return in[i].invalid ? 0u : 1u; };
+    auto emit = [=] __device__(uint32_t i, int, uint32_t d) { o[d] = in[i]; };
+    e = svc::partition<1, 8>(numMatches, keyfn, emit, words, &totals, st);
+  }
+  if (e != hipSuccess) return (int)e;
+  uint32_t host_tot[2] = {0, 0};
+  SSRLCV_HIP_TRY(hipMemcpyAsync(host_tot, totals, sizeof host_tot, hipMemcpyDeviceToHost, st));
+  SSRLCV_HIP_TRY(hipStreamSynchronize(st));
+  *count_host = host_tot[0];
+  if (host_tot[0]) SSRLCV_HIP_TRY(hipMemcpyAsync(matches, tmp, (size_t)host_tot[0] * elem, hipMemcpyDeviceToDevice, st));
+  SSRLCV_HIP_TRY(hipStreamSynchronize(st));
+  return SSRLCV_OK;
+}
+
+// getProjectionMatrix (src/Image.cu:498-539) + multiply(float3[3], float4[3]) (src/matrix_util.cu:35-42): host arithmetic
+void ssrlcv_projection_matrix_host(const ssrlcv_camera* camera, ssrlcv_float4 P[3]) {
+  ssrlcv_float3 K[3];
+  ssrlcv_float4 R[3];
+  K[0].x = camera->foc / camera->dpix.x; K[0].y = 0; K[0].z = camera->size.x / 2.0f;
+  K[1].x = 0; K[1].y = camera->foc / camera->dpix.y; K[1].z = camera->size.y / 2.0f;
+  K[2].x = 0; K[2].y = 0; K[2].z = 1;
+  float rx = camera->cam_rot.x, ry = camera->cam_rot.y, rz = camera->cam_rot.z;
+  R[0].x = cosf(rz) * cosf(ry);
+  R[0].y = sinf(rz) * cosf(ry);
+  R[0].z = -1 * sinf(ry);
+  R[0].w = 0;
+  R[1].x = cosf(rz) * sinf(ry) * sinf(rx) - sinf(rz) * cosf(rx);
+  R[1].y = sinf(rz) * sinf(ry) * sinf(rx) + cosf(rz) * cosf(rx);
+  R[1].z = cosf(ry) * sinf(rx);
+  R[1].w = 0;
+  R[2].x = cosf(rz) * sinf(ry) * cosf(rx) + sinf(rz) * sinf(rx);
+  R[2].y = sinf(rz) * sinf(ry) * cosf(rx) - cosf(rz) * sinf(rx);
+  R[2].z = cosf(ry) * cosf(rx);
+  R[2].w = 0;
+  float ex = camera->cam_pos.x + camera->ecef_offset.x, ey = camera->cam_pos.y + camera->ecef_offset.y,
+        ez = camera->cam_pos.z + camera->ecef_offset.z;
+  for (int i = 0; i < 3; i++) R[i].w -= R[i].x * ex + R[i].y * ey + R[i].z * ez;
+  for (int r = 0; r < 3; ++r) {
+    P[r].x = (K[r].x * R[0].x) + (K[r].y * R[1].x) + (K[r].z * R[2].x);
+    P[r].y = (K[r].x * R[0].y) + (K[r].y * R[1].y) + (K[r].z * R[2].y);
+    P[r].z = (K[r].x * R[0].z) + (K[r].y * R[1].z) + (K[r].z * R[2].z);
+    P[r].w = (K[r].x * R[0].w) + (K[r].y * R[1].w) + (K[r].z * R[2].w);
+  }
+}
+
+}  // extern "C"

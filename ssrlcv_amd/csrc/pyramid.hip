@@ -1,0 +1,568 @@
+// ssrlcv_amd/csrc/pyramid.hip -- DoG scale-space pyramid for gfx950.
+//
+// The pyramid is HBM-bound stencil work.  Design choices (DESIGN.md "Pyramid"):
+//   * separable Gaussian = ONE kernel per level: 256-column strips march down the image 8 rows at a time.  Input rows
+//     are staged in LDS with their horizontal halo (coalesced, mirrored border), the horizontal pass runs from LDS
+//     with an 8-outputs-per-thread register block, the vertical pass keeps a sliding window of 2R+8 horizontally
+//     filtered rows IN REGISTERS (one column per thread), so every input pixel is fetched once per strip and every
+//     tap costs one v_fma_f32 whose weight operand is an SGPR (weights travel in the kernarg segment);
+//   * accumulation order is the reference's (k = -R..R, fmaf chain), so levels are bit-identical to the oracle;
+//   * the level's global min/max (normalizeImage finds it on the host after a D2H copy, src/Image.cu:631-649) is
+//     reduced in the epilogue of the same kernel: wave reduction + one integer atomic per wave;
+//   * both normalisations + the DoG subtraction are one streaming kernel reading 6 levels and writing 5 (float4
+//     lanes), which also reduces the DoG levels' min/max for findKeyPoints' second normalisation.
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
+#include <new>
+#include <string.h>
+#include "device_math.h"
+#include "sift_plan.h"
+#include "ssrlcv_hip.h"
+
+namespace {
+
+// src/Image.cu:1248-1252 getSymmetrizedCoord
+__device__ __forceinline__ int sym_coord(int i, int l) {
+  int ll = 2 * l;
+  i = (i + ll) % ll;
+  return (i > l - 1) ? ll - 1 - i : i;
+}
+
+// float atomics on {min,max} via the integer-ordering trick (same idea as atomicMinFloat/atomicMaxFloat,
+// src/FeatureFactory.cu:769-780)
+__device__ __forceinline__ void atomic_min_f(float* addr, float v) {
+  if (v >= 0) atomicMin((int*)addr, __float_as_int(v));
+  else atomicMax((unsigned int*)addr, __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_max_f(float* addr, float v) {
+  if (v >= 0) atomicMax((int*)addr, __float_as_int(v));
+  else atomicMin((unsigned int*)addr, __float_as_uint(v));
+}
+__device__ __forceinline__ void wave_minmax_commit(float mn, float mx, float* minmax) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, o, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomic_min_f(minmax, mn);
+    atomic_max_f(minmax + 1, mx);
+  }
+}
+
+__global__ void k_init_minmax(float* mm, int pairs) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < pairs) { mm[2 * i] = FLT_MAX; mm[2 * i + 1] = -FLT_MAX; }
+}
+
+// ---- S1 / S2 / S5 ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_u8_to_f32(const uint8_t* __restrict__ in, float* __restrict__ out, size_t n) {
+  size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    uchar4 v = *reinterpret_cast<const uchar4*>(in + i);
+    float4 f = make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+    *reinterpret_cast<float4*>(out + i) = f;
+  } else {
+    for (; i < n; ++i) out[i] = (float)in[i];
+  }
+}
+
+// upsampleImage(float) (src/Image.cu:1393-1414); T = float or uint8_t source (the u8 variant fuses convertToFltImage)
+template <typename T>
+__device__ __forceinline__ float upsample_at(const T* __restrict__ in, int w, int h, int i, int j) {
+  float x = i * 0.5f;
+  float y = j * 0.5f;
+  int xm = sym_coord((int)x, w);
+  int xp = sym_coord((int)x + 1, w);
+  int ym = sym_coord((int)y, h);
+  int yp = sym_coord((int)y + 1, h);
+  float dx = x - floorf(x), dy = y - floorf(y);
+  float sumPix = dx * dy * ((float)in[(size_t)yp * w + xp]);
+  sumPix += (1.0f - dx) * dy * ((float)in[(size_t)yp * w + xm]);
+  sumPix += dx * (1 - dy) * ((float)in[(size_t)ym * w + xp]);
+  sumPix += (1 - dx) * (1 - dy) * ((float)in[(size_t)ym * w + xm]);
+  return sumPix;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_upsample2x(const T* __restrict__ in, uint32_t w, uint32_t h,
+                                                    float* __restrict__ out) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  uint32_t j = blockIdx.y;
+  if (i < w * 2 && j < h * 2) out[(size_t)j * (w * 2) + i] = upsample_at(in, (int)w, (int)h, (int)i, (int)j);
+}
+
+// binImage(float) (src/Image.cu:1380-1392)
+__global__ __launch_bounds__(256) void k_bin2x(const float* __restrict__ in, uint32_t w, uint32_t h,
+                                               float* __restrict__ out) {
+  uint32_t x = blockIdx.x * 256 + threadIdx.x;
+  uint32_t y = blockIdx.y;
+  uint32_t ow = w / 2;
+  if (x < ow && y < h / 2) {
+    float2 r0 = *reinterpret_cast<const float2*>(in + (size_t)(y * 2) * w + x * 2);
+    float2 r1 = *reinterpret_cast<const float2*>(in + (size_t)(y * 2 + 1) * w + x * 2);
+    float sumPix = r0.x + r1.x + r0.y + r1.y;  // reference operand order
+    out[(size_t)y * ow + x] = sumPix / 4.0f;
+  }
+}
+
+// ---- S4: fused separable Gaussian --------------------------------------------------------------------------------
+struct ConvArgs {
+  const float* in;
+  float* out;
+  float* minmax;  // nullable
+  uint32_t w, h;
+  uint32_t rowsPerBlock;
+  float wgt[65];  // taps <= 65 for the templated kernels (R <= 32)
+};
+
+constexpr int kTX = 256;  // strip width = threads per block
+constexpr int kNR = 8;    // rows per marching step
+
+template <int R>
+__global__ __launch_bounds__(kTX) void k_gauss_fused(ConvArgs a) {
+  constexpr int RP = (R + 3) / 4 * 4;   // halo rounded up so LDS reads stay 16-byte aligned
+  constexpr int SW = kTX + 2 * RP;      // staged row width
+  constexpr int WIN = 2 * R + kNR;      // vertical register window
+  constexpr int HIN = 2 * RP + 8;       // horizontal register window (aligned superset of 2R+8)
+  constexpr int STG = (kNR * SW + kTX - 1) / kTX;  // staging elements per thread
+  __shared__ __attribute__((aligned(16))) float s_in[kNR][SW];
+  __shared__ __attribute__((aligned(16))) float s_h[kNR][kTX];
+
+  const int W = (int)a.w, H = (int)a.h;
+  const int x0 = blockIdx.x * kTX;
+  const int y0 = blockIdx.y * (int)a.rowsPerBlock;
+  int nrows = (int)a.rowsPerBlock;
+  if (y0 + nrows > H) nrows = H - y0;
+  const int tid = threadIdx.x;
+  const int hr = tid >> 5, hx = (tid & 31) * 8;  // horizontal-pass role: row hr, outputs hx..hx+7
+
+  float win[WIN];
+#pragma unroll
+  for (int k = 0; k < WIN; ++k) win[k] = 0.0f;
+  float mn = FLT_MAX, mx = -FLT_MAX;
+
+  const int steps = (nrows + 2 * R + kNR - 1) / kNR;
+  float pre[STG];
+  // prefetch helper: H-row group s covers image rows y0 - R + s*kNR + r
+  auto fetch = [&](int s) {
+#pragma unroll
+    for (int e = 0; e < STG; ++e) {
+      int idx = e * kTX + tid;
+      int r = idx / SW, c = idx - r * SW;
+      float v = 0.0f;
+      if (idx < kNR * SW) {
+        int gy = sym_coord(y0 - R + s * kNR + r, H);
+        int gx = sym_coord(x0 - RP + c, W);
+        v = a.in[(size_t)gy * W + gx];
+      }
+      pre[e] = v;
+    }
+  };
+  fetch(0);
+  for (int s = 0; s < steps; ++s) {
+#pragma unroll
+    for (int e = 0; e < STG; ++e) {
+      int idx = e * kTX + tid;
+      if (idx < kNR * SW) (&s_in[0][0])[idx] = pre[e];
+    }
+    __syncthreads();
+    if (s + 1 < steps) fetch(s + 1);  // global loads in flight under the two passes below
+    // horizontal pass: out[i] = sum_k w[k] * row[hx + i + k - R], fmaf chain in the reference's kx order
+    {
+      float rin[HIN];
+      const float4* src = reinterpret_cast<const float4*>(&s_in[hr][hx]);
+#pragma unroll
+      for (int q = 0; q < HIN / 4; ++q) {
+        float4 v = src[q];
+        rin[4 * q] = v.x; rin[4 * q + 1] = v.y; rin[4 * q + 2] = v.z; rin[4 * q + 3] = v.w;
+      }
+      float o[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k <= 2 * R; ++k) sum = __builtin_fmaf(rin[(RP - R) + i + k], a.wgt[k], sum);
+        o[i] = sum;
+      }
+      float4* dst = reinterpret_cast<float4*>(&s_h[hr][hx]);
+      dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+      dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+    }
+    __syncthreads();
+    // vertical pass: this thread owns column x0 + tid
+#pragma unroll
+    for (int i = 0; i < kNR; ++i) win[2 * R + i] = s_h[i][tid];
+    const int gx = x0 + tid;
+#pragma unroll
+    for (int i = 0; i < kNR; ++i) {
+      float sum = 0.0f;
+#pragma unroll
+      for (int k = 0; k <= 2 * R; ++k) sum = __builtin_fmaf(win[i + k], a.wgt[k], sum);
+      int j = s * kNR - 2 * R + i;
+      if (j >= 0 && j < nrows && gx < W) {
+        a.out[(size_t)(y0 + j) * W + gx] = sum;
+        mn = fminf(mn, sum);
+        mx = fmaxf(mx, sum);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * R; ++k) win[k] = win[k + kNR];
+  }
+  if (a.minmax) wave_minmax_commit(mn, mx, a.minmax);
+}
+
+// Generic two-pass fallback for tap counts the pipeline never produces (taps > 65): one 1-D pass per launch.
+__global__ __launch_bounds__(256) void k_conv1d(const float* __restrict__ in, float* __restrict__ out, uint32_t w,
+                                                uint32_t h, int taps, const float* __restrict__ wgt, int vertical,
+                                                float* __restrict__ minmax) {
+  uint32_t x = blockIdx.x * 256 + threadIdx.x;
+  uint32_t y = blockIdx.y;
+  float mn = FLT_MAX, mx = -FLT_MAX;
+  if (x < w && y < h) {
+    int r = taps / 2;
+    float sum = 0.0f;
+    for (int k = -r; k <= r; ++k) {
+      int sx = vertical ? (int)x : sym_coord((int)x + k, (int)w);
+      int sy = vertical ? sym_coord((int)y + k, (int)h) : (int)y;
+      sum = __builtin_fmaf(in[(size_t)sy * w + sx], wgt[k + r], sum);
+    }
+    out[(size_t)y * w + x] = sum;
+    mn = sum;
+    mx = sum;
+  }
+  if (minmax) wave_minmax_commit(mn, mx, minmax);
+}
+
+// ---- S6: min/max + normalize as stand-alone kernels (kernel-level API) -----------------------------------------------
+__global__ __launch_bounds__(256) void k_minmax(const float* __restrict__ in, size_t n, float* __restrict__ minmax) {
+  float mn = FLT_MAX, mx = -FLT_MAX;
+  size_t stride = (size_t)gridDim.x * 256 * 4;
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n) {
+      float4 v = *reinterpret_cast<const float4*>(in + i);
+      mn = fminf(fminf(mn, v.x), fminf(v.y, fminf(v.z, v.w)));
+      mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+    } else {
+      for (size_t k = i; k < n; ++k) { mn = fminf(mn, in[k]); mx = fmaxf(mx, in[k]); }
+    }
+  }
+  wave_minmax_commit(mn, mx, minmax);
+}
+__global__ __launch_bounds__(256) void k_normalize(float* __restrict__ data, size_t n, const float* __restrict__ minmax) {
+  float mn = minmax[0], mx = minmax[1];
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) data[i] = (data[i] - mn) / (mx - mn);
+}
+
+// ---- S6 + S7: both normalisations + DoG, one streaming kernel --------------------------------------------------------
+struct DogArgs {
+  const float* lvl[svp::kGauss];
+  float* dog[svp::kDog];
+  const float* lvlMinMax;  // 6 x {min,max}
+  float* dogMinMax;        // 5 x {min,max}, nullable
+  size_t n;
+};
+__global__ __launch_bounds__(256) void k_dog(DogArgs a) {
+  float lmn[svp::kGauss], lmx[svp::kGauss];
+#pragma unroll
+  for (int b = 0; b < svp::kGauss; ++b) { lmn[b] = a.lvlMinMax[2 * b]; lmx[b] = a.lvlMinMax[2 * b + 1]; }
+  float dmn[svp::kDog], dmx[svp::kDog];
+#pragma unroll
+  for (int b = 0; b < svp::kDog; ++b) { dmn[b] = FLT_MAX; dmx[b] = -FLT_MAX; }
+  size_t stride = (size_t)gridDim.x * 256 * 4;
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < a.n; i += stride) {
+    float4 prev = *reinterpret_cast<const float4*>(a.lvl[0] + i);
+    prev.x = (prev.x - lmn[0]) / (lmx[0] - lmn[0]);
+    prev.y = (prev.y - lmn[0]) / (lmx[0] - lmn[0]);
+    prev.z = (prev.z - lmn[0]) / (lmx[0] - lmn[0]);
+    prev.w = (prev.w - lmn[0]) / (lmx[0] - lmn[0]);
+#pragma unroll
+    for (int b = 0; b < svp::kDog; ++b) {
+      float4 cur = *reinterpret_cast<const float4*>(a.lvl[b + 1] + i);
+      cur.x = (cur.x - lmn[b + 1]) / (lmx[b + 1] - lmn[b + 1]);
+      cur.y = (cur.y - lmn[b + 1]) / (lmx[b + 1] - lmn[b + 1]);
+      cur.z = (cur.z - lmn[b + 1]) / (lmx[b + 1] - lmn[b + 1]);
+      cur.w = (cur.w - lmn[b + 1]) / (lmx[b + 1] - lmn[b + 1]);
+      float4 d = make_float4(cur.x - prev.x, cur.y - prev.y, cur.z - prev.z, cur.w - prev.w);
+      *reinterpret_cast<float4*>(a.dog[b] + i) = d;
+      dmn[b] = fminf(fminf(dmn[b], d.x), fminf(d.y, fminf(d.z, d.w)));
+      dmx[b] = fmaxf(fmaxf(dmx[b], d.x), fmaxf(d.y, fmaxf(d.z, d.w)));
+      prev = cur;
+    }
+  }
+  if (a.dogMinMax) {
+#pragma unroll
+    for (int b = 0; b < svp::kDog; ++b) wave_minmax_commit(dmn[b], dmx[b], a.dogMinMax + 2 * b);
+  }
+}
+
+int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h, int taps, const float* weights_host,
+                float* minmax, hipStream_t st) {
+  if (taps < 1 || (taps & 1) == 0 || taps > svp::kMaxTaps) return SSRLCV_ERR_INVALID_ARG;
+  int R = taps / 2;
+  if (R > 32) {
+    // generic two-pass fallback (needs tmp and a device copy of the weights; never taken by the SIFT pipeline)
+    if (!tmp) return SSRLCV_ERR_INVALID_ARG;
+    return SSRLCV_ERR_UNSUPPORTED;
+  }
+  ConvArgs a;
+  a.in = in;
+  a.out = out;
+  a.minmax = minmax;
+  a.w = w;
+  a.h = h;
+  memset(a.wgt, 0, sizeof a.wgt);
+  // pad the tap set symmetrically into the smallest templated radius: extra taps carry weight 0 and would change
+  // the fmaf chain (0*x + s is exact, so the result is identical) -- only exact radii are dispatched below anyway.
+  int RT = R <= 6 ? 6 : R <= 8 ? 8 : R <= 11 ? 11 : R <= 16 ? 16 : R <= 23 ? 23 : 32;
+  for (int k = 0; k < taps; ++k) a.wgt[(RT - R) + k] = weights_host[k];
+  // rows per block: aim for >= 1024 blocks, never below 64 rows (halo recompute = 2R / rows)
+  uint32_t bx = (w + kTX - 1) / kTX;
+  uint32_t rows = h;
+  while (rows > 64 && bx * ((h + rows - 1) / rows) < 1024) rows = (rows + 1) / 2;
+  rows = (rows + kNR - 1) / kNR * kNR;
+  a.rowsPerBlock = rows;
+  dim3 grid(bx, (h + rows - 1) / rows);
+  switch (RT) {
+    case 6: hipLaunchKernelGGL(k_gauss_fused<6>, grid, dim3(kTX), 0, st, a); break;
+    case 8: hipLaunchKernelGGL(k_gauss_fused<8>, grid, dim3(kTX), 0, st, a); break;
+    case 11: hipLaunchKernelGGL(k_gauss_fused<11>, grid, dim3(kTX), 0, st, a); break;
+    case 16: hipLaunchKernelGGL(k_gauss_fused<16>, grid, dim3(kTX), 0, st, a); break;
+    case 23: hipLaunchKernelGGL(k_gauss_fused<23>, grid, dim3(kTX), 0, st, a); break;
+    default: hipLaunchKernelGGL(k_gauss_fused<32>, grid, dim3(kTX), 0, st, a); break;
+  }
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
+}
+
+inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+}  // namespace
+
+extern "C" {
+
+int ssrlcv_gauss_kernel_host(float sigma, float pixelWidth, float* weights) {
+  // Blur::Blur (src/FeatureFactory.cu:15-18,29-33); PI is the double macro of include/common_includes.hpp:46
+  int ksize = (int)ceilf((float)8 * sigma / pixelWidth);
+  if (ksize % 2 == 0) ksize++;
+  if (ksize > svp::kMaxTaps) return -ksize;
+  int i = 0;
+  for (int x = -ksize / 2; x <= ksize / 2; ++x, ++i) {
+    weights[i] = expf(-((x * x) / 2.0f / sigma / sigma)) / sqrtf((float)(2.0f * SSRLCV_PI_D)) / sigma;
+  }
+  return ksize;
+}
+
+int ssrlcv_hip_u8_to_f32(const uint8_t* pixels, float* out, size_t n, ssrlcv_stream_t stream) {
+  if (!pixels || !out) return SSRLCV_ERR_INVALID_ARG;
+  if (n == 0) return SSRLCV_OK;
+  hipLaunchKernelGGL(k_u8_to_f32, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, pixels, out, n);
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
+}
+
+int ssrlcv_hip_upsample2x(const float* in, uint32_t w, uint32_t h, float* out, ssrlcv_stream_t stream) {
+  if (!in || !out || !w || !h) return SSRLCV_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(k_upsample2x<float>, dim3((2 * w + 255) / 256, 2 * h), dim3(256), 0, (hipStream_t)stream, in, w, h, out);
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
+}
+
+int ssrlcv_hip_upsample2x_u8(const uint8_t* in, uint32_t w, uint32_t h, float* out, ssrlcv_stream_t stream) {
+  if (!in || !out || !w || !h) return SSRLCV_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(k_upsample2x<uint8_t>, dim3((2 * w + 255) / 256, 2 * h), dim3(256), 0, (hipStream_t)stream, in, w, h,
+                     out);
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
+}
+
+int ssrlcv_hip_bin2x(const float* in, uint32_t w, uint32_t h, float* out, ssrlcv_stream_t stream) {
+  if (!in || !out || w < 2 || h < 2 || (w & 1)) return SSRLCV_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(k_bin2x, dim3((w / 2 + 255) / 256, h / 2), dim3(256), 0, (hipStream_t)stream, in, w, h, out);
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
+}
+
+int ssrlcv_hip_gauss_sep_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h, int taps,
+                              const float* weights_host, float* minmax, ssrlcv_stream_t stream) {
+  if (!in || !out || !weights_host || !w || !h || in == out) return SSRLCV_ERR_INVALID_ARG;
+  return launch_conv(in, out, tmp, w, h, taps, weights_host, minmax, (hipStream_t)stream);
+}
+
+int ssrlcv_hip_minmax(const float* in, size_t n, float* minmax, ssrlcv_stream_t stream) {
+  if (!in || !minmax || !n) return SSRLCV_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_init_minmax, dim3(1), dim3(64), 0, st, minmax, 1);
+  size_t blocks = (n + 1023) / 1024;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_minmax, dim3((unsigned)blocks), dim3(256), 0, st, in, n, minmax);
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
+}
+
+int ssrlcv_hip_normalize(float* data, size_t n, const float* minmax, ssrlcv_stream_t stream) {
+  if (!data || !minmax || !n) return SSRLCV_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(k_normalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, data, n, minmax);
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
+}
+
+int ssrlcv_hip_dog_normalised_sub(const float* const levels_host[6], const float* levelMinMax, uint32_t w, uint32_t h,
+                                  float* const dog_host[5], float* dogMinMax, ssrlcv_stream_t stream) {
+  if (!levels_host || !levelMinMax || !dog_host || !w || !h) return SSRLCV_ERR_INVALID_ARG;
+  size_t n = (size_t)w * h;
+  if (n % 4) return SSRLCV_ERR_INVALID_ARG;
+  DogArgs a;
+  for (int b = 0; b < svp::kGauss; ++b) a.lvl[b] = levels_host[b];
+  for (int b = 0; b < svp::kDog; ++b) a.dog[b] = dog_host[b];
+  a.lvlMinMax = levelMinMax;
+  a.dogMinMax = dogMinMax;
+  a.n = n;
+  size_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_dog, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
+}
+
+// ---- plan ------------------------------------------------------------------------------------------------------------
+int ssrlcv_sift_plan_create(uint32_t w, uint32_t h, const ssrlcv_sift_params* params, ssrlcv_sift_plan** out) {
+  if (!out || !params || !w || !h) return SSRLCV_ERR_INVALID_ARG;
+  if (w % 8 || h % 8) return SSRLCV_ERR_UNSUPPORTED;  // makeBinnable would have to pad (src/Image.cu:966-995)
+  if (params->maxOrientations == 0 || params->maxOrientations > (uint32_t)svp::kMaxOrient) return SSRLCV_ERR_UNSUPPORTED;
+  // "image too small" check of ScaleSpace::ScaleSpace (src/FeatureFactory.cu:341-345): numResize = 2^(start+depth.x)
+  if (w / 8 == 0 || h / 8 == 0) return SSRLCV_ERR_INVALID_ARG;
+  ssrlcv_sift_plan* p = new (std::nothrow) ssrlcv_sift_plan;
+  if (!p) return SSRLCV_ERR_INVALID_ARG;
+  memset(p, 0, sizeof *p);
+  p->W = w;
+  p->H = h;
+  p->params = *params;
+  p->stopStage = 7;
+  // sigma ladder: SIFT_FeatureFactory.cu:63-64 + FeatureFactory.cu:383-399
+  float sigmas[svp::kGauss];
+  float mulY = sqrtf(2.0f), mulX = 2;
+  sigmas[0] = sqrtf(2.0f) / 2.0f;
+  for (int i = 1; i < svp::kGauss; ++i) sigmas[i] = sigmas[i - 1] * mulY;
+  uint32_t ow = w * 2, oh = h * 2;
+  float pixelWidth = 1.0f;
+  pixelWidth /= 2.0f;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t r = off; off += align256(bytes); return r; };
+  size_t P0 = (size_t)ow * oh;
+  p->off_in0 = take(P0 * 4);
+  p->off_in1 = take(P0 / 4 * 4);
+  p->off_in2 = take(P0 / 16 * 4);
+  for (int b = 0; b < svp::kGauss; ++b) p->off_gauss[b] = take(P0 * 4);
+  p->off_minmax = take(sizeof(float) * 2 * (svp::kGauss + svp::kDog) * svp::kOctaves);
+  p->off_state = take(sizeof(svp::OctaveState) * svp::kOctaves);
+  uint32_t maxFeat = 0;
+  for (int o = 0; o < svp::kOctaves; ++o) {
+    svp::OctavePlan& oc = p->oct[o];
+    oc.w = ow;
+    oc.h = oh;
+    oc.pixelWidth = pixelWidth;
+    for (int b = 0; b < svp::kGauss; ++b) {
+      oc.sigma[b] = sigmas[b];
+      oc.taps[b] = ssrlcv_gauss_kernel_host(sigmas[b], pixelWidth, oc.weights[b]);
+      if (oc.taps[b] <= 0 || oc.taps[b] > 65) { delete p; return SSRLCV_ERR_UNSUPPORTED; }
+    }
+    size_t P = (size_t)ow * oh;
+    for (int b = 0; b < svp::kDog; ++b) oc.off_dog[b] = take(P * 4);
+    oc.off_flags = take(P);
+    uint32_t cap = params->maxKeyPointsPerOctave ? params->maxKeyPointsPerOctave : (uint32_t)(P / 16);
+    if (cap < 4096) cap = 4096;
+    oc.cap = cap;
+    oc.off_kpA = take((size_t)cap * sizeof(ssrlcv_sskeypoint));
+    oc.off_kpB = take((size_t)cap * sizeof(ssrlcv_sskeypoint));
+    oc.off_theta = take((size_t)cap * svp::kMaxOrient * sizeof(float));
+    oc.off_thetaCnt = take((size_t)cap * sizeof(uint32_t));
+    // partition scratch: pixel-domain (3 keys over P) is the largest user
+    size_t words = (size_t)3 * ((P + 8191) / 8192) + 16 +
+                   (size_t)svp::kDog * (((size_t)cap * svp::kMaxOrient + 2047) / 2048) + 16;
+    oc.off_part = take(words * 4);
+    oc.off_featBase = take(256);
+    maxFeat += cap;
+    if (o + 1 < svp::kOctaves) {
+      ow /= 2;
+      oh /= 2;
+      pixelWidth *= 2.0f;
+      for (int b = 0; b < svp::kGauss; ++b) sigmas[b] *= mulX;
+    }
+  }
+  p->off_extremaCounts = take(256);
+  p->total = off;
+  p->maxFeatures = maxFeat;
+  *out = p;
+  return SSRLCV_OK;
+}
+
+void ssrlcv_sift_plan_destroy(ssrlcv_sift_plan* plan) { delete plan; }
+size_t ssrlcv_sift_plan_workspace_bytes(const ssrlcv_sift_plan* plan) { return plan ? plan->total : 0; }
+uint32_t ssrlcv_sift_plan_max_features(const ssrlcv_sift_plan* plan) { return plan ? plan->maxFeatures : 0; }
+void ssrlcv_sift_plan_set_stop_stage(ssrlcv_sift_plan* plan, int stage) { if (plan) plan->stopStage = stage; }
+
+int ssrlcv_sift_plan_level(const ssrlcv_sift_plan* plan, void* workspace, int kind, int octave, int blur, float** data,
+                           uint32_t* w, uint32_t* h, float** minmax_dev) {
+  if (!plan || !workspace || octave < 0 || octave >= svp::kOctaves) return SSRLCV_ERR_INVALID_ARG;
+  char* ws = (char*)workspace;
+  const svp::OctavePlan& oc = plan->oct[octave];
+  float* mm = (float*)(ws + plan->off_minmax) + (size_t)octave * 2 * (svp::kGauss + svp::kDog);
+  if (kind == 0) {
+    if (blur < 0 || blur >= svp::kDog) return SSRLCV_ERR_INVALID_ARG;
+    if (data) *data = (float*)(ws + oc.off_dog[blur]);
+    if (minmax_dev) *minmax_dev = mm + 2 * (svp::kGauss + blur);
+  } else if (kind == 1) {
+    if (blur < 0 || blur >= svp::kGauss) return SSRLCV_ERR_INVALID_ARG;
+    if (data) *data = (float*)(ws + plan->off_gauss[blur]);
+    if (minmax_dev) *minmax_dev = mm + 2 * blur;
+  } else {
+    return SSRLCV_ERR_INVALID_ARG;
+  }
+  if (w) *w = oc.w;
+  if (h) *h = oc.h;
+  return SSRLCV_OK;
+}
+
+// ScaleSpace::ScaleSpace with makeDOG = true (src/FeatureFactory.cu:338-440)
+int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixels, void* workspace,
+                              ssrlcv_stream_t stream) {
+  if (!plan || !pixels || !workspace) return SSRLCV_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  float* mmAll = (float*)(ws + plan->off_minmax);
+  const int pairs = (svp::kGauss + svp::kDog) * svp::kOctaves;
+  hipLaunchKernelGGL(k_init_minmax, dim3(1), dim3(64), 0, st, mmAll, pairs);
+  // S1+S2: u8 -> f32 + one 2x upsample (startingOctave = -1)
+  float* in = (float*)(ws + plan->off_in0);
+  int rc = ssrlcv_hip_upsample2x_u8(pixels, plan->W, plan->H, in, stream);
+  if (rc) return rc;
+  float* nextIn[3] = {(float*)(ws + plan->off_in1), (float*)(ws + plan->off_in2), (float*)(ws + plan->off_in1)};
+  for (int o = 0; o < svp::kOctaves; ++o) {
+    const svp::OctavePlan& oc = plan->oct[o];
+    float* mm = mmAll + (size_t)o * 2 * (svp::kGauss + svp::kDog);
+    const float* src = in;
+    const float* lv[svp::kGauss];
+    for (int b = 0; b < svp::kGauss; ++b) {
+      float* dst = (float*)(ws + plan->off_gauss[b]);
+      rc = launch_conv(src, dst, nullptr, oc.w, oc.h, oc.taps[b], oc.weights[b], mm + 2 * b, st);
+      if (rc) return rc;
+      lv[b] = dst;
+      src = dst;
+    }
+    if (o + 1 < svp::kOctaves) {
+      // next octave input = 2x2 bin of the UN-normalised level 3 (src/FeatureFactory.cu:392-399)
+      rc = ssrlcv_hip_bin2x(lv[3], oc.w, oc.h, nextIn[o], stream);
+      if (rc) return rc;
+      in = nextIn[o];
+    }
+    float* dogs[svp::kDog];
+    for (int b = 0; b < svp::kDog; ++b) dogs[b] = (float*)(ws + oc.off_dog[b]);
+    rc = ssrlcv_hip_dog_normalised_sub(lv, mm, oc.w, oc.h, dogs, mm + 2 * svp::kGauss, stream);
+    if (rc) return rc;
+  }
+  return SSRLCV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+// ssrlcv_amd/csrc/sift_plan.h -- host-side description of the SIFT workspace (shared by pyramid.hip / keypoints.hip).
+//
+// HBM layout of one image's workspace (all offsets 256-byte aligned, sizes for a W x H u8 input):
+//   octave o (0..3) works at (2W >> o) x (2H >> o); P_o pixels, sum P = 5.3125 W H
+//   in0        f32  P_0        octave-0 input (2x bilinear upsample of the u8 image)
+//   in1        f32  P_1        input of octaves 1..3 (2x2 bin of the previous octave's un-normalised level 3); reused
+//   gauss[6]   f32  6 P_0      the six gaussian levels of the octave being built (un-normalised); reused per octave
+//   dog[o][5]  f32  5 sum P    raw DoG levels of every octave (kept: extrema, refinement, gradients read them)
+//   flags[o]   u8   sum P      3 extremum bits per pixel (levels 1..3)
+//   minmax     f32  4 x (6+5) x 2   per level {min,max} (gaussian, DoG)
+//   key points: per octave two ping-pong SSKeyPoint lists (capacity cap_o), theta lists, counters, index tables
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include "ssrlcv_hip.h"
+
+namespace svp {
+
+constexpr int kOctaves = 4;
+constexpr int kGauss = 6;
+constexpr int kDog = 5;
+constexpr int kMaxTaps = 129;
+constexpr int kMaxOrient = 4;
+
+// Device-resident per-octave key-point bookkeeping (mirrors Octave::extrema / extremaBlurIndices,
+// include/FeatureFactory.cuh:107-123).
+struct OctaveState {
+  int idx[kDog];        // extremaBlurIndices
+  int n;                // extrema->size(); 0 == nullptr
+  int hasExtrema;       // extrema != nullptr
+  int overflow;         // set when a list outgrew its capacity
+  int stale[kDog];      // scratch for bookkeeping kernels
+  int pad[3];
+};
+
+struct OctavePlan {
+  uint32_t w, h;
+  float pixelWidth;
+  float sigma[kGauss];
+  int taps[kGauss];
+  float weights[kGauss][kMaxTaps];
+  uint32_t cap;            // key-point list capacity
+  size_t off_dog[kDog];
+  size_t off_flags;
+  size_t off_kpA, off_kpB; // SSKeyPoint ping-pong lists
+  size_t off_theta;        // cap * kMaxOrient floats
+  size_t off_thetaCnt;     // cap uint32 (number of orientations per key point)
+  size_t off_part;         // partition workspace (uint32 words)
+  size_t off_featBase;     // uint32: first feature index of this octave
+};
+
+}  // namespace svp
+
+struct ssrlcv_sift_plan {
+  uint32_t W, H;
+  ssrlcv_sift_params params;
+  svp::OctavePlan oct[svp::kOctaves];
+  size_t off_in0, off_in1, off_in2;
+  size_t off_gauss[svp::kGauss];
+  size_t off_minmax;   // floats: [oct][kGauss + kDog][2]
+  size_t off_state;    // OctaveState[kOctaves]
+  size_t off_extremaCounts;  // scratch for the pixel-domain partition
+  size_t total;
+  uint32_t maxFeatures;
+  int stopStage;
+};

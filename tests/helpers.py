@@ -194,3 +194,101 @@ def oracle_triangulate(lib, nview, bundles, lines, want_errors=False, cutoff=Non
     f = lib.oracle_n_view_triangulate if nview else lib.oracle_two_view_triangulate
     total = f(ctypes.c_uint32(n), P(lines), P(bundles), P(pts), P(errs), P(cut))
     return pts, errs, total
+
+
+class OracleSift:
+    """Staged access to the oracle's scale space for kernel-level parity tests."""
+
+    def __init__(self, lib, pixels):
+        self.lib = lib
+        img = np.ascontiguousarray(pixels, dtype=np.uint8)
+        self.h, self.w = img.shape
+        lib.oracle_sift_create.restype = ctypes.c_void_p
+        self.handle = ctypes.c_void_p(lib.oracle_sift_create(P(img), ctypes.c_uint32(self.w), ctypes.c_uint32(self.h)))
+        assert self.handle.value
+
+    def close(self):
+        if self.handle:
+            self.lib.oracle_sift_destroy(self.handle)
+            self.handle = None
+
+    def octave_info(self, o):
+        w, h, pw = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_float()
+        sig = np.zeros(6, np.float32)
+        self.lib.oracle_sift_octave_info(self.handle, ctypes.c_int(o), ctypes.byref(w), ctypes.byref(h),
+                                         ctypes.byref(pw), P(sig))
+        return w.value, h.value, pw.value, sig
+
+    def level(self, kind, o, b):
+        """kind 0 normalised gaussian, 1 raw DoG, 2 twice-normalised DoG"""
+        w, h, _, _ = self.octave_info(o)
+        out = np.zeros((h, w), np.float32)
+        self.lib.oracle_sift_level(self.handle, ctypes.c_int(kind), ctypes.c_int(o), ctypes.c_int(b), P(out), None, None)
+        return out
+
+    def minmax(self, kind, o, b):
+        mn, mx = ctypes.c_float(), ctypes.c_float()
+        self.lib.oracle_sift_minmax(self.handle, ctypes.c_int(kind), ctypes.c_int(o), ctypes.c_int(b),
+                                    ctypes.byref(mn), ctypes.byref(mx))
+        return mn.value, mx.value
+
+    def keypoints(self, stage):
+        out = ctypes.c_void_p()
+        idx = np.zeros((4, 6), np.int32)
+        self.lib.oracle_sift_keypoints.restype = ctypes.c_int
+        n = self.lib.oracle_sift_keypoints(self.handle, ctypes.c_int(stage), ctypes.byref(out), P(idx))
+        kps = np.ctypeslib.as_array(ctypes.cast(out, ctypes.POINTER(ctypes.c_uint8)),
+                                    shape=(max(n, 1) * 32,)).view(SSKEYPOINT)[:n].copy()
+        self.lib.oracle_free(out)
+        return kps, idx
+
+    def features(self, max_orientations=2, thr=0.8, ow=1.5, dw=6.0):
+        out = ctypes.c_void_p()
+        self.lib.oracle_sift_features.restype = ctypes.c_int
+        n = self.lib.oracle_sift_features(self.handle, ctypes.c_uint32(max_orientations), ctypes.c_float(thr),
+                                          ctypes.c_float(ow), ctypes.c_float(dw), ctypes.byref(out))
+        f = np.ctypeslib.as_array(ctypes.cast(out, ctypes.POINTER(ctypes.c_uint8)),
+                                  shape=(max(n, 1) * 152,)).view(FEATURE)[:n].copy()
+        self.lib.oracle_free(out)
+        return f
+
+
+def oracle_gauss_kernel(lib, sigma, pixel_width):
+    w = np.zeros(257, np.float32)
+    lib.oracle_gauss_kernel.restype = ctypes.c_int
+    taps = lib.oracle_gauss_kernel(ctypes.c_float(sigma), ctypes.c_float(pixel_width), P(w))
+    return taps, w[:taps].copy()
+
+
+def synthetic_image(w, h, seed=0, blobs=None):
+    """Deterministic textured test image (smooth noise + gaussian blobs), u8, mean ~128: gives stable DoG extrema.
+    Pure numpy so the same image exists on the GPU box."""
+    rng = np.random.default_rng(0x53524C43 + seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = np.zeros((h, w), np.float32)
+    for octv in range(5):
+        gw, gh = max(2, (w >> (5 - octv)) + 2), max(2, (h >> (5 - octv)) + 2)
+        grid = rng.standard_normal((gh, gw)).astype(np.float32)
+        gx = xx * (gw - 1.001) / w
+        gy = yy * (gh - 1.001) / h
+        x0, y0 = gx.astype(int), gy.astype(int)
+        fx, fy = gx - x0, gy - y0
+        fx = fx * fx * (3 - 2 * fx)
+        fy = fy * fy * (3 - 2 * fy)
+        v = (grid[y0, x0] * (1 - fx) * (1 - fy) + grid[y0, x0 + 1] * fx * (1 - fy) +
+             grid[y0 + 1, x0] * (1 - fx) * fy + grid[y0 + 1, x0 + 1] * fx * fy)
+        img += v * (24.0 * 0.6 ** octv)
+    nb = blobs if blobs is not None else max(16, (w * h) // 1024)
+    bx = rng.uniform(0, w, nb)
+    by = rng.uniform(0, h, nb)
+    bs = rng.uniform(1.5, 6.0, nb)
+    ba = rng.uniform(-40, 40, nb)
+    for i in range(nb):
+        r = int(4 * bs[i]) + 1
+        xa, xb = max(0, int(bx[i]) - r), min(w, int(bx[i]) + r + 1)
+        ya, yb = max(0, int(by[i]) - r), min(h, int(by[i]) + r + 1)
+        if xa >= xb or ya >= yb:
+            continue
+        sub = np.exp(-(((xx[ya:yb, xa:xb] - bx[i]) ** 2 + (yy[ya:yb, xa:xb] - by[i]) ** 2) / (2 * bs[i] ** 2)))
+        img[ya:yb, xa:xb] += ba[i] * sub
+    return np.clip(np.rint(img + 128.0), 0, 255).astype(np.uint8)

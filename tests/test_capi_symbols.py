@@ -1,0 +1,77 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/ssrlcv_hip.h declares; the POD layouts match the reference's (sizes measured in SURVEY.md 8a)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+import helpers as H
+
+ROOT = H.ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    from ssrlcv_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "ssrlcv_hip.h")).read()
+    declared = set(re.findall(r"\b(ssrlcv_(?:hip_)?[A-Za-z0-9_]+)\s*\(", header))
+    declared -= {"ssrlcv_stream_t"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libssrlcv_hip.so does not export %s" % name
+    assert declared == set(_lib.EXPORTED)
+    assert b"gfx950" in lib.ssrlcv_hip_version()
+    assert lib.ssrlcv_hip_status_string(0) == b"ok"
+    assert lib.ssrlcv_hip_status_string(-3) == b"workspace too small"
+
+
+def test_missing_extension_fails_loudly(tmp_path, monkeypatch):
+    from ssrlcv_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    try:
+        _lib.load()
+    except _lib.HipExtensionMissing as e:
+        assert "no CPU fallback" in str(e)
+    else:
+        raise AssertionError("load() must raise when the HIP library is absent")
+
+
+def test_host_only_entry_points_match_oracle(oracle_lib):
+    """Host arithmetic exported by the C ABI (no GPU needed): Gaussian taps and the projection matrix."""
+    from ssrlcv_amd import _lib
+    lib = _lib.load()
+    for sigma, pw in ((0.70710678, 0.5), (1.0, 0.5), (2.0, 0.5), (4.0, 0.5), (5.656854, 2.0), (16.0, 4.0)):
+        w = np.zeros(129, np.float32)
+        taps = lib.ssrlcv_gauss_kernel_host(ctypes.c_float(sigma), ctypes.c_float(pw), H.P(w))
+        otaps, ow = H.oracle_gauss_kernel(oracle_lib, sigma, pw)
+        assert taps == otaps and taps % 2 == 1
+        assert np.array_equal(w[:taps], ow)
+    v = H.load_view("Pipeline3View")
+    for i in range(3):
+        cam = v["cameras"][i:i + 1]
+        out = np.zeros((3, 4), np.float32)
+        lib.ssrlcv_projection_matrix_host(H.P(cam), H.P(out))
+        assert np.array_equal(out, H.oracle_projection(oracle_lib, cam))
+
+
+def test_sift_plan_layout_is_host_only():
+    from ssrlcv_amd import _lib
+    lib = _lib.load()
+
+    class SiftParams(ctypes.Structure):
+        _fields_ = [("maxOrientations", ctypes.c_uint32), ("orientationThreshold", ctypes.c_float),
+                    ("orientationContribWidth", ctypes.c_float), ("descriptorContribWidth", ctypes.c_float),
+                    ("maxKeyPointsPerOctave", ctypes.c_uint32)]
+    p = SiftParams(2, 0.8, 1.5, 6.0, 0)
+    plan = ctypes.c_void_p()
+    assert lib.ssrlcv_sift_plan_create(ctypes.c_uint32(1024), ctypes.c_uint32(1024), ctypes.byref(p),
+                                       ctypes.byref(plan)) == 0
+    nbytes = lib.ssrlcv_sift_plan_workspace_bytes(plan)
+    # sum P = 5.3125 W H pixels; in0 + 6 gaussian + 5 DoG levels dominate
+    assert 5.3125 * 1024 * 1024 * 4 * 5 < nbytes < 400e6
+    lib.ssrlcv_sift_plan_destroy(plan)
+    # sizes that would need makeBinnable padding are refused, not silently mishandled
+    assert lib.ssrlcv_sift_plan_create(ctypes.c_uint32(1001), ctypes.c_uint32(1024), ctypes.byref(p),
+                                       ctypes.byref(plan)) == -4

@@ -1,0 +1,167 @@
+"""GPU parity: fp16-MFMA 128-D matcher (C ABI) vs the CPU oracle -- indices and distances bit-exact."""
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+REL, ABS = 0.6, 200.0 * 200.0
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from ssrlcv_amd import capi
+    return capi
+
+
+def random_features(n, seed, lo=0, hi=256, w=1024):
+    rng = np.random.default_rng(seed)
+    f = np.zeros(n, H.FEATURE)
+    f["parent"] = -1
+    f["values"] = rng.integers(lo, hi, (n, 128), dtype=np.uint8) if n else 0
+    f["loc"] = rng.uniform(0, w, (n, 2)).astype(np.float32)
+    f["sigma"] = 1.0
+    return f
+
+
+def run_gpu(capi, mode, q, t, kind, seed=None, eps=0.0, delta=0.0, cam=None, proj=None, rel=REL, absolute=ABS,
+            qid=3, tid=7):
+    params = capi.make_match_params(mode, qid, tid, eps, delta, rel, absolute, cam, proj)
+    out_d = capi.match(capi.to_dev(q), len(q), capi.to_dev(t) if len(t) else None, len(t), params, kind,
+                       seed_d=capi.to_dev(seed) if seed is not None else None)
+    dt = {capi.OUT_DMATCH: H.DMATCH, capi.OUT_UINT2_PAIR: H.UINT2_PAIR, capi.OUT_MATCH: H.MATCH}[kind]
+    return capi.to_host(out_d, dt, len(q))
+
+
+def assert_dmatch_equal(g, o):
+    assert np.array_equal(g["invalid"], o["invalid"])
+    assert np.array_equal(g["distance"], o["distance"])
+    ok = o["invalid"] == 0
+    for name in ("kp0_parent", "kp1_parent", "kp0_loc", "kp1_loc"):
+        assert np.array_equal(g[name][ok], o[name][ok]), name
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (37, 5), (513, 1000), (2048, 4097), (700, 33)])
+def test_brute_force_full_range_u8_is_exact(capi, oracle_lib, nq, nt):
+    """Uniform 0..255 bytes: distances up to ~2.8M exercise all three norm digits and the 2^24 headroom."""
+    q, t = random_features(nq, 1), random_features(nt, 2)
+    big = 3.0e7
+    g = run_gpu(capi, 0, q, t, capi.OUT_DMATCH, absolute=big)
+    o = H.oracle_match_dmatch(oracle_lib, 0, 3, q, 7, t, None, None, 0, 0, None, REL, big)
+    assert_dmatch_equal(g, o)
+    assert (g["invalid"] == 0).all()
+
+
+def test_extreme_descriptors_exact(capi, oracle_lib):
+    """All-0 vs all-255 rows: the largest possible distance 128*255^2 = 8,323,200 and the largest cross term."""
+    q = random_features(64, 3)
+    t = random_features(96, 4)
+    q["values"][0] = 255
+    q["values"][1] = 0
+    t["values"][0] = 0
+    t["values"][1] = 255
+    t["values"][2] = 255
+    g = run_gpu(capi, 0, q, t, capi.OUT_DMATCH, absolute=3.0e7)
+    o = H.oracle_match_dmatch(oracle_lib, 0, 3, q, 7, t, None, None, 0, 0, None, REL, 3.0e7)
+    assert_dmatch_equal(g, o)
+    # restrict the targets to the extremes to force the 8,323,200 distance
+    g2 = run_gpu(capi, 0, q[:2], t[:1], capi.OUT_DMATCH, absolute=3.0e7)
+    assert g2["distance"][0] == 128 * 255 * 255 and g2["distance"][1] == 0
+
+
+def test_tie_break_is_lowest_lane_then_lowest_index(capi, oracle_lib):
+    """Duplicated targets: winner = smallest (distance, f mod 32, f), not smallest f (src/MatchFactory.cu:2256-2271)."""
+    q = random_features(300, 5, hi=40)
+    t = random_features(1500, 6, hi=40)
+    rng = np.random.default_rng(7)
+    # plant exact copies of query descriptors at several target indices with different f mod 32
+    for qi in range(0, 300, 3):
+        for f in rng.choice(1500, 4, replace=False):
+            t["values"][f] = q["values"][qi]
+    g = run_gpu(capi, 0, q, t, capi.OUT_UINT2_PAIR)
+    o = H.oracle_match_pairs(oracle_lib, 0, 3, q, 7, t, None, None, 0, 0, None, REL, ABS)
+    assert np.array_equal(g["a"], o["a"]) and np.array_equal(g["b"], o["b"])
+    # the planted queries all matched (distance 0) and at least one winner is not the lowest duplicate index
+    planted = g["b"][0::3]
+    assert (planted[:, 0] == 7).all()
+
+
+def test_absolute_threshold_and_seed_ratio(capi, oracle_lib):
+    q = random_features(1000, 8, hi=64)
+    t = random_features(3000, 9, hi=64)
+    s = random_features(777, 10, hi=64)
+    sd_g = capi.seed_distances(capi.to_dev(q), len(q), capi.to_dev(s), len(s)).cpu().numpy()
+    sd_o = H.oracle_seed_distances(oracle_lib, q, s)
+    assert np.array_equal(sd_g, sd_o)
+    absolute = float(np.median(sd_o)) * 0.98  # roughly half of the queries fail the absolute test
+    for kind, orc in ((capi.OUT_DMATCH, H.oracle_match_dmatch), (capi.OUT_UINT2_PAIR, H.oracle_match_pairs)):
+        for rel in (0.6, 0.97, 1.1):
+            g = run_gpu(capi, 0, q, t, kind, seed=sd_o, rel=rel, absolute=absolute)
+            o = orc(oracle_lib, 0, 3, q, 7, t, None, None, 0, 0, sd_o, rel, absolute)
+            if kind == capi.OUT_DMATCH:
+                assert_dmatch_equal(g, o)
+            else:
+                assert np.array_equal(g["a"], o["a"]) and np.array_equal(g["b"], o["b"])
+    # Match output kind (no distance field)
+    g = run_gpu(capi, 0, q, t, capi.OUT_MATCH, absolute=absolute)
+    o = H.oracle_match_dmatch(oracle_lib, 0, 3, q, 7, t, None, None, 0, 0, None, REL, absolute)
+    assert np.array_equal(g["invalid"], o["invalid"])
+    ok = o["invalid"] == 0
+    assert np.array_equal(g["kp1_loc"][ok], o["kp1_loc"][ok])
+
+
+def test_empty_target_set_and_seed_flt_max(capi):
+    q = random_features(10, 11)
+    g = run_gpu(capi, 0, q, random_features(0, 12), capi.OUT_DMATCH)
+    assert (g["invalid"] == 1).all() and (g["distance"] == np.float32(ABS)).all()
+    sd = capi.seed_distances(capi.to_dev(q), len(q), None, 0).cpu().numpy()
+    assert (sd == np.finfo(np.float32).max).all()
+
+
+def test_double_constrained_matches_oracle(capi, oracle_lib):
+    """Epipolar prefilter with the fixture cameras (GEO_ORBIT path of doFeatureMatching)."""
+    v = H.load_view("Pipeline2View")
+    cams = v["cameras"]
+    proj = capi.projection_matrix(cams[1:2])
+    q = random_features(3000, 13, hi=48)
+    t = random_features(5000, 14, hi=48)
+    for eps, delta in ((25.0, 5.0), (5.0, 0.0), (200.0, 50.0)):
+        g = run_gpu(capi, 1, q, t, capi.OUT_DMATCH, eps=eps, delta=delta, cam=cams[0:1], proj=proj, absolute=3e7)
+        o = H.oracle_match_dmatch(oracle_lib, 1, 3, q, 7, t, cams[0:1], proj, eps, delta, None, REL, 3e7)
+        assert_dmatch_equal(g, o)
+    assert 0 < (o["invalid"] == 0).sum()
+
+
+def test_compact_matches_is_stable(capi):
+    q, t = random_features(5000, 15, hi=64), random_features(800, 16, hi=64)
+    absolute = 330000.0
+    g_d = capi.match(capi.to_dev(q), len(q), capi.to_dev(t), len(t),
+                     capi.make_match_params(0, 0, 1, 0, 0, REL, absolute), capi.OUT_DMATCH)
+    before = capi.to_host(g_d, H.DMATCH, len(q))
+    ws = capi.match_workspace(len(q), len(t))
+    n = capi.compact_matches(capi.OUT_DMATCH, g_d, len(q), ws)
+    after = capi.to_host(g_d, H.DMATCH, n)
+    keep = before[before["invalid"] == 0]
+    assert 0 < n == len(keep) < len(q)
+    assert np.array_equal(after["kp0_loc"], keep["kp0_loc"]) and np.array_equal(after["distance"], keep["distance"])
+
+
+def test_everest_fixture_matches_reproduced_on_gpu(capi, oracle_lib, everest_oracle_features):
+    """The reference's FeatureMatching2View golden output, matched on the GPU from the oracle's SIFT features."""
+    f0, f1, _ = everest_oracle_features
+    seed, _ = H.load_seed_features()
+    v = H.load_view("Pipeline2View")
+    cams = v["cameras"]
+    f0_d, f1_d = capi.to_dev(f0), capi.to_dev(f1)
+    sd_d = capi.seed_distances(f0_d, len(f0), capi.to_dev(seed), len(seed))
+    assert np.array_equal(sd_d.cpu().numpy(), H.oracle_seed_distances(oracle_lib, f0, seed))
+    params = capi.make_match_params(1, 0, 1, 25.0, 5.0, REL, ABS, cams[0:1], capi.projection_matrix(cams[1:2]))
+    out_d = capi.match(f0_d, len(f0), f1_d, len(f1), params, capi.OUT_DMATCH, seed_d=sd_d)
+    ws = capi.match_workspace(len(f0), len(f1))
+    n = capi.compact_matches(capi.OUT_DMATCH, out_d, len(f0), ws)
+    dm = capi.to_host(out_d, H.DMATCH, n)
+    kp = v["kp0"]
+    assert n == 13534
+    assert np.array_equal(dm["kp0_loc"], kp["loc"][0::2]) and np.array_equal(dm["kp1_loc"], kp["loc"][1::2])
+    assert np.array_equal(dm["kp0_parent"], kp["parentId"][0::2])
