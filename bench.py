@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- SIFT extract (Mpix/s) + 128-D brute-force match (Mmatches/s) on MI355X.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it
+under torch.distributed.run, one rank per GPU.  One STEP = one pass of the SIFT hot path
+(ssrlcv_hip_sift_extract: pyramid -> DoG -> extrema -> refinement -> orientation -> descriptors) over this rank's
+batch of synthetic u8 images already resident in HBM.  Ranks own different image pairs (weak scaling, no data-path
+collective inside the SIFT stage).  value = total input pixels of all ranks / max-over-ranks time.
+
+Besides the contract keys the JSON line carries
+  roofline      : the DoG-pyramid stage (ssrlcv_hip_sift_build_dog: 33 launches per image) against HBM, algorithmic
+                  bytes 362.25*W*H per image, duration from HIP events inside the timed steps;
+  matcher       : Mmatches/s of ssrlcv_hip_match_u8x128 (pairs compared / time) on Nq = Nt synthetic descriptors,
+                  with its own fp16-MFMA roofline (2*128*Nq*Nt flop);
+  cpu_baseline  : the CPU oracle (oracle/, a port restating the reference's kernels) timed on a bounded sample on
+                  rank 0's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (~2.5 PF)
+
+
+def synth_images(n, w, h, seed, device):
+    """Multi-scale smooth noise quantised to u8 (mean 128) -- generated on the GPU with torch (plumbing only)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(0x53524C43 + seed)
+    imgs = []
+    for _ in range(n):
+        img = torch.zeros(1, 1, h, w, device=device)
+        amp = 30.0
+        for k in range(1, 8):
+            gh, gw = max(2, h >> k), max(2, w >> k)
+            noise = torch.randn(1, 1, gh, gw, device=device, generator=g)
+            img += torch.nn.functional.interpolate(noise, size=(h, w), mode="bicubic", align_corners=False) * amp
+            amp *= 0.8
+        img = (img + 128.0).round().clamp(0, 255).to(torch.uint8).reshape(h, w).contiguous()
+        imgs.append(img)
+    return imgs
+
+
+def synth_descriptors(n, seed):
+    """uniform u8 vectors L2-normalised to ~255 like real SIFT descriptors, 25 % planted near-duplicates (+-3)."""
+    import helpers as H
+    rng = np.random.default_rng(seed)
+    v = rng.integers(0, 256, (n, 128)).astype(np.float32)
+    v = np.rint(v * (255.0 / np.sqrt((v * v).sum(1, keepdims=True)))).clip(0, 255)
+    f = np.zeros(n, H.FEATURE)
+    f["parent"] = -1
+    f["values"] = v.astype(np.uint8)
+    f["loc"] = rng.uniform(0, 4096, (n, 2)).astype(np.float32)
+    return f
+
+
+def bench_matcher(capi, torch, nq, nt, iters):
+    q = synth_descriptors(nq, 1)
+    t = synth_descriptors(nt, 2)
+    rng = np.random.default_rng(3)
+    dup = rng.choice(nq, nq // 4, replace=False)
+    tgt = rng.choice(nt, nq // 4, replace=False)
+    t["values"][tgt] = np.clip(q["values"][dup].astype(np.int32) + rng.integers(-3, 4, (len(dup), 128)), 0, 255)
+    q_d, t_d = capi.to_dev(q), capi.to_dev(t)
+    ws = capi.match_workspace(nq, nt)
+    out = capi.dev_bytes(nq * 48)
+    params = capi.make_match_params(0, 0, 1, 0.0, 0.0, 0.6, 200.0 * 200.0)
+    capi.match(q_d, nq, t_d, nt, params, capi.OUT_DMATCH, workspace=ws, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        capi.match(q_d, nq, t_d, nt, params, capi.OUT_DMATCH, workspace=ws, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    pairs = float(nq) * float(nt)
+    flops = 2.0 * 128.0 * pairs
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"value": pairs / (ms * 1e-3) / 1e6, "unit": "Mmatches/s", "nq": nq, "nt": nt, "ms": ms,
+            "output_matches_per_s": nq / (ms * 1e-3),
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / MFMA_F16_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "k_match (v_mfma_f32_32x32x16_f16), whole ssrlcv_hip_match_u8x128 call"}}
+
+
+def cpu_baseline(size):
+    """Oracle (CPU port of the reference kernels) SIFT on ONE size x size image: bounded sample of the workload."""
+    import helpers as H
+    lib = H.oracle()
+    img = H.synthetic_image(size, size, seed=21)
+    t0 = time.time()
+    f = H.oracle_sift(lib, img)
+    dt = time.time() - t0
+    return {"value": size * size / dt / 1e6, "unit": "Mpix/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "oracle_sift_generate on one %dx%d synthetic image (%d features, %.1f s, OpenMP on all host "
+                      "cores); the reference itself has no CPU compute path" % (size, size, len(f), dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=4096, help="image edge (config[2]: 2-view 4096x4096)")
+    ap.add_argument("--images", type=int, default=2, help="images per rank per step (one pair)")
+    ap.add_argument("--match-n", type=int, default=1 << 17, help="Nq = Nt of the stand-alone matcher measurement")
+    ap.add_argument("--match-iters", type=int, default=3)
+    ap.add_argument("--cpu-size", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-matcher", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    from ssrlcv_amd import capi  # raises if the HIP library is missing: no CPU fallback
+
+    W = H_ = args.size
+    dev = torch.device("cuda", torch.cuda.current_device())
+    imgs = synth_images(args.images, W, H_, seed=rank, device=dev)
+    plans = [capi.SiftPlan(W, H_) for _ in range(args.images)]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(ev=None):
+        for i, (p, im) in enumerate(zip(plans, imgs)):
+            if ev is not None:
+                ev[i][0].record()
+            p.build_dog(im)
+            if ev is not None:
+                ev[i][1].record()
+            p.describe()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    events = [[[torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)] for _ in plans]
+              for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    nfeat = [p.count() for p in plans]
+    overflow = 0
+    pyr_ms = float(np.mean([e[0].elapsed_time(e[1]) for st in events for e in st]))
+
+    if rank == 0:
+        pixels_per_step = world * args.images * W * H_
+        value = pixels_per_step * args.steps / dt / 1e6
+        b_pyr = 362.25 * W * H_  # bytes per image
+        achieved = b_pyr / (pyr_ms * 1e-3) / 1e9
+        line = {
+            "metric": "Mpix/s SIFT extract (+ Mmatches/s 128-D brute-force, see `matcher`)",
+            "value": value, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "2-view %dx%d synthetic pair per GPU: SIFT_FeatureFactory::generateFeatures "
+                                   "(sparse DoG path) on each image, pixels resident in HBM" % (W, H_),
+                       "images_per_gpu": args.images, "features_per_image": nfeat, "parallelism": "image-pair shard"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "DoG pyramid stage = ssrlcv_hip_sift_build_dog (upsample, 24 k_gauss_fused, 3 bin, "
+                                   "4 k_dog launches per image); algorithmic bytes 362.25*W*H per image",
+                         "ms_per_image": pyr_ms},
+        }
+        if not args.no_matcher:
+            line["matcher"] = bench_matcher(capi, torch, args.match_n, args.match_n, args.match_iters)
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_size)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
