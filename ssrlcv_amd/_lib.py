@@ -32,6 +32,8 @@ def load():
 # every symbol include/ssrlcv_hip.h declares (checked by tests/test_capi_symbols.py without a GPU)
 EXPORTED = [
     "ssrlcv_hip_version", "ssrlcv_hip_status_string",
+    "ssrlcv_hip_device_count", "ssrlcv_hip_malloc", "ssrlcv_hip_free", "ssrlcv_hip_host_malloc",
+    "ssrlcv_hip_host_free", "ssrlcv_hip_memcpy", "ssrlcv_hip_memset", "ssrlcv_hip_device_synchronize",
     "ssrlcv_hip_generate_bundles", "ssrlcv_hip_generate_pushbroom_bundles", "ssrlcv_hip_triangulate2",
     "ssrlcv_hip_triangulateN", "ssrlcv_hip_ba_sweep2_workspace_bytes", "ssrlcv_hip_ba_sweep2",
     "ssrlcv_projection_matrix_host", "ssrlcv_hip_match_workspace_bytes", "ssrlcv_hip_seed_distances_u8x128",

@@ -1,0 +1,251 @@
+// ssrlcv_amd/host/MatchFactory.hpp -- MatchFactory<T> with the reference's signatures (include/MatchFactory.cuh:23-309),
+// bound to the fp16-MFMA matcher of the HIP C ABI.  Provided for T = SIFT_Descriptor (the pipeline's only
+// instantiation, src/Pipeline.cu:175); Window_* descriptors, FeatureMatch outputs, the F-matrix constrained matcher,
+// disparity matchers and match-file IO are out of scope.
+//
+// Every method keeps upstream's memory-state contract: inputs are moved to the gpu for the call and restored to their
+// origin state before returning; results are fresh Unity objects on the gpu holding only the valid matches
+// (validateMatches = stable compaction).
+#pragma once
+#include <algorithm>
+#include <iterator>
+#include <vector>
+#include "Feature.hpp"
+#include "Image.hpp"
+
+namespace ssrlcv {
+
+struct uint2_pair { uint2 a; uint2 b; };
+struct KeyPoint { int parentId; float2 loc; };
+struct MultiMatch { unsigned int numKeyPoints; int index; };
+struct MatchSet {
+  ptr::value<Unity<KeyPoint>> keyPoints;
+  ptr::value<Unity<MultiMatch>> matches;
+};
+struct Match { bool invalid; KeyPoint keyPoints[2]; };
+struct DMatch : Match { float distance; };
+
+static_assert(sizeof(uint2_pair) == sizeof(ssrlcv_uint2_pair) && sizeof(KeyPoint) == sizeof(ssrlcv_keypoint) &&
+              sizeof(MultiMatch) == sizeof(ssrlcv_multimatch) && sizeof(Match) == sizeof(ssrlcv_match) &&
+              sizeof(DMatch) == sizeof(ssrlcv_dmatch), "match POD layouts");
+
+template <typename T>
+class MatchFactory {
+ private:
+  ptr::value<Unity<Feature<T>>> seedFeatures;
+
+  static ssrlcv_match_params make_params(int mode, ptr::value<Image> query, ptr::value<Image> target, float epsilon,
+                                         float delta, float rel, float absolute) {
+    ssrlcv_match_params p;
+    std::memset(&p, 0, sizeof p);
+    p.mode = mode;
+    p.queryImageID = (uint32_t)query->id;
+    p.targetImageID = (uint32_t)target->id;
+    p.epsilon = epsilon;
+    p.delta = delta;
+    p.relativeThreshold = rel;
+    p.absoluteThreshold = absolute;
+    std::memcpy(&p.queryCamera, &query->camera, sizeof(ssrlcv_camera));
+    if (mode == 1) {
+      ssrlcv_camera tc;
+      std::memcpy(&tc, &target->camera, sizeof tc);
+      ssrlcv_projection_matrix_host(&tc, p.targetProjection);  // getProjectionMatrix (src/Image.cu:498-539)
+    }
+    return p;
+  }
+
+  // common body of generate*Matches*: launch, validate (compact), shrink
+  template <typename OUT>
+  ptr::value<Unity<OUT>> run(int mode, int outKind, ptr::value<Image> query, ptr::value<Unity<Feature<T>>> queryFeatures,
+                             ptr::value<Image> target, ptr::value<Unity<Feature<T>>> targetFeatures, float epsilon,
+                             float delta, ptr::value<Unity<float>> seedDistances) {
+    static_assert(std::is_same<T, SIFT_Descriptor>::value, "MatchFactory is provided for SIFT_Descriptor");
+    MemoryState origin[2] = {queryFeatures->getMemoryState(), targetFeatures->getMemoryState()};
+    if (origin[0] != gpu) queryFeatures->setMemoryState(gpu);
+    if (origin[1] != gpu) targetFeatures->setMemoryState(gpu);
+    uint32_t nq = (uint32_t)queryFeatures->size(), nt = (uint32_t)targetFeatures->size();
+    const float* seed_d = nullptr;
+    MemoryState seedOrigin = null;
+    if (seedDistances != nullptr) {
+      if (seedDistances->size() != queryFeatures->size()) {
+        logger.err << "ERROR: seedDistances should have come from matching a seed image to queryFeatures";
+        std::exit(-1);
+      }
+      seedOrigin = seedDistances->getMemoryState();
+      if (seedOrigin != gpu) seedDistances->setMemoryState(gpu);
+      seed_d = seedDistances->device.get();
+    }
+    ssrlcv_match_params p = make_params(mode, query, target, epsilon, delta, relativeThreshold, absoluteThreshold);
+    size_t wsBytes = ssrlcv_hip_match_workspace_bytes(nq, nt);
+    ptr::device<unsigned char> ws((long)wsBytes);
+    ptr::value<Unity<OUT>> matches(nullptr, (unsigned long)nq, gpu);
+    HipSafeCall(ssrlcv_hip_match_u8x128(reinterpret_cast<const ssrlcv_sift_feature*>(queryFeatures->device.get()), nq,
+                                        reinterpret_cast<const ssrlcv_sift_feature*>(targetFeatures->device.get()), nt,
+                                        seed_d, &p, outKind, matches->device.get(), ws.get(), wsBytes, nullptr));
+    HipCheckError();
+    if (seedDistances != nullptr && seedOrigin != gpu) seedDistances->setMemoryState(seedOrigin);
+    // validateMatches (src/MatchFactory.cu:32-108)
+    uint32_t left = 0;
+    HipSafeCall(ssrlcv_hip_compact_matches(outKind, matches->device.get(), nq, &left, ws.get(), wsBytes, nullptr));
+    if (left == 0) {
+      logger.info << "No valid matches found";
+    } else {
+      logger.info.printf("%d valid matches found out of %lu original matches", (int)left, (unsigned long)nq);
+      ptr::device<OUT> validated((long)left);
+      HipSafeCall(ssrlcv_hip_memcpy(validated.get(), matches->device.get(), (size_t)left * sizeof(OUT), 2));
+      matches->setData(validated, left, gpu);
+    }
+    if (origin[0] != gpu) queryFeatures->setMemoryState(origin[0]);
+    if (origin[1] != gpu) targetFeatures->setMemoryState(origin[1]);
+    return matches;
+  }
+
+ public:
+  float absoluteThreshold;
+  float relativeThreshold;
+
+  MatchFactory(float relativeThreshold, float absoluteThreshold)
+      : absoluteThreshold(absoluteThreshold), relativeThreshold(relativeThreshold) {
+    seedFeatures = nullptr;
+  }
+  void setSeedFeatures(ptr::value<Unity<Feature<T>>> seedFeatures) { this->seedFeatures = seedFeatures; }
+
+  // src/MatchFactory.cu:315-346
+  ptr::value<Unity<float>> getSeedDistances(ptr::value<Unity<Feature<T>>> features) {
+    MemoryState origin = features->getMemoryState();
+    if (seedFeatures->getMemoryState() != gpu) seedFeatures->setMemoryState(gpu);
+    if (origin != gpu) features->setMemoryState(gpu);
+    uint32_t nq = (uint32_t)features->size(), ns = (uint32_t)seedFeatures->size();
+    ptr::value<Unity<float>> out(nullptr, (unsigned long)nq, gpu);
+    size_t wsBytes = ssrlcv_hip_match_workspace_bytes(nq, ns);
+    ptr::device<unsigned char> ws((long)wsBytes);
+    HipSafeCall(ssrlcv_hip_seed_distances_u8x128(reinterpret_cast<const ssrlcv_sift_feature*>(features->device.get()), nq,
+                                                 reinterpret_cast<const ssrlcv_sift_feature*>(seedFeatures->device.get()),
+                                                 ns, out->device.get(), ws.get(), wsBytes, nullptr));
+    HipCheckError();
+    if (origin != gpu) features->setMemoryState(origin);
+    return out;
+  }
+
+  // brute force (src/MatchFactory.cu:504-547, :754-800)
+  ptr::value<Unity<DMatch>> generateDistanceMatches(ptr::value<Image> query, ptr::value<Unity<Feature<T>>> queryFeatures,
+                                                    ptr::value<Image> target, ptr::value<Unity<Feature<T>>> targetFeatures,
+                                                    ptr::value<Unity<float>> seedDistances = nullptr) {
+    return run<DMatch>(0, SSRLCV_OUT_DMATCH, query, queryFeatures, target, targetFeatures, 0.0f, 0.0f, seedDistances);
+  }
+  ptr::value<Unity<uint2_pair>> generateMatchesIndexOnly(ptr::value<Image> query, ptr::value<Unity<Feature<T>>> queryFeatures,
+                                                         ptr::value<Image> target, ptr::value<Unity<Feature<T>>> targetFeatures,
+                                                         ptr::value<Unity<float>> seedDistances = nullptr) {
+    return run<uint2_pair>(0, SSRLCV_OUT_UINT2_PAIR, query, queryFeatures, target, targetFeatures, 0.0f, 0.0f, seedDistances);
+  }
+  // orbit double-constrained (src/MatchFactory.cu:599-651, :852-905)
+  ptr::value<Unity<DMatch>> generateDistanceMatchesDoubleConstrained(ptr::value<Image> query, ptr::value<Unity<Feature<T>>> queryFeatures,
+                                                                     ptr::value<Image> target, ptr::value<Unity<Feature<T>>> targetFeatures,
+                                                                     float epsilon, float delta,
+                                                                     ptr::value<Unity<float>> seedDistances = nullptr) {
+    return run<DMatch>(1, SSRLCV_OUT_DMATCH, query, queryFeatures, target, targetFeatures, epsilon, delta, seedDistances);
+  }
+  ptr::value<Unity<uint2_pair>> generateMatchesDoubleConstrainedIndexOnly(ptr::value<Image> query, ptr::value<Unity<Feature<T>>> queryFeatures,
+                                                                          ptr::value<Image> target, ptr::value<Unity<Feature<T>>> targetFeatures,
+                                                                          float epsilon, float delta,
+                                                                          ptr::value<Unity<float>> seedDistances = nullptr) {
+    return run<uint2_pair>(1, SSRLCV_OUT_UINT2_PAIR, query, queryFeatures, target, targetFeatures, epsilon, delta, seedDistances);
+  }
+
+  // convertMatchToRaw (src/MatchFactory.cu:257-280, :2921-2926): slice the DMatch base
+  ptr::value<Unity<Match>> getRawMatches(ptr::value<Unity<DMatch>> matches) {
+    MemoryState origin = matches->getMemoryState();
+    bool onGpu = origin == gpu || matches->getFore() == gpu;
+    if (onGpu && origin == gpu) matches->transferMemoryTo(cpu);
+    ptr::host<Match> raw((long)matches->size());
+    for (unsigned long i = 0; i < matches->size(); ++i) raw.get()[i] = Match(matches->host.get()[i]);
+    if (onGpu && origin == gpu) matches->clear(cpu);
+    ptr::value<Unity<Match>> out(raw, matches->size(), cpu);
+    if (onGpu) out->setMemoryState(gpu);
+    return out;
+  }
+
+  // src/MatchFactory.cu:907-1028: all pairs i<j on the GPU, adjacency merge on the host
+  MatchSet generateMatchesExhaustive(std::vector<ptr::value<Image>> images, std::vector<ptr::value<Unity<Feature<T>>>> features,
+                                     float epsilon, float delta, bool ordered = true, float estimatedOverlap = 0.0f) {
+    MatchSet matchSet;
+    matchSet.keyPoints = nullptr;
+    matchSet.matches = nullptr;
+    if (estimatedOverlap == 0) logger.warn << "WARNING: estimated overlap fraction of 0.0f requires unordered match interpolation";
+    std::vector<ptr::value<Unity<uint2_pair>>> matchIndices;
+    ptr::value<Unity<float>> seedDistances;
+    unsigned long long totalMatches = 0;
+    logger.info << "matching images";
+    int skipCounter = 0;
+    for (size_t q = 0; q + 1 < images.size(); ++q) {
+      if (seedFeatures != nullptr) seedDistances = getSeedDistances(features[q]);
+      for (size_t t = q + 1; t < images.size(); ++t) {
+        if (ordered && estimatedOverlap > 0.0f && ++skipCounter * (1 - estimatedOverlap) > 1.0f) continue;
+        matchIndices.push_back(generateMatchesDoubleConstrainedIndexOnly(images[q], features[q], images[t], features[t],
+                                                                         epsilon, delta, seedDistances));  // GEO_ORBIT == 1
+        totalMatches += matchIndices.back()->size();
+      }
+    }
+    if (totalMatches == 0) {
+      logger.err << "There were no matches found in the set of images, likely due to unreasonable threshold";
+      logger.err << "exiting...";
+      std::exit(0);
+    }
+    // adjacency lists per (query image, feature), filled in pair order
+    const size_t V = images.size();
+    std::vector<std::vector<std::vector<uint2>>> adj(V - 1);
+    for (size_t i = 0; i + 1 < V; ++i) adj[i].resize(features[i]->size());
+    for (auto& m : matchIndices) {
+      if (m->getMemoryState() != cpu) m->setMemoryState(cpu);
+      uint2_pair* h = m->host.get();
+      for (unsigned long p = 0; p < m->size(); ++p) adj[h[p].a.x][h[p].a.y].push_back(h[p].b);
+    }
+    std::vector<MemoryState> origin(V);
+    std::vector<std::vector<uint2>> multiMatch_vec;
+    for (size_t i = 0; i + 1 < V; ++i) {
+      origin[i] = features[i]->getMemoryState();
+      if (origin[i] != cpu) features[i]->setMemoryState(cpu);
+      for (size_t f = 0; i + 2 < V && f < features[i]->size(); ++f) {  // only images 0..V-3 seed multi-matches (:969)
+        std::vector<uint2>* a = &adj[i][f];
+        if (a->empty()) continue;
+        bool badMatch = false;
+        std::vector<uint2>* prev = a;
+        while (true) {
+          if (prev->begin()->x == V - 1) break;
+          std::vector<uint2>* next = &adj[prev->begin()->x][prev->begin()->y];
+          if (next->empty()) break;
+          std::vector<uint2> inter;
+          std::set_intersection(prev->begin(), prev->end(), next->begin(), next->end(), std::back_inserter(inter));
+          if (inter.size() != next->size()) { badMatch = true; break; }
+          else if (next->size() == 1) break;
+          else prev = next;
+        }
+        if (badMatch) { a->clear(); continue; }
+        std::vector<uint2> match;
+        match.push_back({(unsigned int)i, (unsigned int)f});
+        match.insert(match.end(), a->begin(), a->end());
+        multiMatch_vec.push_back(match);
+        for (auto m = a->begin(); m != a->end() - 1; ++m) {
+          if (m->x == V - 1) break;
+          adj[m->x][m->y].clear();
+        }
+      }
+    }
+    logger.info.printf("total matches found in set = %d", (int)multiMatch_vec.size());
+    matchSet.matches = ptr::value<Unity<MultiMatch>>(nullptr, (unsigned long)multiMatch_vec.size(), cpu);
+    std::vector<KeyPoint> kp_vec;
+    int index = 0, k = 0;
+    for (auto& m : multiMatch_vec) {
+      matchSet.matches->host.get()[k++] = {(unsigned int)m.size(), index};
+      index += (int)m.size();
+      for (auto& kp : m) kp_vec.push_back({(int)kp.x, features[kp.x]->host.get()[kp.y].loc});
+    }
+    matchSet.keyPoints = ptr::value<Unity<KeyPoint>>(nullptr, (unsigned long)kp_vec.size(), gpu);
+    HipSafeCall(ssrlcv_hip_memcpy(matchSet.keyPoints->device.get(), kp_vec.data(), kp_vec.size() * sizeof(KeyPoint), 0));
+    for (size_t i = 0; i + 1 < V; ++i)
+      if (origin[i] != cpu) features[i]->setMemoryState(origin[i]);
+    return matchSet;
+  }
+};
+
+}  // namespace ssrlcv

@@ -1,0 +1,185 @@
+// tests/cpp/host_mirror_test.cpp -- exercises the C++ host mirror of the reference API (ssrlcv_amd/host/*.hpp).
+//   typeinfo            print typeid name / hash_code of the checkpointable types (compared with the reference's .uty headers)
+//   cpu <dir>           Unity<T> state machine, exceptions, checkpoint round trip, Image .cpimg reader (no GPU needed)
+//   pipeline2 <dir>     (GPU) SIFT -> seed distances -> double-constrained match -> MatchSet -> triangulate -> BA, through
+//                       the reference's class API; inputs/outputs are .uty / .cpimg files in <dir>
+//   pipeline3 <dir>     (GPU) 3-view: generateMatchesExhaustive -> nViewTriangulate
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include "ssrlcv.hpp"
+
+using namespace ssrlcv;
+
+#define CHECK(cond)                                                                  \
+  do {                                                                               \
+    if (!(cond)) { std::fprintf(stderr, "CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #cond); return 1; } \
+  } while (0)
+
+template <typename T> static std::string cp_path(const std::string& dir, int id) {
+  return dir + "/" + std::to_string(id) + "_" + typeid(T).name() + ".uty";
+}
+
+static int typeinfo_mode() {
+  auto p = [](const char* label, const std::type_info& t) { std::printf("%s %s %zu\n", label, t.name(), t.hash_code()); };
+  p("uchar", typeid(unsigned char));
+  p("float", typeid(float));
+  p("float3", typeid(float3));
+  p("KeyPoint", typeid(KeyPoint));
+  p("MultiMatch", typeid(MultiMatch));
+  p("Feature", typeid(Feature<SIFT_Descriptor>));
+  p("Image", typeid(Image));
+  return 0;
+}
+
+static bool is_even(const float& v) { return ((int)v) % 2 == 0; }
+static bool kp_less(const KeyPoint& a, const KeyPoint& b) { return a.parentId < b.parentId; }
+
+static int cpu_mode(const std::string& dir) {
+  // construction, ownership, resize, clear
+  ptr::host<float> h(8);
+  for (int i = 0; i < 8; ++i) h.get()[i] = (float)i;
+  Unity<float> u(h, 8, cpu);
+  CHECK(u.size() == 8 && u.getMemoryState() == cpu && u.getFore() == cpu && u.host.get() == h.get());
+  u.resize(5);
+  CHECK(u.size() == 5 && u.host.get()[4] == 4.0f);
+  u.remove(is_even);
+  CHECK(u.size() == 2 && u.host.get()[0] == 1.0f && u.host.get()[1] == 3.0f);
+  // exceptions of the state machine (include/Unity.cuh:77-133)
+  bool threw = false;
+  try { Unity<float> n; n.transferMemoryTo(gpu); } catch (NullUnityException&) { threw = true; }
+  CHECK(threw);
+  threw = false;
+  try { Unity<float> n; n.setData(ptr::host<float>(2), 2, gpu); } catch (IllegalUnityTransition&) { threw = true; }
+  CHECK(threw);
+  threw = false;
+  try { Unity<float> n; n.setData(nullptr, 0, cpu); } catch (IllegalUnityTransition&) { threw = true; }
+  CHECK(threw);
+  threw = false;
+  try { u.setFore(gpu); } catch (IllegalUnityTransition&) { threw = true; }
+  CHECK(threw);
+  threw = false;
+  try { Unity<KeyPoint> bad(dir + "/missing.uty"); } catch (CheckpointException&) { threw = true; }
+  CHECK(threw);
+  // sort (stable) + checkpoint round trip in the reference's on-disk format
+  ptr::value<Unity<KeyPoint>> kps(nullptr, 6, cpu);
+  for (int i = 0; i < 6; ++i) kps->host.get()[i] = {5 - i / 2, {(float)i, (float)(10 * i)}};
+  kps->sort(kp_less);
+  CHECK(kps->host.get()[0].parentId == 3 && kps->host.get()[0].loc.x == 4.0f && kps->host.get()[1].loc.x == 5.0f);
+  kps->checkpoint(7, dir + "/");
+  Unity<KeyPoint> back(cp_path<KeyPoint>(dir, 7));
+  CHECK(back.size() == 6 && back.getMemoryState() == cpu);
+  CHECK(std::memcmp(back.host.get(), kps->host.get(), 6 * sizeof(KeyPoint)) == 0);
+  threw = false;
+  try { Unity<MultiMatch> wrong(cp_path<KeyPoint>(dir, 7)); } catch (CheckpointException&) { threw = true; }
+  CHECK(threw);
+  // files written by the Python side with the REFERENCE's header bytes must load: proves typeid compatibility
+  Unity<float3> pts(cp_path<float3>(dir, 0));
+  CHECK(pts.size() == 3 && pts.host.get()[2].z == 9.0f);
+  Image img(dir + "/0_" + typeid(Image).name() + ".cpimg", 0);
+  CHECK(img.id == 0 && img.size.x == 1024 && img.colorDepth == 1 && img.camera.foc > 0.85f && img.camera.foc < 0.87f);
+  // Feature() default state that Unity(nullptr, n, gpu) relies on
+  Feature<SIFT_Descriptor> f;
+  CHECK(f.parent == -1 && f.loc.x == -1.0f && f.descriptor.theta == 0.0f);
+  std::printf("cpu ok\n");
+  return 0;
+}
+
+static std::vector<ptr::value<Image>> load_images(const std::string& dir, int n) {
+  std::vector<ptr::value<Image>> images;
+  for (int i = 0; i < n; ++i) {
+    ptr::value<Image> im(dir + "/" + std::to_string(i) + "_" + typeid(Image).name() + ".cpimg", i);
+    im->pixels = ptr::value<Unity<unsigned char>>(dir + "/pixels_" + std::to_string(i) + ".uty");
+    images.push_back(im);
+  }
+  return images;
+}
+
+static int pipeline_mode(const std::string& dir, int views) {
+  std::vector<ptr::value<Image>> images = load_images(dir, views);
+  SIFT_FeatureFactory featureFactory(1.5f, 6.0f);  // src/Pipeline.cu:17
+  std::vector<ptr::value<Unity<Feature<SIFT_Descriptor>>>> allFeatures;
+  for (auto& im : images) {
+    auto feats = featureFactory.generateFeatures(im, false, 2, 0.8);
+    CHECK(feats->getMemoryState() == gpu && im->pixels->getMemoryState() == cpu);  // pixels restored to origin
+    feats->transferMemoryTo(cpu);  // src/Pipeline.cu:45
+    allFeatures.push_back(feats);
+    std::printf("features %d %lu\n", im->id, feats->size());
+  }
+  ptr::value<Unity<Feature<SIFT_Descriptor>>> seedFeatures(cp_path<Feature<SIFT_Descriptor>>(dir, -1));
+  MatchFactory<SIFT_Descriptor> matchFactory(0.6f, 200.0f * 200.0f);  // src/Pipeline.cu:175
+  matchFactory.setSeedFeatures(seedFeatures);
+  const float epsilon = 25.0f, delta = 5.0f;
+  MatchSet matchSet;
+  PointCloudFactory pcf;
+  float error = 0;
+  if (views == 2) {
+    auto seedDistances = matchFactory.getSeedDistances(allFeatures[0]);
+    auto dm = matchFactory.generateDistanceMatchesDoubleConstrained(images[0], allFeatures[0], images[1], allFeatures[1],
+                                                                    epsilon, delta, seedDistances);
+    CHECK(allFeatures[0]->getMemoryState() == both);  // origin state restored
+    auto matches = matchFactory.getRawMatches(dm);
+    matches->setMemoryState(cpu);
+    // 2-view MatchSet assembly (src/Pipeline.cu:198-224)
+    matchSet.keyPoints = ptr::value<Unity<KeyPoint>>(nullptr, matches->size() * 2, cpu);
+    matchSet.matches = ptr::value<Unity<MultiMatch>>(nullptr, matches->size(), cpu);
+    for (unsigned long i = 0; i < matches->size(); ++i) {
+      matchSet.keyPoints->host.get()[2 * i] = matches->host.get()[i].keyPoints[0];
+      matchSet.keyPoints->host.get()[2 * i + 1] = matches->host.get()[i].keyPoints[1];
+      matchSet.matches->host.get()[i] = {2, (int)(2 * i)};
+    }
+  } else {
+    matchSet = matchFactory.generateMatchesExhaustive(images, allFeatures, epsilon, delta);
+    matchSet.matches->setMemoryState(cpu);
+    matchSet.keyPoints->setMemoryState(cpu);
+  }
+  matchSet.keyPoints->checkpoint(100, dir + "/");
+  matchSet.matches->checkpoint(100, dir + "/");
+  BundleSet bundleSet = pcf.generateBundles(&matchSet, images);
+  CHECK(matchSet.matches->getMemoryState() == cpu && bundleSet.lines->getMemoryState() == cpu);
+  ptr::value<Unity<float3>> points = views == 2 ? pcf.twoViewTriangulate(bundleSet, &error) : pcf.nViewTriangulate(bundleSet, &error);
+  CHECK(points->getMemoryState() == cpu);
+  points->checkpoint(100, dir + "/");
+  std::printf("matches %lu error %f\n", matchSet.matches->size(), error);
+  if (views == 2) {
+    // doBundleAdjust (src/Pipeline.cu:371-384): 10 iterations requested
+    auto adjusted = pcf.BundleAdjustTwoView(&matchSet, images, 10, "");
+    CHECK(adjusted != nullptr && adjusted->size() == points->size());
+    adjusted->checkpoint(101, dir + "/");
+    // pseudo-inverse self check: H H+ H ~ H on a symmetric rank-deficient matrix
+    ptr::value<Unity<float>> H(nullptr, 144, cpu);
+    for (int i = 0; i < 12; ++i)
+      for (int j = 0; j < 12; ++j) H->host.get()[i * 12 + j] = (i < 9 && j < 9) ? (float)((i + 1) * (j + 1) % 7) + (i == j ? 20.0f : 0.0f) : 0.0f;
+    for (int i = 0; i < 12; ++i)
+      for (int j = 0; j < i; ++j) H->host.get()[i * 12 + j] = H->host.get()[j * 12 + i];
+    auto Hp = pcf.calculateImageHessianInverse(H);
+    double worst = 0;
+    for (int i = 0; i < 12; ++i)
+      for (int j = 0; j < 12; ++j) {
+        double acc = 0;
+        for (int a = 0; a < 12; ++a)
+          for (int b = 0; b < 12; ++b) acc += (double)H->host.get()[i * 12 + a] * Hp->host.get()[a * 12 + b] * H->host.get()[b * 12 + j];
+        worst = std::max(worst, std::fabs(acc - H->host.get()[i * 12 + j]));
+      }
+    std::printf("pinv residual %g\n", worst);
+    CHECK(worst < 1e-3);
+  }
+  std::printf("pipeline ok\n");
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  std::string mode = argc > 1 ? argv[1] : "typeinfo";
+  try {
+    if (mode == "typeinfo") return typeinfo_mode();
+    if (argc < 3) { std::fprintf(stderr, "usage: %s <mode> <dir>\n", argv[0]); return 2; }
+    if (mode == "cpu") return cpu_mode(argv[2]);
+    if (mode == "pipeline2") return pipeline_mode(argv[2], 2);
+    if (mode == "pipeline3") return pipeline_mode(argv[2], 3);
+  } catch (std::exception& e) {
+    std::fprintf(stderr, "exception: %s\n", e.what());
+    return 3;
+  }
+  return 2;
+}

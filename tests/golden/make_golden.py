@@ -51,6 +51,12 @@ def read_uty(path, dtype):
     return name, state, arr
 
 
+def read_uty_header(path):
+    raw = open(path, "rb").read(256)
+    nl = raw.index(b"\n")
+    return raw[:nl].decode(), int(np.frombuffer(raw, "<u8", 1, nl + 1)[0])
+
+
 def read_cpimg(path):
     raw = open(path, "rb").read()
     assert len(raw) == 240
@@ -87,6 +93,9 @@ def main():
         if view == "Pipeline2View":
             _, _, pts = read_uty(os.path.join(d, "2_6float3.uty"), FLOAT3)
             out["points2"] = pts
+        # raw 240-byte Image dumps (process-local pointer fields included, ignored by readers) for the .cpimg reader test
+        out["cpimg_raw"] = np.stack([np.frombuffer(open(os.path.join(d, "%d_N6ssrlcv5ImageE.cpimg" % i), "rb").read(),
+                                                   np.uint8) for i in range(nimg)])
         np.savez_compressed(os.path.join(OUT, view + ".npz"), **out)
         print(view, {k: v.shape for k, v in out.items()})
         # pixels (1024x1024 u8 each)
@@ -96,6 +105,16 @@ def main():
             pix["pixels_%d" % i] = p.reshape(1024, 1024)
         if view == "Pipeline3View":
             np.savez_compressed(os.path.join(OUT, "everest_pixels.npz"), **pix)
+    # typeid name + std::type_info::hash_code of every checkpointed type, as the reference wrote them
+    import json
+    d2 = os.path.join(REF, "Pipeline2View")
+    headers = {}
+    for fn in ("0_6float3.uty", "0_N6ssrlcv8KeyPointE.uty", "0_N6ssrlcv10MultiMatchE.uty",
+               "-1_N6ssrlcv7FeatureINS_15SIFT_DescriptorEEE.uty", "pixels/0_h.uty"):
+        name, h = read_uty_header(os.path.join(d2, fn))
+        headers[name] = h
+    json.dump(headers, open(os.path.join(OUT, "uty_headers.json"), "w"), indent=1, sort_keys=True)
+    print(headers)
     # seed features (identical apart from one byte between the two dirs)
     _, st, f2 = read_uty(os.path.join(REF, "Pipeline2View", "-1_N6ssrlcv7FeatureINS_15SIFT_DescriptorEEE.uty"), FEATURE)
     _, _, f3 = read_uty(os.path.join(REF, "Pipeline3View", "-1_N6ssrlcv7FeatureINS_15SIFT_DescriptorEEE.uty"), FEATURE)
