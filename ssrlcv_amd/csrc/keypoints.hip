@@ -289,189 +289,223 @@ __device__ __forceinline__ float2 pixel_gradient(const float* __restrict__ px, f
 }
 
 // ---- S13: computeThetas(SSKeyPoint) (src/FeatureFactory.cu:1004-1112) -----------------------------------------------------
-// One thread per key point, samples visited in the reference's order so each histogram bin accumulates in the same
-// sequence as the oracle.
+// One WAVE per key point (the reference: one thread).  The (2w+1)^2 window is swept one row (two rows when the window is
+// at most 32 samples wide) per step with lanes along x; the 36-bin histogram lives in LDS and is accumulated with
+// ds_add_f32.  Sample coordinates are generated by the same sequence of +1.0f additions as the reference's loops so
+// llroundf() sees identical values.  Peak tests run one bin per lane; only the insertion of the (1-4) surviving peaks
+// into the best-N list is sequential, in ascending bin order like the reference.
 template <int MAXO>
-__global__ __launch_bounds__(64) void k_thetas(const OctaveState* st, const ssrlcv_sskeypoint* kps, LevelSet L,
-                                               float pixelWidth, float lambda, float orientationThreshold,
-                                               float* __restrict__ thetas, uint32_t* __restrict__ thetaCnt) {
-  int n = st->hasExtrema ? st->n : 0;
-  int gi = blockIdx.x * 64 + threadIdx.x;
-  if (gi >= n) return;
+__global__ __launch_bounds__(256) void k_thetas(const OctaveState* st, const ssrlcv_sskeypoint* kps, LevelSet L,
+                                                float pixelWidth, float lambda, float orientationThreshold,
+                                                float* __restrict__ thetas, uint32_t* __restrict__ thetaCnt) {
+  __shared__ float s_hist[4][64];
+  const int n = st->hasExtrema ? st->n : 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* hist = s_hist[wave];
   const float pi = SSRLCV_PI_F;
-  int seg = segment_of(st, gi);
-  const float* px = L.dog[seg];
-  float lmn = L.minmax[2 * seg], lmx = L.minmax[2 * seg + 1];
-  ssrlcv_sskeypoint kp = kps[gi];
-  float kx = kp.loc.x, ky = kp.loc.y;
-  float windowWidth = ceilf(kp.sigma * 3.0f * lambda / pixelWidth);
-  float minx = kx - windowWidth, miny = ky - windowWidth, maxx = kx + windowWidth, maxy = ky + windowWidth;
-  uint32_t cnt = 0;
-  float outTheta[MAXO];
+  const float rad10 = pi / 18.0f;
+  for (int gi = blockIdx.x * 4 + wave; gi < n; gi += gridDim.x * 4) {
+    const int seg = segment_of(st, gi);
+    const float* px = L.dog[seg];
+    const float lmn = L.minmax[2 * seg], lmx = L.minmax[2 * seg + 1];
+    const ssrlcv_sskeypoint kp = kps[gi];
+    const float kx = kp.loc.x, ky = kp.loc.y;
+    const float windowWidth = ceilf(kp.sigma * 3.0f * lambda / pixelWidth);
+    const float minx = kx - windowWidth, miny = ky - windowWidth, maxx = kx + windowWidth, maxy = ky + windowWidth;
+    uint32_t cnt = 0;
+    float outTheta[MAXO];
 #pragma unroll
-  for (int i = 0; i < MAXO; ++i) outTheta[i] = -FLT_MAX;
-  if (!(minx < 0.0f || miny < 0.0f || maxx >= (unsigned)(L.w - 1) || maxy >= (unsigned)(L.h - 1))) {
-    float hist[36];
-#pragma unroll
-    for (int i = 0; i < 36; ++i) hist[i] = 0.0f;
-    float weight = 2.0f * lambda * lambda * kp.sigma * kp.sigma;
-    float rad10 = pi / 18.0f;
-    for (float y = miny; y <= maxy; y += 1.0f) {
-      for (float x = minx; x <= maxx; x += 1.0f) {
-        float2 g = pixel_gradient(px, lmn, lmx, L.w, L.h, (int)llroundf(x), (int)llroundf(y));
-        float tx = x - kx, ty = y - ky;
-        float angle = fmodf(atan2f(g.y, g.x) + (2.0f * pi), 2.0f * pi);
-        int bin = (int)floorf(angle / rad10);
-        float mag = sqrtf((g.x * g.x) + (g.y * g.y));
-        float wgt = expf(-((tx * tx) + (ty * ty)) / weight);
-        // dynamic register indexing would spill: select the bin with a predicated sweep
-#pragma unroll
-        for (int b = 0; b < 36; ++b)
-          if (b == bin) hist[b] = __builtin_fmaf(mag, wgt, hist[b]);
+    for (int i = 0; i < MAXO; ++i) outTheta[i] = -FLT_MAX;
+    if (!(minx < 0.0f || miny < 0.0f || maxx >= (unsigned)(L.w - 1) || maxy >= (unsigned)(L.h - 1))) {
+      hist[lane] = 0.0f;
+      __builtin_amdgcn_wave_barrier();
+      const float weight = 2.0f * lambda * lambda * kp.sigma * kp.sigma;
+      const int S = 2 * (int)windowWidth + 1;
+      const bool two = S <= 32;
+      const int c = two ? (lane & 31) : lane;
+      const int rsub = two ? (lane >> 5) : 0;
+      // x of this lane's column: minx + 1 + 1 ... (c additions), as the reference's inner loop produces it
+      float x = minx;
+      for (int i = 1; i < S; ++i)
+        if (i <= c) x += 1.0f;
+      float y = miny;
+      if (rsub) y += 1.0f;
+      const bool colOk = c < S;
+      for (int r0 = 0; r0 < S; r0 += (two ? 2 : 1)) {
+        const int r = r0 + rsub;
+        if (colOk && r < S) {
+          float2 g = pixel_gradient(px, lmn, lmx, L.w, L.h, (int)llroundf(x), (int)llroundf(y));
+          float tx = x - kx, ty = y - ky;
+          float angle = fmodf(atan2f(g.y, g.x) + (2.0f * pi), 2.0f * pi);
+          int bin = (int)floorf(angle / rad10);
+          float mag = sqrtf((g.x * g.x) + (g.y * g.y));
+          float wgt = expf(-((tx * tx) + (ty * ty)) / weight);
+          if (bin >= 0 && bin < 36) atomicAdd(&hist[bin], mag * wgt);
+        }
+        y += 1.0f;
+        if (two) y += 1.0f;
       }
-    }
-    float maxHist = 0.0f;
+      __builtin_amdgcn_wave_barrier();
+      const float hb = lane < 36 ? hist[lane] : 0.0f;
+      const float hprev = lane < 36 ? hist[(lane + 35) % 36] : 0.0f;
+      const float hnext = lane < 36 ? hist[(lane + 1) % 36] : 0.0f;
+      float maxHist = hb;
 #pragma unroll
-    for (int i = 0; i < 36; ++i)
-      if (hist[i] > maxHist) maxHist = hist[i];
-    maxHist *= orientationThreshold;
-    float bestMag[MAXO], bestTh[MAXO];
-#pragma unroll
-    for (int i = 0; i < MAXO; ++i) { bestMag[i] = 0.0f; bestTh[i] = 0.0f; }
-#pragma unroll
-    for (int b = 0; b < 36; ++b) {
-      float hb = hist[b];
-      float hprev = hist[(b + 35) % 36], hnext = hist[(b + 1) % 36];
-      // the five neighbour tests of :1064-1069 reduce to: below threshold, below either circular neighbour, or below
-      // the weakest kept peak
-      if (hb < maxHist || hb < hprev || hb < hnext || hb < bestMag[MAXO - 1]) continue;
-      float tmag = hb;
+      for (int o = 32; o > 0; o >>= 1) maxHist = fmaxf(maxHist, __shfl_xor(maxHist, o, 64));
+      maxHist = fmaxf(maxHist, 0.0f) * orientationThreshold;
+      // tests 1-5 of :1064-1068 (circular neighbours); test 6 (weakest kept peak) is order dependent, done below
+      const bool peak = lane < 36 && !(hb < maxHist || hb < hprev || hb < hnext);
       float tth = (hprev - hnext) / (hprev - (2.0f * hb) + hnext);
       tth *= (pi / 36.0f);
-      tth += (b * rad10);
+      tth += (lane * rad10);
       tth = fmodf(tth + (2.0f * pi), 2.0f * pi);
+      unsigned long long mask = __ballot(peak);
+      float bestMag[MAXO], bestTh[MAXO];
 #pragma unroll
-      for (int i = 0; i < MAXO; ++i) {
-        if (tmag > bestMag[i]) {
+      for (int i = 0; i < MAXO; ++i) { bestMag[i] = 0.0f; bestTh[i] = 0.0f; }
+      while (mask) {
+        const int b = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        float tmag = __shfl(hb, b, 64);
+        float tt = __shfl(tth, b, 64);
+        if (tmag < bestMag[MAXO - 1]) continue;
 #pragma unroll
-          for (int ii = i; ii < MAXO; ++ii) {
-            float m2 = bestMag[ii], t2 = bestTh[ii];
-            bestMag[ii] = tmag;
-            bestTh[ii] = tth;
-            tmag = m2;
-            tth = t2;
-          }
-        }
-      }
-    }
-    // valid entries are a prefix (bestMag is kept sorted descending)
+        for (int i = 0; i < MAXO; ++i) {
+          if (tmag > bestMag[i]) {
 #pragma unroll
-    for (int i = 0; i < MAXO; ++i) {
-      if (bestMag[i] != 0.0f) { outTheta[i] = bestTh[i]; cnt = i + 1; }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < MAXO; ++i) thetas[(size_t)gi * svp::kMaxOrient + i] = outTheta[i];
-  thetaCnt[gi] = cnt;
-}
-
-// ---- S14: fillDescriptors(SSKeyPoint) (src/SIFT_FeatureFactory.cu:475-549) ------------------------------------------------
-// One thread per key point; its 4x4x8 histogram lives in LDS, bin-major / lane-minor (conflict-free), so the
-// accumulation order per bin is the raster sample order of the oracle (the reference's shared atomicAdd order is
-// non-deterministic).  64 lanes x 128 bins x 4 B = 32 KiB per wave.
-__global__ __launch_bounds__(64) void k_descriptors(const OctaveState* st, const ssrlcv_sskeypoint* kps, LevelSet L,
-                                                    float pixelWidth, float lambda, const uint32_t* featBase, int octave,
-                                                    ssrlcv_sift_feature* __restrict__ features, uint32_t maxFeatures) {
-  __shared__ float s_bins[128][64];
-  int n = st->hasExtrema ? st->n : 0;
-  int gi = blockIdx.x * 64 + threadIdx.x;
-  const int lane = threadIdx.x;
-  if (gi >= n) return;
-#pragma unroll 8
-  for (int b = 0; b < 128; ++b) s_bins[b][lane] = 0.0f;
-  const float pi = SSRLCV_PI_F;
-  int seg = segment_of(st, gi);
-  const float* px = L.dog[seg];
-  float lmn = L.minmax[2 * seg], lmx = L.minmax[2 * seg + 1];
-  ssrlcv_sskeypoint kp = kps[gi];
-  float kx = kp.loc.x, ky = kp.loc.y;
-  float windowWidth = ceilf(kp.sigma * lambda / pixelWidth);
-  float theta = kp.theta;
-  float binWidth = windowWidth / 2.0f;
-  float rad45 = pi / 4.0f;
-  float c = cosf(-theta), s = sinf(-theta);
-  for (float y = -windowWidth; y <= windowWidth; y += 1.0f) {
-    for (float x = -windowWidth; x <= windowWidth; x += 1.0f) {
-      float cx = (x * c) + (y * s), cy = (-x * s) + (y * c);
-      if (fabsf(cx) > windowWidth || fabsf(cy) > windowWidth) continue;
-      float2 g = pixel_gradient(px, lmn, lmx, L.w, L.h, (int)llroundf(cx + kx), (int)llroundf(cy + ky));
-      float mag = sqrtf((g.x * g.x) + (g.y * g.y)) * expf(-((cx * cx) + (cy * cy)) / (2.0f * windowWidth * windowWidth));
-      float ang = fmodf(atan2f(g.y, g.x) - theta + (2.0f * pi), 2.0f * pi);
-      for (int nxi = 0; nxi < 4; ++nxi) {
-        float nx = (float)nxi;
-        for (int nyi = 0; nyi < 4; ++nyi) {
-          float ny = (float)nyi;
-          float hx = (nx * 0.5f - 0.75f) * windowWidth, hy = (ny * 0.5f - 0.75f) * windowWidth;
-          float rx = (hx * c) + (hy * s), ry = (-hx * s) + (hy * c);
-          hx = fabsf(rx - cx);
-          hy = fabsf(ry - cy);
-          if (hx <= binWidth && hy <= binWidth) {
-            hx = hx / binWidth;
-            hy = hy / binWidth;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              float angle = fabsf(ang - ((float)k * rad45));
-              if (angle < rad45) {
-                angle /= rad45;
-                float temp = (1.0f - hx) * (1.0f - hy) * (1.0f - angle) * mag;
-                s_bins[(nxi * 4 + nyi) * 8 + k][lane] += temp;
-              }
+            for (int ii = i; ii < MAXO; ++ii) {
+              float m2 = bestMag[ii], t2 = bestTh[ii];
+              bestMag[ii] = tmag;
+              bestTh[ii] = tt;
+              tmag = m2;
+              tt = t2;
             }
           }
         }
       }
-    }
-  }
-  // normalise, clamp at 0.2, renormalise, quantise (:529-542); sums in CUDA linear thread order (x fastest, then y, z)
-  float norm = 0.0f;
-  for (int z = 0; z < 8; ++z)
-    for (int yy = 0; yy < 4; ++yy)
-      for (int xx = 0; xx < 4; ++xx) {
-        float v = s_bins[(xx * 4 + yy) * 8 + z][lane];
-        norm += v * v;
-      }
-  float sq = sqrtf(norm);
-  for (int b = 0; b < 128; ++b) {
-    float v = s_bins[b][lane] / sq;
-    if (v > 0.2f) v = 0.2f;
-    s_bins[b][lane] = v;
-  }
-  norm = 0.0f;
-  for (int z = 0; z < 8; ++z)
-    for (int yy = 0; yy < 4; ++yy)
-      for (int xx = 0; xx < 4; ++xx) {
-        float v = s_bins[(xx * 4 + yy) * 8 + z][lane];
-        norm += v * v;
-      }
-  sq = sqrtf(norm);
-  uint32_t fi = featBase[octave] + (uint32_t)gi;
-  if (fi >= maxFeatures) return;
-  ssrlcv_sift_feature* f = features + fi;
-  for (int xx = 0; xx < 4; ++xx)
-    for (int yy = 0; yy < 4; ++yy) {
-      uint32_t packed[2] = {0, 0};
 #pragma unroll
-      for (int z = 0; z < 8; ++z) {
-        uint32_t q = (uint32_t)(uint8_t)roundf(255.0f * s_bins[(xx * 4 + yy) * 8 + z][lane] / sq);
-        packed[z >> 2] |= q << (8 * (z & 3));
+      for (int i = 0; i < MAXO; ++i) {
+        if (bestMag[i] != 0.0f) { outTheta[i] = bestTh[i]; cnt = i + 1; }
       }
-      *reinterpret_cast<uint2*>(&f->values[(yy * 4 + xx) * 8]) = make_uint2(packed[0], packed[1]);
+      __builtin_amdgcn_wave_barrier();
     }
-  f->parent = -1;  // Feature() default (include/Feature.cuh:43-46); the reference kernel never writes it
-  f->theta = kp.theta;
-  f->sigma = kp.sigma;
-  f->loc.x = kp.loc.x * pixelWidth;
-  f->loc.y = kp.loc.y * pixelWidth;
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < MAXO; ++i) thetas[(size_t)gi * svp::kMaxOrient + i] = outTheta[i];
+      thetaCnt[gi] = cnt;
+    }
+  }
+}
+
+// ---- S14: fillDescriptors(SSKeyPoint) (src/SIFT_FeatureFactory.cu:475-549) ------------------------------------------------
+// One WAVE per key point (the reference: a 4x4x8 block of which 16 threads sweep the window).  Lanes run along x of the
+// rotated (2w+1)^2 window, one or two rows per step; each sample votes into the wave's 4x4x8 LDS histogram with
+// ds_add_f32 (the reference also uses shared-memory float atomics, :521).  The 16 rotated cell centres and the two
+// possible orientation bins are computed once per key point / once per sample instead of inside the 16 x 8 inner loops.
+__global__ __launch_bounds__(256) void k_descriptors(const OctaveState* st, const ssrlcv_sskeypoint* kps, LevelSet L,
+                                                     float pixelWidth, float lambda, const uint32_t* featBase, int octave,
+                                                     ssrlcv_sift_feature* __restrict__ features, uint32_t maxFeatures) {
+  __shared__ float s_bins[4][128];
+  __shared__ __attribute__((aligned(8))) uint8_t s_bytes[4][128];
+  const int n = st->hasExtrema ? st->n : 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* bins = s_bins[wave];
+  const float pi = SSRLCV_PI_F;
+  const float rad45 = pi / 4.0f;
+  for (int gi = blockIdx.x * 4 + wave; gi < n; gi += gridDim.x * 4) {
+    const int seg = segment_of(st, gi);
+    const float* px = L.dog[seg];
+    const float lmn = L.minmax[2 * seg], lmx = L.minmax[2 * seg + 1];
+    const ssrlcv_sskeypoint kp = kps[gi];
+    const float kx = kp.loc.x, ky = kp.loc.y;
+    const float windowWidth = ceilf(kp.sigma * lambda / pixelWidth);
+    const float theta = kp.theta;
+    const float binWidth = windowWidth / 2.0f;
+    const float c = cosf(-theta), s = sinf(-theta);
+    bins[lane] = 0.0f;
+    bins[lane + 64] = 0.0f;
+    // rotated cell centres (:511-512), identical expressions to the reference's per-sample recomputation
+    float rcx[16], rcy[16];
+#pragma unroll
+    for (int nxi = 0; nxi < 4; ++nxi)
+#pragma unroll
+      for (int nyi = 0; nyi < 4; ++nyi) {
+        float hx = ((float)nxi * 0.5f - 0.75f) * windowWidth, hy = ((float)nyi * 0.5f - 0.75f) * windowWidth;
+        rcx[nxi * 4 + nyi] = (hx * c) + (hy * s);
+        rcy[nxi * 4 + nyi] = (-hx * s) + (hy * c);
+      }
+    __builtin_amdgcn_wave_barrier();
+    const int S = 2 * (int)windowWidth + 1;
+    const bool two = S <= 32;
+    const int col = two ? (lane & 31) : lane;
+    const int rsub = two ? (lane >> 5) : 0;
+    const float x = -windowWidth + (float)col;  // integers: exact, equal to the reference's repeated += 1.0f
+    const bool colOk = col < S;
+    for (int r0 = 0; r0 < S; r0 += (two ? 2 : 1)) {
+      const int r = r0 + rsub;
+      const float y = -windowWidth + (float)r;
+      const float cx = (x * c) + (y * s), cy = (-x * s) + (y * c);
+      if (colOk && r < S && !(fabsf(cx) > windowWidth || fabsf(cy) > windowWidth)) {
+        float2 g = pixel_gradient(px, lmn, lmx, L.w, L.h, (int)llroundf(cx + kx), (int)llroundf(cy + ky));
+        float mag = sqrtf((g.x * g.x) + (g.y * g.y)) * expf(-((cx * cx) + (cy * cy)) / (2.0f * windowWidth * windowWidth));
+        float ang = fmodf(atan2f(g.y, g.x) - theta + (2.0f * pi), 2.0f * pi);
+        // orientation bins: every k with |ang - k*rad45| < rad45 (at most two); evaluated for all 8 k like the reference
+        int ka = -1, kb = -1;
+        float wa = 0.0f, wb = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float angle = fabsf(ang - ((float)k * rad45));
+          if (angle < rad45) {
+            float wk = 1.0f - (angle / rad45);
+            if (ka < 0) { ka = k; wa = wk; }
+            else if (kb < 0) { kb = k; wb = wk; }
+          }
+        }
+#pragma unroll
+        for (int cell = 0; cell < 16; ++cell) {
+          float hx = fabsf(rcx[cell] - cx), hy = fabsf(rcy[cell] - cy);
+          if (hx <= binWidth && hy <= binWidth) {
+            hx = hx / binWidth;
+            hy = hy / binWidth;
+            float wxy = (1.0f - hx) * (1.0f - hy);
+            if (ka >= 0) atomicAdd(&bins[cell * 8 + ka], wxy * wa * mag);
+            if (kb >= 0) atomicAdd(&bins[cell * 8 + kb], wxy * wb * mag);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // normalise, clamp at 0.2, renormalise, quantise (:529-542); each lane owns bins lane and lane + 64
+    float v0 = bins[lane], v1 = bins[lane + 64];
+    float sq = sqrtf(sv::wave_sum((v0 * v0) + (v1 * v1)));
+    v0 = v0 / sq;
+    v1 = v1 / sq;
+    if (v0 > 0.2f) v0 = 0.2f;
+    if (v1 > 0.2f) v1 = 0.2f;
+    sq = sqrtf(sv::wave_sum((v0 * v0) + (v1 * v1)));
+    // bins are [nx][ny][k]; the descriptor byte order is (ny*4 + nx)*8 + k (:542)
+    {
+      int b0 = lane, b1 = lane + 64;
+      int o0 = (((b0 >> 3) & 3) * 4 + (b0 >> 5)) * 8 + (b0 & 7);
+      int o1 = (((b1 >> 3) & 3) * 4 + (b1 >> 5)) * 8 + (b1 & 7);
+      s_bytes[wave][o0] = (uint8_t)roundf(255.0f * v0 / sq);
+      s_bytes[wave][o1] = (uint8_t)roundf(255.0f * v1 / sq);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t fi = featBase[octave] + (uint32_t)gi;
+    if (fi < maxFeatures) {
+      ssrlcv_sift_feature* f = features + fi;
+      if (lane < 16) *reinterpret_cast<uint2*>(&f->values[lane * 8]) = *reinterpret_cast<const uint2*>(&s_bytes[wave][lane * 8]);
+      if (lane == 16) {
+        f->parent = -1;  // Feature() default (include/Feature.cuh:43-46); the reference kernel never writes it
+        f->theta = kp.theta;
+        f->sigma = kp.sigma;
+        f->loc.x = kp.loc.x * pixelWidth;
+        f->loc.y = kp.loc.y * pixelWidth;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 LevelSet make_levels(const ssrlcv_sift_plan* plan, char* ws, int o) {
@@ -624,12 +658,12 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
     if (stop >= 6) {  // computeKeyPointOrientations (src/FeatureFactory.cu:540-632)
       float* thetas = (float*)(ws + oc.off_theta);
       uint32_t* thetaCnt = (uint32_t*)(ws + oc.off_thetaCnt);
-      dim3 g((cap + 63) / 64);
+      dim3 g(list_blocks(cap) * 2);
       switch (maxO) {
-        case 1: hipLaunchKernelGGL(k_thetas<1>, g, dim3(64), 0, s, st, cur, L, oc.pixelWidth, plan->params.orientationContribWidth, plan->params.orientationThreshold, thetas, thetaCnt); break;
-        case 2: hipLaunchKernelGGL(k_thetas<2>, g, dim3(64), 0, s, st, cur, L, oc.pixelWidth, plan->params.orientationContribWidth, plan->params.orientationThreshold, thetas, thetaCnt); break;
-        case 3: hipLaunchKernelGGL(k_thetas<3>, g, dim3(64), 0, s, st, cur, L, oc.pixelWidth, plan->params.orientationContribWidth, plan->params.orientationThreshold, thetas, thetaCnt); break;
-        default: hipLaunchKernelGGL(k_thetas<4>, g, dim3(64), 0, s, st, cur, L, oc.pixelWidth, plan->params.orientationContribWidth, plan->params.orientationThreshold, thetas, thetaCnt); break;
+        case 1: hipLaunchKernelGGL(k_thetas<1>, g, dim3(256), 0, s, st, cur, L, oc.pixelWidth, plan->params.orientationContribWidth, plan->params.orientationThreshold, thetas, thetaCnt); break;
+        case 2: hipLaunchKernelGGL(k_thetas<2>, g, dim3(256), 0, s, st, cur, L, oc.pixelWidth, plan->params.orientationContribWidth, plan->params.orientationThreshold, thetas, thetaCnt); break;
+        case 3: hipLaunchKernelGGL(k_thetas<3>, g, dim3(256), 0, s, st, cur, L, oc.pixelWidth, plan->params.orientationContribWidth, plan->params.orientationThreshold, thetas, thetaCnt); break;
+        default: hipLaunchKernelGGL(k_thetas<4>, g, dim3(256), 0, s, st, cur, L, oc.pixelWidth, plan->params.orientationContribWidth, plan->params.orientationThreshold, thetas, thetaCnt); break;
       }
       // thrust::remove of the -FLT_MAX / -1 slots + expandKeyPoints (:594-611): element space n x maxOrientations
       const OctaveState* cst = st;
@@ -662,7 +696,7 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
     for (int o = 0; o < svp::kOctaves; ++o) {
       const svp::OctavePlan& oc = plan->oct[o];
       LevelSet L = make_levels(plan, ws, o);
-      hipLaunchKernelGGL(k_descriptors, dim3((oc.cap + 63) / 64), dim3(64), 0, s, states + o,
+      hipLaunchKernelGGL(k_descriptors, dim3(list_blocks(oc.cap) * 2), dim3(256), 0, s, states + o,
                          (const ssrlcv_sskeypoint*)(ws + oc.off_kpA), L, oc.pixelWidth,
                          plan->params.descriptorContribWidth, featBase, o, features, plan->maxFeatures);
     }

@@ -25,7 +25,8 @@ namespace {
 // src/Image.cu:1248-1252 getSymmetrizedCoord
 __device__ __forceinline__ int sym_coord(int i, int l) {
   int ll = 2 * l;
-  i = (i + ll) % ll;
+  if (__builtin_expect(i < -ll || i >= ll, 0)) i = (i + ll) % ll;  // only tiny images reach this
+  if (i < 0) i += ll;        // (i + ll) % ll for -ll <= i < 0
   return (i > l - 1) ? ll - 1 - i : i;
 }
 
@@ -46,6 +47,26 @@ __device__ __forceinline__ void wave_minmax_commit(float mn, float mx, float* mi
     mx = fmaxf(mx, __shfl_xor(mx, o, 64));
   }
   if ((threadIdx.x & 63) == 0) {
+    atomic_min_f(minmax, mn);
+    atomic_max_f(minmax + 1, mx);
+  }
+}
+
+// Block-level variant: one atomic pair per BLOCK.  Same-address float atomics serialise at the memory side (~12-50 ns
+// each), so one pair per wave cost 1.5 ms on a 67 Mpx DoG launch; per block it is noise.  Every thread of the block
+// must call it (it contains __syncthreads).
+__device__ __forceinline__ void block_minmax_commit(float mn, float mx, float* minmax, float* s_red /* >= 8 floats */) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, o, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  }
+  const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { s_red[2 * wave] = mn; s_red[2 * wave + 1] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < nw; ++w) { mn = fminf(mn, s_red[2 * w]); mx = fmaxf(mx, s_red[2 * w + 1]); }
     atomic_min_f(minmax, mn);
     atomic_max_f(minmax + 1, mx);
   }
@@ -113,7 +134,7 @@ struct ConvArgs {
   float* minmax;  // nullable
   uint32_t w, h;
   uint32_t rowsPerBlock;
-  float wgt[65];  // taps <= 65 for the templated kernels (R <= 32)
+  float wgt[33];  // taps are symmetric (w[k] == w[2R-k] bit for bit): only k = 0..R travel, in SGPRs
 };
 
 constexpr int kTX = 256;  // strip width = threads per block
@@ -122,12 +143,15 @@ constexpr int kNR = 8;    // rows per marching step
 template <int R>
 __global__ __launch_bounds__(kTX) void k_gauss_fused(ConvArgs a) {
   constexpr int RP = (R + 3) / 4 * 4;   // halo rounded up so LDS reads stay 16-byte aligned
-  constexpr int SW = kTX + 2 * RP;      // staged row width
+  constexpr int SW = kTX + 2 * RP;      // staged row width (floats)
   constexpr int WIN = 2 * R + kNR;      // vertical register window
-  constexpr int HIN = 2 * RP + 8;       // horizontal register window (aligned superset of 2R+8)
-  constexpr int STG = (kNR * SW + kTX - 1) / kTX;  // staging elements per thread
-  __shared__ __attribute__((aligned(16))) float s_in[kNR][SW];
-  __shared__ __attribute__((aligned(16))) float s_h[kNR][kTX];
+  constexpr int HQ = (2 * RP + 8) / 4;  // float4 reads of the horizontal pass
+  constexpr int TOT = kNR * SW;         // staged floats per step
+  constexpr int STG = (TOT + kTX - 1) / kTX;
+  __shared__ float4 s_in4[kNR][SW / 4];
+  __shared__ float4 s_h4[kNR][kTX / 4];
+  float* s_in = reinterpret_cast<float*>(&s_in4[0][0]);
+  float* s_h = reinterpret_cast<float*>(&s_h4[0][0]);
 
   const int W = (int)a.w, H = (int)a.h;
   const int x0 = blockIdx.x * kTX;
@@ -135,70 +159,79 @@ __global__ __launch_bounds__(kTX) void k_gauss_fused(ConvArgs a) {
   int nrows = (int)a.rowsPerBlock;
   if (y0 + nrows > H) nrows = H - y0;
   const int tid = threadIdx.x;
-  const int hr = tid >> 5, hx = (tid & 31) * 8;  // horizontal-pass role: row hr, outputs hx..hx+7
+  const int hr = tid >> 5, hq = (tid & 31) * 2;  // horizontal-pass role: row hr, outputs 8*(tid&31) .. +7
 
+  // staging role: element e of this thread is float (e*256 + tid) of the [kNR][SW] tile; its column never changes.
+  // Columns/rows beyond the last pixel any valid output needs are clamped first, so the mirror needs no modulo
+  // (host guarantees W,H >= 64 > R).
+  int gxs[STG], rws[STG];
+#pragma unroll
+  for (int e = 0; e < STG; ++e) {
+    int idx = e * kTX + tid;
+    int r = idx / SW, c = idx - r * SW;
+    int x = x0 - RP + c;
+    x = x > W - 1 + R ? W - 1 + R : x;
+    x = x < 0 ? -1 - x : x;                 // sym_coord for -l <= i < 0
+    x = x > W - 1 ? 2 * W - 1 - x : x;      // sym_coord for l <= i < 2l
+    gxs[e] = x;
+    rws[e] = r;
+  }
   float win[WIN];
 #pragma unroll
   for (int k = 0; k < WIN; ++k) win[k] = 0.0f;
   float mn = FLT_MAX, mx = -FLT_MAX;
-
   const int steps = (nrows + 2 * R + kNR - 1) / kNR;
   float pre[STG];
-  // prefetch helper: H-row group s covers image rows y0 - R + s*kNR + r
   auto fetch = [&](int s) {
+    const int ybase = y0 - R + s * kNR;
 #pragma unroll
     for (int e = 0; e < STG; ++e) {
-      int idx = e * kTX + tid;
-      int r = idx / SW, c = idx - r * SW;
-      float v = 0.0f;
-      if (idx < kNR * SW) {
-        int gy = sym_coord(y0 - R + s * kNR + r, H);
-        int gx = sym_coord(x0 - RP + c, W);
-        v = a.in[(size_t)gy * W + gx];
-      }
-      pre[e] = v;
+      int y = ybase + rws[e];
+      y = y > H - 1 + R ? H - 1 + R : y;
+      y = y < 0 ? -1 - y : y;
+      y = y > H - 1 ? 2 * H - 1 - y : y;
+      if ((e + 1) * kTX <= TOT || e * kTX + tid < TOT) pre[e] = a.in[(size_t)y * W + gxs[e]];
     }
   };
   fetch(0);
   for (int s = 0; s < steps; ++s) {
 #pragma unroll
-    for (int e = 0; e < STG; ++e) {
-      int idx = e * kTX + tid;
-      if (idx < kNR * SW) (&s_in[0][0])[idx] = pre[e];
-    }
+    for (int e = 0; e < STG; ++e)
+      if ((e + 1) * kTX <= TOT || e * kTX + tid < TOT) s_in[e * kTX + tid] = pre[e];
     __syncthreads();
-    if (s + 1 < steps) fetch(s + 1);  // global loads in flight under the two passes below
-    // horizontal pass: out[i] = sum_k w[k] * row[hx + i + k - R], fmaf chain in the reference's kx order
+    if (s + 1 < steps) fetch(s + 1);  // global loads stay in flight under the two passes below
+    // horizontal pass: out[i] = sum_k w[k] * row[8*(tid&31) + i + k - R]; the window streams through 4 registers at a
+    // time and every output's fmaf chain still runs k = 0..2R in order
     {
-      float rin[HIN];
-      const float4* src = reinterpret_cast<const float4*>(&s_in[hr][hx]);
-#pragma unroll
-      for (int q = 0; q < HIN / 4; ++q) {
-        float4 v = src[q];
-        rin[4 * q] = v.x; rin[4 * q + 1] = v.y; rin[4 * q + 2] = v.z; rin[4 * q + 3] = v.w;
-      }
       float o[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float sum = 0.0f;
+      for (int i = 0; i < 8; ++i) o[i] = 0.0f;
 #pragma unroll
-        for (int k = 0; k <= 2 * R; ++k) sum = __builtin_fmaf(rin[(RP - R) + i + k], a.wgt[k], sum);
-        o[i] = sum;
+      for (int q = 0; q < HQ; ++q) {
+        float4 v4 = s_in4[hr][hq + q];
+        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int k = 4 * q + j - (RP - R) - i;
+            if (k >= 0 && k <= 2 * R) o[i] = __builtin_fmaf(v[j], a.wgt[k <= R ? k : 2 * R - k], o[i]);
+          }
+        }
       }
-      float4* dst = reinterpret_cast<float4*>(&s_h[hr][hx]);
-      dst[0] = make_float4(o[0], o[1], o[2], o[3]);
-      dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+      s_h4[hr][hq] = make_float4(o[0], o[1], o[2], o[3]);
+      s_h4[hr][hq + 1] = make_float4(o[4], o[5], o[6], o[7]);
     }
     __syncthreads();
-    // vertical pass: this thread owns column x0 + tid
+    // vertical pass: this thread owns column x0 + tid; sliding window of 2R + 8 filtered rows in registers
 #pragma unroll
-    for (int i = 0; i < kNR; ++i) win[2 * R + i] = s_h[i][tid];
+    for (int i = 0; i < kNR; ++i) win[2 * R + i] = s_h[i * kTX + tid];
     const int gx = x0 + tid;
 #pragma unroll
     for (int i = 0; i < kNR; ++i) {
       float sum = 0.0f;
 #pragma unroll
-      for (int k = 0; k <= 2 * R; ++k) sum = __builtin_fmaf(win[i + k], a.wgt[k], sum);
+      for (int k = 0; k <= 2 * R; ++k) sum = __builtin_fmaf(win[i + k], a.wgt[k <= R ? k : 2 * R - k], sum);
       int j = s * kNR - 2 * R + i;
       if (j >= 0 && j < nrows && gx < W) {
         a.out[(size_t)(y0 + j) * W + gx] = sum;
@@ -209,7 +242,7 @@ __global__ __launch_bounds__(kTX) void k_gauss_fused(ConvArgs a) {
 #pragma unroll
     for (int k = 0; k < 2 * R; ++k) win[k] = win[k + kNR];
   }
-  if (a.minmax) wave_minmax_commit(mn, mx, a.minmax);
+  if (a.minmax) block_minmax_commit(mn, mx, a.minmax, s_h);
 }
 
 // Generic two-pass fallback for tap counts the pipeline never produces (taps > 65): one 1-D pass per launch.
@@ -247,7 +280,8 @@ __global__ __launch_bounds__(256) void k_minmax(const float* __restrict__ in, si
       for (size_t k = i; k < n; ++k) { mn = fminf(mn, in[k]); mx = fmaxf(mx, in[k]); }
     }
   }
-  wave_minmax_commit(mn, mx, minmax);
+  __shared__ float s_red[8];
+  block_minmax_commit(mn, mx, minmax, s_red);
 }
 __global__ __launch_bounds__(256) void k_normalize(float* __restrict__ data, size_t n, const float* __restrict__ minmax) {
   float mn = minmax[0], mx = minmax[1];
@@ -292,8 +326,9 @@ __global__ __launch_bounds__(256) void k_dog(DogArgs a) {
     }
   }
   if (a.dogMinMax) {
+    __shared__ float s_red[8];
 #pragma unroll
-    for (int b = 0; b < svp::kDog; ++b) wave_minmax_commit(dmn[b], dmx[b], a.dogMinMax + 2 * b);
+    for (int b = 0; b < svp::kDog; ++b) block_minmax_commit(dmn[b], dmx[b], a.dogMinMax + 2 * b, s_red);
   }
 }
 
@@ -301,11 +336,8 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
                 float* minmax, hipStream_t st) {
   if (taps < 1 || (taps & 1) == 0 || taps > svp::kMaxTaps) return SSRLCV_ERR_INVALID_ARG;
   int R = taps / 2;
-  if (R > 32) {
-    // generic two-pass fallback (needs tmp and a device copy of the weights; never taken by the SIFT pipeline)
-    if (!tmp) return SSRLCV_ERR_INVALID_ARG;
-    return SSRLCV_ERR_UNSUPPORTED;
-  }
+  if (R > 32) return SSRLCV_ERR_UNSUPPORTED;  // the pipeline's sigma ladder never exceeds 65 taps
+  if (w < 64 || h < 64) return SSRLCV_ERR_UNSUPPORTED;  // fused kernel mirrors without modulo: needs size >= 2R
   ConvArgs a;
   a.in = in;
   a.out = out;
@@ -316,7 +348,10 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
   // pad the tap set symmetrically into the smallest templated radius: extra taps carry weight 0 and would change
   // the fmaf chain (0*x + s is exact, so the result is identical) -- only exact radii are dispatched below anyway.
   int RT = R <= 6 ? 6 : R <= 8 ? 8 : R <= 11 ? 11 : R <= 16 ? 16 : R <= 23 ? 23 : 32;
-  for (int k = 0; k < taps; ++k) a.wgt[(RT - R) + k] = weights_host[k];
+  for (int k = 0; k <= R; ++k) {
+    if (weights_host[k] != weights_host[taps - 1 - k]) return SSRLCV_ERR_UNSUPPORTED;  // symmetric taps only
+    a.wgt[(RT - R) + k] = weights_host[k];
+  }
   // rows per block: aim for >= 1024 blocks, never below 64 rows (halo recompute = 2R / rows)
   uint32_t bx = (w + kTX - 1) / kTX;
   uint32_t rows = h;
@@ -395,7 +430,7 @@ int ssrlcv_hip_minmax(const float* in, size_t n, float* minmax, ssrlcv_stream_t 
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_init_minmax, dim3(1), dim3(64), 0, st, minmax, 1);
   size_t blocks = (n + 1023) / 1024;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(k_minmax, dim3((unsigned)blocks), dim3(256), 0, st, in, n, minmax);
   SSRLCV_LAUNCH_CHECK();
   return SSRLCV_OK;
@@ -420,7 +455,7 @@ int ssrlcv_hip_dog_normalised_sub(const float* const levels_host[6], const float
   a.dogMinMax = dogMinMax;
   a.n = n;
   size_t blocks = (n / 4 + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  if (blocks > 1024) blocks = 1024;  // 4 blocks per CU; each block ends with 10 same-address atomics
   hipLaunchKernelGGL(k_dog, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   SSRLCV_LAUNCH_CHECK();
   return SSRLCV_OK;
@@ -433,6 +468,8 @@ int ssrlcv_sift_plan_create(uint32_t w, uint32_t h, const ssrlcv_sift_params* pa
   if (params->maxOrientations == 0 || params->maxOrientations > (uint32_t)svp::kMaxOrient) return SSRLCV_ERR_UNSUPPORTED;
   // "image too small" check of ScaleSpace::ScaleSpace (src/FeatureFactory.cu:341-345): numResize = 2^(start+depth.x)
   if (w / 8 == 0 || h / 8 == 0) return SSRLCV_ERR_INVALID_ARG;
+  // the fused Gaussian kernel needs every octave >= 64 pixels on each side (the smallest octave is W/4 x H/4)
+  if (w < 256 || h < 256) return SSRLCV_ERR_UNSUPPORTED;
   ssrlcv_sift_plan* p = new (std::nothrow) ssrlcv_sift_plan;
   if (!p) return SSRLCV_ERR_INVALID_ARG;
   memset(p, 0, sizeof *p);
