@@ -3,7 +3,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libssrlcv_hip.so")
+LIB_PATH = os.environ.get("SSRLCV_HIP_LIB", os.path.join(_HERE, "libssrlcv_hip.so"))  # override: developer experiments
 
 _lib = None
 

@@ -26,6 +26,7 @@ namespace {
 struct LevelSet {  // one octave's raw DoG levels + their min/max
   const float* dog[svp::kDog];
   const float* minmax;  // 5 x {min,max}
+  const float2* polar;  // {|grad|, atan2(gy,gx)} of the normalised levels 1..3, level-major; nullptr = not built
   int w, h;
 };
 
@@ -288,6 +289,42 @@ __device__ __forceinline__ float2 pixel_gradient(const float* __restrict__ px, f
   return g;
 }
 
+// Gradient magnitude / direction of every pixel of the normalised DoG levels 1..3, computed once per image: the
+// orientation and descriptor windows of neighbouring key points overlap ~10x, and 4 gathers + 4 divisions + sqrtf +
+// atan2f per sample was two thirds of their instruction count.  Same operations as the on-the-fly path, so values are
+// bit-identical.
+__global__ __launch_bounds__(256) void k_polar(LevelSet L, float2* __restrict__ out) {
+  int x = blockIdx.x * 256 + threadIdx.x;
+  int y = blockIdx.y;
+  int lvl = blockIdx.z + 1;
+  if (x >= L.w) return;
+  float mn = L.minmax[2 * lvl], mx = L.minmax[2 * lvl + 1];
+  float2 g = pixel_gradient(L.dog[lvl], mn, mx, L.w, L.h, x, y);
+  float2 r;
+  r.x = sqrtf((g.x * g.x) + (g.y * g.y));
+  r.y = atan2f(g.y, g.x);
+  out[((size_t)blockIdx.z * L.h + y) * L.w + x] = r;
+}
+// {|grad|, atan2} at a pixel of the level of segment `seg`
+__device__ __forceinline__ float2 polar_at(const LevelSet& L, int seg, const float* __restrict__ px, float mn, float mx,
+                                           int x, int y) {
+  if (L.polar && seg >= 1 && seg <= 3) return L.polar[((size_t)(seg - 1) * L.h + y) * L.w + x];
+  float2 g = pixel_gradient(px, mn, mx, L.w, L.h, x, y);
+  float2 r;
+  r.x = sqrtf((g.x * g.x) + (g.y * g.y));
+  r.y = atan2f(g.y, g.x);
+  return r;
+}
+
+// 2^-40 fixed point for histogram votes (see k_descriptors)
+__device__ __forceinline__ unsigned long long to_fixed(float v) { return (unsigned long long)(v * 1099511627776.0f); }
+__device__ __forceinline__ float from_fixed(unsigned long long t) { return (float)t * 9.094947017729282e-13f; }
+
+// fmodf(v, p) for |v| < 2p, exact: fmod is an exact operation and v - p is exact for p <= v < 2p (Sterbenz)
+__device__ __forceinline__ float fmod_2pi(float v, float p) {
+  return v >= p ? v - p : (v <= -p ? v + p : v);
+}
+
 // ---- S13: computeThetas(SSKeyPoint) (src/FeatureFactory.cu:1004-1112) -----------------------------------------------------
 // One WAVE per key point (the reference: one thread).  The (2w+1)^2 window is swept one row (two rows when the window is
 // at most 32 samples wide) per step with lanes along x; the 36-bin histogram lives in LDS and is accumulated with
@@ -298,10 +335,13 @@ template <int MAXO>
 __global__ __launch_bounds__(256) void k_thetas(const OctaveState* st, const ssrlcv_sskeypoint* kps, LevelSet L,
                                                 float pixelWidth, float lambda, float orientationThreshold,
                                                 float* __restrict__ thetas, uint32_t* __restrict__ thetaCnt) {
-  __shared__ float s_hist[4][64];
+  // 2^-40 fixed-point votes with 64-bit integer LDS atomics (float LDS atomics are ~30x slower on gfx950, see
+  // k_descriptors); 8 lane-private copies (copy = lane & 7, bin-major / copy-minor)
+  __shared__ unsigned long long s_hist[4][36 * 8];
   const int n = st->hasExtrema ? st->n : 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* hist = s_hist[wave];
+  unsigned long long* hist = s_hist[wave];
+  const int copy = lane & 7;
   const float pi = SSRLCV_PI_F;
   const float rad10 = pi / 18.0f;
   for (int gi = blockIdx.x * 4 + wave; gi < n; gi += gridDim.x * 4) {
@@ -317,7 +357,9 @@ __global__ __launch_bounds__(256) void k_thetas(const OctaveState* st, const ssr
 #pragma unroll
     for (int i = 0; i < MAXO; ++i) outTheta[i] = -FLT_MAX;
     if (!(minx < 0.0f || miny < 0.0f || maxx >= (unsigned)(L.w - 1) || maxy >= (unsigned)(L.h - 1))) {
-      hist[lane] = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+        if (i * 64 + lane < 36 * 8) hist[i * 64 + lane] = 0ull;
       __builtin_amdgcn_wave_barrier();
       const float weight = 2.0f * lambda * lambda * kp.sigma * kp.sigma;
       const int S = 2 * (int)windowWidth + 1;
@@ -334,21 +376,27 @@ __global__ __launch_bounds__(256) void k_thetas(const OctaveState* st, const ssr
       for (int r0 = 0; r0 < S; r0 += (two ? 2 : 1)) {
         const int r = r0 + rsub;
         if (colOk && r < S) {
-          float2 g = pixel_gradient(px, lmn, lmx, L.w, L.h, (int)llroundf(x), (int)llroundf(y));
+          float2 pg = polar_at(L, seg, px, lmn, lmx, (int)roundf(x), (int)roundf(y));  // roundf == llroundf here
           float tx = x - kx, ty = y - ky;
-          float angle = fmodf(atan2f(g.y, g.x) + (2.0f * pi), 2.0f * pi);
+          float angle = fmod_2pi(pg.y + (2.0f * pi), 2.0f * pi);
           int bin = (int)floorf(angle / rad10);
-          float mag = sqrtf((g.x * g.x) + (g.y * g.y));
+          float mag = pg.x;
           float wgt = expf(-((tx * tx) + (ty * ty)) / weight);
-          if (bin >= 0 && bin < 36) atomicAdd(&hist[bin], mag * wgt);
+          if (bin >= 0 && bin < 36) atomicAdd(&hist[bin * 8 + copy], to_fixed(mag * wgt));
         }
         y += 1.0f;
         if (two) y += 1.0f;
       }
       __builtin_amdgcn_wave_barrier();
-      const float hb = lane < 36 ? hist[lane] : 0.0f;
-      const float hprev = lane < 36 ? hist[(lane + 35) % 36] : 0.0f;
-      const float hnext = lane < 36 ? hist[(lane + 1) % 36] : 0.0f;
+      float hb = 0.0f;
+      if (lane < 36) {
+        unsigned long long t = 0ull;
+#pragma unroll
+        for (int cpy = 0; cpy < 8; ++cpy) t += hist[lane * 8 + cpy];
+        hb = from_fixed(t);
+      }
+      const float hprev = __shfl(hb, (lane + 35) % 36, 64);
+      const float hnext = __shfl(hb, (lane + 1) % 36, 64);
       float maxHist = hb;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) maxHist = fmaxf(maxHist, __shfl_xor(maxHist, o, 64));
@@ -405,11 +453,19 @@ __global__ __launch_bounds__(256) void k_thetas(const OctaveState* st, const ssr
 __global__ __launch_bounds__(256) void k_descriptors(const OctaveState* st, const ssrlcv_sskeypoint* kps, LevelSet L,
                                                      float pixelWidth, float lambda, const uint32_t* featBase, int octave,
                                                      ssrlcv_sift_feature* __restrict__ features, uint32_t maxFeatures) {
-  __shared__ float s_bins[4][128];
+  // The 4x4x8 histogram is accumulated in 2^-40 fixed point with 64-bit integer LDS atomics: ds_add_f32 runs at about
+  // one lane per clock on gfx950 (measured: 27 of 55 ms of this kernel), ds_add_u64 does not.  Every vote is >= 0 and
+  // < 4, a bin sums < 2^12 votes, so 2^40 * vote never overflows; the integer sum is exact and order-independent, i.e.
+  // deterministic (the reference's shared float atomicAdd is not).  8 lane-private copies (copy = lane & 7) keep
+  // same-address conflicts low.  8 KiB per wave.
+  __shared__ unsigned long long s_bins[4][128 * 8];
   __shared__ __attribute__((aligned(8))) uint8_t s_bytes[4][128];
+  __shared__ float s_cells[4][32];
   const int n = st->hasExtrema ? st->n : 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* bins = s_bins[wave];
+  unsigned long long* bins = s_bins[wave];
+  float* cells = s_cells[wave];
+  const int copy = lane & 7;
   const float pi = SSRLCV_PI_F;
   const float rad45 = pi / 4.0f;
   for (int gi = blockIdx.x * 4 + wave; gi < n; gi += gridDim.x * 4) {
@@ -422,61 +478,97 @@ __global__ __launch_bounds__(256) void k_descriptors(const OctaveState* st, cons
     const float theta = kp.theta;
     const float binWidth = windowWidth / 2.0f;
     const float c = cosf(-theta), s = sinf(-theta);
-    bins[lane] = 0.0f;
-    bins[lane + 64] = 0.0f;
-    // rotated cell centres (:511-512), identical expressions to the reference's per-sample recomputation
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bins[i * 64 + lane] = 0ull;
+    // rotated cell centres (:511-512), identical expressions to the reference's per-sample recomputation; kept in
+    // LDS so the per-lane loop over passing cells can index them
+    if (lane < 16) {
+      const int nxi = lane >> 2, nyi = lane & 3;
+      float hx = ((float)nxi * 0.5f - 0.75f) * windowWidth, hy = ((float)nyi * 0.5f - 0.75f) * windowWidth;
+      cells[lane] = (hx * c) + (hy * s);
+      cells[16 + lane] = (-hx * s) + (hy * c);
+    }
+    __builtin_amdgcn_wave_barrier();
     float rcx[16], rcy[16];
 #pragma unroll
-    for (int nxi = 0; nxi < 4; ++nxi)
-#pragma unroll
-      for (int nyi = 0; nyi < 4; ++nyi) {
-        float hx = ((float)nxi * 0.5f - 0.75f) * windowWidth, hy = ((float)nyi * 0.5f - 0.75f) * windowWidth;
-        rcx[nxi * 4 + nyi] = (hx * c) + (hy * s);
-        rcy[nxi * 4 + nyi] = (-hx * s) + (hy * c);
-      }
-    __builtin_amdgcn_wave_barrier();
+    for (int i = 0; i < 16; ++i) { rcx[i] = cells[i]; rcy[i] = cells[16 + i]; }
+    const float invBin = 1.0f / binWidth;   // hx / binWidth is evaluated as hx * (1/binWidth): <= 1 ulp from the division
+    const float inv45 = 1.0f / rad45;
     const int S = 2 * (int)windowWidth + 1;
     const bool two = S <= 32;
     const int col = two ? (lane & 31) : lane;
     const int rsub = two ? (lane >> 5) : 0;
     const float x = -windowWidth + (float)col;  // integers: exact, equal to the reference's repeated += 1.0f
     const bool colOk = col < S;
-    for (int r0 = 0; r0 < S; r0 += (two ? 2 : 1)) {
-      const int r = r0 + rsub;
+    // The polar gather of row r+1 is issued before row r is processed: its HBM/L2 latency (the window of a key point
+    // is touched once per key point) would otherwise be exposed once per row, 30-60 times per key point.
+    const int rstep = two ? 2 : 1;
+    auto sample = [&](int r, float& cx, float& cy, bool& ok) {
       const float y = -windowWidth + (float)r;
-      const float cx = (x * c) + (y * s), cy = (-x * s) + (y * c);
-      if (colOk && r < S && !(fabsf(cx) > windowWidth || fabsf(cy) > windowWidth)) {
-        float2 g = pixel_gradient(px, lmn, lmx, L.w, L.h, (int)llroundf(cx + kx), (int)llroundf(cy + ky));
-        float mag = sqrtf((g.x * g.x) + (g.y * g.y)) * expf(-((cx * cx) + (cy * cy)) / (2.0f * windowWidth * windowWidth));
-        float ang = fmodf(atan2f(g.y, g.x) - theta + (2.0f * pi), 2.0f * pi);
-        // orientation bins: every k with |ang - k*rad45| < rad45 (at most two); evaluated for all 8 k like the reference
+      cx = (x * c) + (y * s);
+      cy = (-x * s) + (y * c);
+      ok = colOk && r < S && !(fabsf(cx) > windowWidth || fabsf(cy) > windowWidth);
+    };
+    float ncx, ncy;
+    bool nok;
+    sample(rsub, ncx, ncy, nok);
+    float2 npg = make_float2(0.0f, 0.0f);
+    if (nok) npg = polar_at(L, seg, px, lmn, lmx, (int)roundf(ncx + kx), (int)roundf(ncy + ky));  // roundf == llroundf
+    for (int r0 = 0; r0 < S; r0 += rstep) {
+      const float cx = ncx, cy = ncy;
+      const bool ok = nok;
+      const float2 pg = npg;
+      sample(r0 + rstep + rsub, ncx, ncy, nok);
+      if (nok) npg = polar_at(L, seg, px, lmn, lmx, (int)roundf(ncx + kx), (int)roundf(ncy + ky));
+      if (ok) {
+        float mag = pg.x * expf(-((cx * cx) + (cy * cy)) / (2.0f * windowWidth * windowWidth));
+        float ang = fmod_2pi(pg.y - theta + (2.0f * pi), 2.0f * pi);
+        // orientation bins: every k with |ang - k*rad45| < rad45 (at most two).  Only k0-1..k0+1 around
+        // k0 = floor(ang/rad45) can pass (any other k is >= 1.99 rad45 away); the test itself is the reference's
         int ka = -1, kb = -1;
         float wa = 0.0f, wb = 0.0f;
+        const int k0 = (int)(ang * inv45);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int dk = -1; dk <= 1; ++dk) {
+          int k = k0 + dk;
           float angle = fabsf(ang - ((float)k * rad45));
-          if (angle < rad45) {
-            float wk = 1.0f - (angle / rad45);
-            if (ka < 0) { ka = k; wa = wk; }
-            else if (kb < 0) { kb = k; wb = wk; }
+          if (k >= 0 && k < 8 && angle < rad45) {
+            if (ka < 0) { ka = k; wa = angle; }
+            else if (kb < 0) { kb = k; wb = angle; }
           }
         }
+        wa = 1.0f - (wa * inv45);
+        wb = 1.0f - (wb * inv45);
+        // cells whose rotated centre lies within binWidth of the sample on both axes (:513-514): branch-free mask,
+        // then a per-lane loop over the (typically 4) set bits
+        unsigned pass = 0;
 #pragma unroll
         for (int cell = 0; cell < 16; ++cell) {
-          float hx = fabsf(rcx[cell] - cx), hy = fabsf(rcy[cell] - cy);
-          if (hx <= binWidth && hy <= binWidth) {
-            hx = hx / binWidth;
-            hy = hy / binWidth;
-            float wxy = (1.0f - hx) * (1.0f - hy);
-            if (ka >= 0) atomicAdd(&bins[cell * 8 + ka], wxy * wa * mag);
-            if (kb >= 0) atomicAdd(&bins[cell * 8 + kb], wxy * wb * mag);
-          }
+          bool in = (fabsf(rcx[cell] - cx) <= binWidth) && (fabsf(rcy[cell] - cy) <= binWidth);
+          pass |= in ? (1u << cell) : 0u;
+        }
+        while (pass) {
+          const int cell = __ffs((int)pass) - 1;
+          pass &= pass - 1;
+          // rotated centre of this cell, recomputed with the same expressions as above (no LDS read in this loop)
+          const float ux = ((float)(cell >> 2) * 0.5f - 0.75f) * windowWidth, uy = ((float)(cell & 3) * 0.5f - 0.75f) * windowWidth;
+          const float qx = (ux * c) + (uy * s), qy = (-ux * s) + (uy * c);
+          float hx = fabsf(qx - cx) * invBin, hy = fabsf(qy - cy) * invBin;
+          float wxy = (1.0f - hx) * (1.0f - hy);
+          if (ka >= 0) atomicAdd(&bins[(cell * 8 + ka) * 8 + copy], to_fixed(wxy * wa * mag));  // reference association
+          if (kb >= 0) atomicAdd(&bins[(cell * 8 + kb) * 8 + copy], to_fixed(wxy * wb * mag));
         }
       }
     }
     __builtin_amdgcn_wave_barrier();
     // normalise, clamp at 0.2, renormalise, quantise (:529-542); each lane owns bins lane and lane + 64
-    float v0 = bins[lane], v1 = bins[lane + 64];
+    unsigned long long t0 = 0ull, t1 = 0ull;
+#pragma unroll
+    for (int cpy = 0; cpy < 8; ++cpy) {
+      t0 += bins[lane * 8 + cpy];
+      t1 += bins[(lane + 64) * 8 + cpy];
+    }
+    float v0 = from_fixed(t0), v1 = from_fixed(t1);
     float sq = sqrtf(sv::wave_sum((v0 * v0) + (v1 * v1)));
     v0 = v0 / sq;
     v1 = v1 / sq;
@@ -513,6 +605,7 @@ LevelSet make_levels(const ssrlcv_sift_plan* plan, char* ws, int o) {
   const svp::OctavePlan& oc = plan->oct[o];
   for (int b = 0; b < svp::kDog; ++b) L.dog[b] = (const float*)(ws + oc.off_dog[b]);
   L.minmax = (const float*)(ws + plan->off_minmax) + (size_t)o * 2 * (svp::kGauss + svp::kDog) + 2 * svp::kGauss;
+  L.polar = (const float2*)(ws + oc.off_polar);
   L.w = (int)oc.w;
   L.h = (int)oc.h;
   return L;
@@ -656,6 +749,7 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
       swap();
     }
     if (stop >= 6) {  // computeKeyPointOrientations (src/FeatureFactory.cu:540-632)
+      hipLaunchKernelGGL(k_polar, dim3((oc.w + 255) / 256, oc.h, 3), dim3(256), 0, s, L, (float2*)(ws + oc.off_polar));
       float* thetas = (float*)(ws + oc.off_theta);
       uint32_t* thetaCnt = (uint32_t*)(ws + oc.off_thetaCnt);
       dim3 g(list_blocks(cap) * 2);

@@ -7,6 +7,7 @@
 //   gauss[6]   f32  6 P_0      the six gaussian levels of the octave being built (un-normalised); reused per octave
 //   dog[o][5]  f32  5 sum P    raw DoG levels of every octave (kept: extrema, refinement, gradients read them)
 //   flags[o]   u8   sum P      3 extremum bits per pixel (levels 1..3)
+//   polar[o]   f32x2 3 sum P   gradient magnitude / direction of DoG levels 1..3 (shared by orientation + descriptors)
 //   minmax     f32  4 x (6+5) x 2   per level {min,max} (gaussian, DoG)
 //   key points: per octave two ping-pong SSKeyPoint lists (capacity cap_o), theta lists, counters, index tables
 #pragma once
@@ -42,6 +43,7 @@ struct OctavePlan {
   uint32_t cap;            // key-point list capacity
   size_t off_dog[kDog];
   size_t off_flags;
+  size_t off_polar;        // float2 {|grad|, atan2} of the twice-normalised DoG levels 1..3 (3 * P * 8 bytes)
   size_t off_kpA, off_kpB; // SSKeyPoint ping-pong lists
   size_t off_theta;        // cap * kMaxOrient floats
   size_t off_thetaCnt;     // cap uint32 (number of orientations per key point)
