@@ -495,30 +495,30 @@ __global__ __launch_bounds__(256) void k_descriptors(const OctaveState* st, cons
     const float invBin = 1.0f / binWidth;   // hx / binWidth is evaluated as hx * (1/binWidth): <= 1 ulp from the division
     const float inv45 = 1.0f / rad45;
     const int S = 2 * (int)windowWidth + 1;
-    const bool two = S <= 32;
-    const int col = two ? (lane & 31) : lane;
-    const int rsub = two ? (lane >> 5) : 0;
-    const float x = -windowWidth + (float)col;  // integers: exact, equal to the reference's repeated += 1.0f
-    const bool colOk = col < S;
-    // The polar gather of row r+1 is issued before row r is processed: its HBM/L2 latency (the window of a key point
-    // is touched once per key point) would otherwise be exposed once per row, 30-60 times per key point.
-    const int rstep = two ? 2 : 1;
-    auto sample = [&](int r, float& cx, float& cy, bool& ok) {
+    // Samples are packed densely over the lanes (sample index -> (row, col) with a multiply-high by a per-key-point
+    // magic constant), so every lane works until the tail of the (2w+1)^2 window; votes are exact integers, so the
+    // visiting order does not matter.  The polar gather of the next batch is issued before the current one is used.
+    const unsigned total = (unsigned)(S * S);
+    const unsigned magic = (unsigned)((0x100000000ull + (unsigned long long)S - 1ull) / (unsigned long long)S);
+    auto sample = [&](unsigned sidx, float& cx, float& cy, bool& ok) {
+      const unsigned r = __umulhi(sidx, magic);  // sidx / S, exact for sidx < 2^16
+      const unsigned cc = sidx - r * (unsigned)S;
+      const float x = -windowWidth + (float)cc;  // integers: exact, equal to the reference's repeated += 1.0f
       const float y = -windowWidth + (float)r;
       cx = (x * c) + (y * s);
       cy = (-x * s) + (y * c);
-      ok = colOk && r < S && !(fabsf(cx) > windowWidth || fabsf(cy) > windowWidth);
+      ok = sidx < total && !(fabsf(cx) > windowWidth || fabsf(cy) > windowWidth);
     };
     float ncx, ncy;
     bool nok;
-    sample(rsub, ncx, ncy, nok);
+    sample((unsigned)lane, ncx, ncy, nok);
     float2 npg = make_float2(0.0f, 0.0f);
     if (nok) npg = polar_at(L, seg, px, lmn, lmx, (int)roundf(ncx + kx), (int)roundf(ncy + ky));  // roundf == llroundf
-    for (int r0 = 0; r0 < S; r0 += rstep) {
+    for (unsigned base = 0; base < total; base += 64) {
       const float cx = ncx, cy = ncy;
       const bool ok = nok;
       const float2 pg = npg;
-      sample(r0 + rstep + rsub, ncx, ncy, nok);
+      sample(base + 64 + (unsigned)lane, ncx, ncy, nok);
       if (nok) npg = polar_at(L, seg, px, lmn, lmx, (int)roundf(ncx + kx), (int)roundf(ncy + ky));
       if (ok) {
         float mag = pg.x * expf(-((cx * cx) + (cy * cy)) / (2.0f * windowWidth * windowWidth));
