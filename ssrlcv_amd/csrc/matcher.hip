@@ -39,7 +39,13 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int kKPad = 144;       // fp16 elements per packed row
 constexpr int kKSteps = 9;       // 144 / 16
-constexpr int kQT = 4;           // query tiles (of 32) held in registers per wave
+#ifndef SSRLCV_MATCH_QT
+#define SSRLCV_MATCH_QT 4
+#endif
+#ifndef SSRLCV_MATCH_WPS
+#define SSRLCV_MATCH_WPS 2
+#endif
+constexpr int kQT = SSRLCV_MATCH_QT;  // query tiles (of 32) held in registers per wave
 constexpr int kWaves = 4;        // waves per block
 constexpr int kQPerBlock = kWaves * kQT * 32;  // 512 queries per block
 constexpr unsigned long long kNoKey = ~0ull;
@@ -182,7 +188,7 @@ __device__ __forceinline__ unsigned long long make_key(float dist, uint32_t f) {
 // ---- the contraction ---------------------------------------------------------------------------------------------
 // grid.x: query blocks of 512, grid.y: target splits.  256 threads = 4 waves, one per SIMD; each wave keeps kQT query
 // tiles (B operands, 36 VGPRs each) resident and streams every target tile of its split through the matrix core.
-__global__ __launch_bounds__(256, 1) void k_match(const _Float16* __restrict__ packedQ, const _Float16* __restrict__ packedT,
+__global__ __launch_bounds__(256, SSRLCV_MATCH_WPS) void k_match(const _Float16* __restrict__ packedQ, const _Float16* __restrict__ packedT,
                                                   const float* __restrict__ normQ, const ssrlcv_float2* __restrict__ locT,
                                                   const Geom* __restrict__ geom, uint32_t nq, uint32_t nt,
                                                   uint32_t tilesPerSplit, int mode, float epsilon, float absThreshold,
@@ -211,46 +217,88 @@ __global__ __launch_bounds__(256, 1) void k_match(const _Float16* __restrict__ p
     key[qt] = kNoKey;
   }
 
-  for (uint32_t tt = tile0; tt < tile1; ++tt) {
-    half8 a[kKSteps];
-    const _Float16* trow = packedT + ((size_t)tt * 32 + col) * kKPad + kgrp * 8;
+  // v_min3_f32 directly: fminf() on MFMA outputs makes hipcc insert a canonicalising v_max per operand
+  auto min3 = [](float a, float b, float c) {
+    float r;
+    asm volatile("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+  };
+  // argmin epilogue of one 32x32 tile (query tile qt): v_min tree, wave-uniform branch, rare slow path
+  auto epilogue = [&](uint32_t tt, int qt, const floatx16& acc) {
+    float m0 = min3(acc[0], acc[1], acc[2]);
+    float m1 = min3(acc[3], acc[4], acc[5]);
+    float m2 = min3(acc[6], acc[7], acc[8]);
+    float m3 = min3(acc[9], acc[10], acc[11]);
+    float m4 = min3(acc[12], acc[13], acc[14]);
+    float m = min3(min3(m0, m1, m2), min3(m3, m4, acc[15]), m0);
+    if (__any(m <= bestAcc[qt])) {
+      // slow path: decode rows.  C/D layout of the 32x32 MFMA: row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+      Geom g;
+      if (mode == 1) g = geom[qbase + qt * 32 + col];
 #pragma unroll
-    for (int s = 0; s < kKSteps; ++s) a[s] = *reinterpret_cast<const half8*>(trow + s * 16);
-#pragma unroll
-    for (int qt = 0; qt < kQT; ++qt) {
-      floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-      for (int s = 0; s < kKSteps; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], bq[qt][s], acc, 0, 0, 0);
-      float m0 = fminf(fminf(acc[0], acc[1]), acc[2]);
-      float m1 = fminf(fminf(acc[3], acc[4]), acc[5]);
-      float m2 = fminf(fminf(acc[6], acc[7]), acc[8]);
-      float m3 = fminf(fminf(acc[9], acc[10]), acc[11]);
-      float m4 = fminf(fminf(acc[12], acc[13]), acc[14]);
-      float m = fminf(fminf(fminf(m0, m1), fminf(m2, m3)), fminf(m4, acc[15]));
-      if (__any(m <= bestAcc[qt])) {
-        // slow path: decode rows.  C/D layout of the 32x32 MFMA: row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
-        Geom g;
-        if (mode == 1) g = geom[qbase + qt * 32 + col];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[r];
-          if (v <= bestAcc[qt]) {
-            uint32_t f = tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
-            float d = na[qt] + v;  // exact integer
-            bool ok = (f < nt) && (d < absThreshold);
-            if (ok && mode == 1) ok = passes_prefilter(g, locT[f], epsilon);
-            if (ok) {
-              unsigned long long k = make_key(d, f);
-              if (k < key[qt]) {
-                key[qt] = k;
-                bestAcc[qt] = v;
-              }
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[r];
+        if (v <= bestAcc[qt]) {
+          uint32_t f = tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
+          float d = na[qt] + v;  // exact integer
+          bool ok = (f < nt) && (d < absThreshold);
+          if (ok && mode == 1) ok = passes_prefilter(g, locT[f], epsilon);
+          if (ok) {
+            unsigned long long k = make_key(d, f);
+            if (k < key[qt]) {
+              key[qt] = k;
+              bestAcc[qt] = v;
             }
           }
         }
       }
     }
+  };
+  // The MFMA chain of query tile qt+1 is issued before the epilogue of tile qt: the matrix pipe runs the 9 MFMAs
+  // (9 x 32 cycles) while the VALU does the ~20-instruction min tree of the previous accumulator.
+  auto process_tile = [&](uint32_t tt, const half8 (&a)[kKSteps]) {
+    floatx16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1;
+#pragma unroll
+    for (int s = 0; s < kKSteps; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], bq[0][s], acc0, 0, 0, 0);
+#pragma unroll
+    for (int qt = 1; qt < kQT; ++qt) {
+      floatx16& cur = (qt & 1) ? acc1 : acc0;
+      floatx16& prev = (qt & 1) ? acc0 : acc1;
+      cur = floatx16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < kKSteps; ++s) cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], bq[qt][s], cur, 0, 0, 0);
+      epilogue(tt, qt - 1, prev);
+    }
+    epilogue(tt, kQT - 1, ((kQT - 1) & 1) ? acc1 : acc0);
+  };
+  // Target tiles stream straight from L2 into registers (all blocks walk the same tiles at about the same time, so
+  // the 75 MB target set is served by L2 / Infinity Cache).  Staging them through LDS with one barrier per tile
+  // measured 25 % slower at one wave per SIMD.
+  auto load_tile = [&](uint32_t tt, half8 (&dst)[kKSteps]) {
+    const _Float16* trow = packedT + ((size_t)tt * 32 + col) * kKPad + kgrp * 8;
+#pragma unroll
+    for (int s2 = 0; s2 < kKSteps; ++s2) dst[s2] = *reinterpret_cast<const half8*>(trow + s2 * 16);
+  };
+#if SSRLCV_MATCH_WPS >= 2
+  // two waves per SIMD: the partner wave hides the load latency, one register buffer suffices
+  for (uint32_t tt = tile0; tt < tile1; ++tt) {
+    half8 a[kKSteps];
+    load_tile(tt, a);
+    process_tile(tt, a);
   }
+#else
+  // one wave per SIMD: two register buffers, the loads of tile tt+1 fly under the 36 MFMAs of tile tt
+  half8 bufA[kKSteps], bufB[kKSteps];
+  if (tile0 < tile1) load_tile(tile0, bufA);
+  for (uint32_t tt = tile0; tt < tile1; tt += 2) {
+    if (tt + 1 < tile1) load_tile(tt + 1, bufB);
+    process_tile(tt, bufA);
+    if (tt + 1 < tile1) {
+      if (tt + 2 < tile1) load_tile(tt + 2, bufA);
+      process_tile(tt + 1, bufB);
+    }
+  }
+#endif
   // merge: lanes l and l+32 hold the same query (different target rows); other splits merge through the atomic
 #pragma unroll
   for (int qt = 0; qt < kQT; ++qt) {
