@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=4096, help="image edge (config[2]: 2-view 4096x4096)")
     ap.add_argument("--images", type=int, default=2, help="images per rank per step (one pair)")
-    ap.add_argument("--match-n", type=int, default=1 << 17, help="Nq = Nt of the stand-alone matcher measurement")
+    ap.add_argument("--match-n", type=int, default=1 << 18, help="Nq = Nt of the stand-alone matcher measurement")
     ap.add_argument("--match-iters", type=int, default=3)
     ap.add_argument("--cpu-size", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -227,16 +227,24 @@ __global__ __launch_bounds__(kTX) void k_gauss_fused(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < kNR; ++i) win[2 * R + i] = s_h[i * kTX + tid];
     const int gx = x0 + tid;
+    {
+      // k outer / i inner: eight independent fmaf chains in flight (each output's own chain still runs k = 0..2R)
+      float vs[kNR];
 #pragma unroll
-    for (int i = 0; i < kNR; ++i) {
-      float sum = 0.0f;
+      for (int i = 0; i < kNR; ++i) vs[i] = 0.0f;
 #pragma unroll
-      for (int k = 0; k <= 2 * R; ++k) sum = __builtin_fmaf(win[i + k], a.wgt[k <= R ? k : 2 * R - k], sum);
-      int j = s * kNR - 2 * R + i;
-      if (j >= 0 && j < nrows && gx < W) {
-        a.out[(size_t)(y0 + j) * W + gx] = sum;
-        mn = fminf(mn, sum);
-        mx = fmaxf(mx, sum);
+      for (int k = 0; k <= 2 * R; ++k) {
+#pragma unroll
+        for (int i = 0; i < kNR; ++i) vs[i] = __builtin_fmaf(win[i + k], a.wgt[k <= R ? k : 2 * R - k], vs[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < kNR; ++i) {
+        int j = s * kNR - 2 * R + i;
+        if (j >= 0 && j < nrows && gx < W) {
+          a.out[(size_t)(y0 + j) * W + gx] = vs[i];
+          mn = fminf(mn, vs[i]);
+          mx = fmaxf(mx, vs[i]);
+        }
       }
     }
 #pragma unroll
