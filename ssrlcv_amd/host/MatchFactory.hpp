@@ -191,59 +191,41 @@ class MatchFactory {
       logger.err << "exiting...";
       std::exit(0);
     }
-    // adjacency lists per (query image, feature), filled in pair order
+    // host merge (adjacency lists + consistency walk, :943-1005) lives in the library so that the single-GPU shell
+    // and the multi-GPU driver share one implementation
     const size_t V = images.size();
-    std::vector<std::vector<std::vector<uint2>>> adj(V - 1);
-    for (size_t i = 0; i + 1 < V; ++i) adj[i].resize(features[i]->size());
+    std::vector<uint32_t> numFeatures(V), pairCounts;
+    std::vector<uint2_pair> allPairs;
+    for (size_t i = 0; i < V; ++i) numFeatures[i] = (uint32_t)features[i]->size();
     for (auto& m : matchIndices) {
       if (m->getMemoryState() != cpu) m->setMemoryState(cpu);
-      uint2_pair* h = m->host.get();
-      for (unsigned long p = 0; p < m->size(); ++p) adj[h[p].a.x][h[p].a.y].push_back(h[p].b);
+      pairCounts.push_back((uint32_t)m->size());
+      allPairs.insert(allPairs.end(), m->host.get(), m->host.get() + m->size());
     }
+    ssrlcv_multimatch* mm_raw = nullptr;
+    ssrlcv_uint2* mem_raw = nullptr;
+    uint32_t nmm = 0, nmem = 0;
+    HipSafeCall(ssrlcv_merge_matches_host((uint32_t)V, numFeatures.data(), (uint32_t)pairCounts.size(), pairCounts.data(),
+                                          reinterpret_cast<const ssrlcv_uint2_pair*>(allPairs.data()), &mm_raw, &mem_raw,
+                                          &nmm, &nmem));
     std::vector<MemoryState> origin(V);
-    std::vector<std::vector<uint2>> multiMatch_vec;
-    for (size_t i = 0; i + 1 < V; ++i) {
+    for (size_t i = 0; i < V; ++i) {
       origin[i] = features[i]->getMemoryState();
-      if (origin[i] != cpu) features[i]->setMemoryState(cpu);
-      for (size_t f = 0; i + 2 < V && f < features[i]->size(); ++f) {  // only images 0..V-3 seed multi-matches (:969)
-        std::vector<uint2>* a = &adj[i][f];
-        if (a->empty()) continue;
-        bool badMatch = false;
-        std::vector<uint2>* prev = a;
-        while (true) {
-          if (prev->begin()->x == V - 1) break;
-          std::vector<uint2>* next = &adj[prev->begin()->x][prev->begin()->y];
-          if (next->empty()) break;
-          std::vector<uint2> inter;
-          std::set_intersection(prev->begin(), prev->end(), next->begin(), next->end(), std::back_inserter(inter));
-          if (inter.size() != next->size()) { badMatch = true; break; }
-          else if (next->size() == 1) break;
-          else prev = next;
-        }
-        if (badMatch) { a->clear(); continue; }
-        std::vector<uint2> match;
-        match.push_back({(unsigned int)i, (unsigned int)f});
-        match.insert(match.end(), a->begin(), a->end());
-        multiMatch_vec.push_back(match);
-        for (auto m = a->begin(); m != a->end() - 1; ++m) {
-          if (m->x == V - 1) break;
-          adj[m->x][m->y].clear();
-        }
-      }
+      if (origin[i] != cpu && origin[i] != both) features[i]->setMemoryState(cpu);
+      else if (origin[i] == both && features[i]->getFore() == gpu) features[i]->transferMemoryTo(cpu);
     }
-    logger.info.printf("total matches found in set = %d", (int)multiMatch_vec.size());
-    matchSet.matches = ptr::value<Unity<MultiMatch>>(nullptr, (unsigned long)multiMatch_vec.size(), cpu);
-    std::vector<KeyPoint> kp_vec;
-    int index = 0, k = 0;
-    for (auto& m : multiMatch_vec) {
-      matchSet.matches->host.get()[k++] = {(unsigned int)m.size(), index};
-      index += (int)m.size();
-      for (auto& kp : m) kp_vec.push_back({(int)kp.x, features[kp.x]->host.get()[kp.y].loc});
-    }
+    logger.info.printf("total matches found in set = %d", (int)nmm);
+    matchSet.matches = ptr::value<Unity<MultiMatch>>(nullptr, (unsigned long)nmm, cpu);
+    std::memcpy(matchSet.matches->host.get(), mm_raw, sizeof(MultiMatch) * nmm);
+    std::vector<KeyPoint> kp_vec(nmem);
+    for (uint32_t k = 0; k < nmem; ++k)
+      kp_vec[k] = {(int)mem_raw[k].x, features[mem_raw[k].x]->host.get()[mem_raw[k].y].loc};
+    ssrlcv_host_free(mm_raw);
+    ssrlcv_host_free(mem_raw);
     matchSet.keyPoints = ptr::value<Unity<KeyPoint>>(nullptr, (unsigned long)kp_vec.size(), gpu);
     HipSafeCall(ssrlcv_hip_memcpy(matchSet.keyPoints->device.get(), kp_vec.data(), kp_vec.size() * sizeof(KeyPoint), 0));
-    for (size_t i = 0; i + 1 < V; ++i)
-      if (origin[i] != cpu) features[i]->setMemoryState(origin[i]);
+    for (size_t i = 0; i < V; ++i)
+      if (origin[i] != cpu && origin[i] != both) features[i]->setMemoryState(origin[i]);
     return matchSet;
   }
 };

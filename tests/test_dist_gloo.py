@@ -1,0 +1,120 @@
+"""world_size-2 gloo tests of the multi-GPU exchange logic (runs on CPU): variable-length all-gather, keyed exchange
+of per-image feature arrays and per-pair uint2_pair arrays, and the replicated deterministic merge, checked against
+the single-process result and the oracle's merge."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import helpers as H
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _synthetic_pairs(num_images, num_features, seed):
+    """Consistent random matches between images: a hidden 'track id' per feature makes some chains transitive."""
+    rng = np.random.default_rng(seed)
+    tracks = [rng.permutation(4 * nf)[:nf] for nf in num_features]
+    lists = []
+    from ssrlcv_amd import dist as sd
+    for (i, j) in sd.pair_list(num_images):
+        lookup = {t: idx for idx, t in enumerate(tracks[j])}
+        rows = []
+        for f, t in enumerate(tracks[i]):
+            if t in lookup and rng.random() < 0.9:
+                rows.append((i, f, j, lookup[t]))
+            elif rng.random() < 0.05:
+                rows.append((i, f, j, int(rng.integers(0, num_features[j]))))  # inconsistent match
+        arr = np.array(rows, np.uint32).reshape(-1, 4) if rows else np.zeros((0, 4), np.uint32)
+        lists.append(arr)
+    return lists
+
+
+def _worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ssrlcv_amd import dist as sd
+    try:
+        # variable-length all-gather, including an empty contribution
+        local = torch.arange(rank * 5, dtype=torch.uint8)
+        got = sd.all_gather_bytes(local)
+        assert [g.numel() for g in got] == [r * 5 for r in range(world)]
+        assert all(torch.equal(g, torch.arange(r * 5, dtype=torch.uint8)) for r, g in enumerate(got))
+        # exchange 1: per-image feature arrays owned by image % world
+        num_images, num_features = 4, [300, 280, 310, 290]
+        feats = {}
+        for v in range(num_images):
+            if sd.image_owner(v, world) == rank:
+                rng = np.random.default_rng(100 + v)
+                feats[v] = torch.from_numpy(rng.integers(0, 256, num_features[v] * 152, dtype=np.uint8))
+        allf = sd.exchange_keyed(feats, num_images, sd.image_owner)
+        for v in range(num_images):
+            rng = np.random.default_rng(100 + v)
+            assert torch.equal(allf[v], torch.from_numpy(rng.integers(0, 256, num_features[v] * 152, dtype=np.uint8)))
+        # exchange 2: per-pair uint2_pair arrays owned by pair index % world, then the replicated merge
+        pair_lists = _synthetic_pairs(num_images, num_features, 7)
+        mine = {p: torch.from_numpy(pair_lists[p].view(np.uint8).reshape(-1).copy())
+                for p in range(len(pair_lists)) if sd.pair_owner(p, world) == rank}
+        allp = sd.exchange_keyed(mine, len(pair_lists), sd.pair_owner)
+        for p in range(len(pair_lists)):
+            assert np.array_equal(allp[p].numpy().view(np.uint32).reshape(-1, 4), pair_lists[p])
+        mm, mem = sd.merge_matches(num_features, allp)
+        np.save(os.path.join(tmp, "mm_%d.npy" % rank), mm)
+        np.save(os.path.join(tmp, "mem_%d.npy" % rank), mem)
+        lo, hi = sd.bundle_range(len(mm), world, rank)
+        assert 0 <= lo <= hi <= len(mm)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_rank_exchange_and_replicated_merge(tmp_path, oracle_lib):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mm0, mm1 = np.load(tmp_path / "mm_0.npy"), np.load(tmp_path / "mm_1.npy")
+    mem0, mem1 = np.load(tmp_path / "mem_0.npy"), np.load(tmp_path / "mem_1.npy")
+    assert np.array_equal(mm0, mm1) and np.array_equal(mem0, mem1)  # replicated merge is deterministic
+    assert len(mm0) > 50 and (mm0["numKeyPoints"] >= 2).all() and (mm0["numKeyPoints"] <= 4).all()
+    # single-process product merge and the oracle's restatement agree with the 2-rank result
+    from ssrlcv_amd import dist as sd
+    num_features = [300, 280, 310, 290]
+    lists = _synthetic_pairs(4, num_features, 7)
+    tens = [torch.from_numpy(l.view(np.uint8).reshape(-1).copy()) for l in lists]
+    mm_s, mem_s = sd.merge_matches(num_features, tens)
+    assert np.array_equal(mm_s, mm0) and np.array_equal(mem_s, mem0)
+    omm, omem = H.oracle_merge(oracle_lib, num_features, [l.view(H.UINT2_PAIR).reshape(-1) for l in lists])
+    assert np.array_equal(omm["numKeyPoints"], mm0["numKeyPoints"]) and np.array_equal(omm["index"], mm0["index"])
+    assert np.array_equal(omem, mem0)
+
+
+def test_merge_reproduces_reference_3view_fixture(oracle_lib, everest_oracle_features):
+    """The library's host merge on the oracle's pair lists -> the reference's Pipeline3View MultiMatch fixture."""
+    from ssrlcv_amd import dist as sd
+    feats = everest_oracle_features
+    seed, _ = H.load_seed_features()
+    v = H.load_view("Pipeline3View")
+    cams = v["cameras"]
+    pair_lists = []
+    for qi in range(2):
+        sdist = H.oracle_seed_distances(oracle_lib, feats[qi], seed)
+        for ti in range(qi + 1, 3):
+            proj = H.oracle_projection(oracle_lib, cams[ti:ti + 1])
+            pr = H.oracle_match_pairs(oracle_lib, 1, qi, feats[qi], ti, feats[ti], cams[qi:qi + 1], proj, 25.0, 5.0,
+                                      sdist, 0.6, 200.0 * 200.0)
+            pair_lists.append(pr[~(pr["a"] == pr["b"]).all(1)])
+    tens = [torch.from_numpy(p.view(np.uint8).reshape(-1).copy()) for p in pair_lists]
+    mm, mem = sd.merge_matches([len(f) for f in feats], tens)
+    assert len(mm) == 21177
+    assert np.array_equal(mm["numKeyPoints"], v["mm0"]["numKeyPoints"]) and np.array_equal(mm["index"], v["mm0"]["index"])
+    assert np.array_equal(mem[:, 0].astype(np.int32), v["kp0"]["parentId"])

@@ -192,3 +192,27 @@ def test_everest_end_to_end_reproduces_reference_matches(capi, oracle_lib):
     pts_d, _, _ = capi.triangulate(l_d, b_d, len(v["mm0"]))
     diff = pts_d.cpu().numpy().reshape(-1, 3) - v["points0"]
     assert float(np.sqrt((diff.astype(np.float64) ** 2).sum(1).mean())) <= 1e-4
+
+
+def test_nview_flow_single_rank_matches_3view_fixture(capi):
+    """ssrlcv_amd.pipeline.reconstruct (the multi-GPU driver at world size 1) on the three everest fixtures:
+    MultiMatch structure and cloud vs Pipeline3View golden outputs."""
+    from ssrlcv_amd import pipeline
+    pix = [capi.to_dev(p).view(1024, 1024) for p in H.load_everest_pixels()]
+    seed, _ = H.load_seed_features()
+    v = H.load_view("Pipeline3View")
+    res = pipeline.reconstruct(pix, v["cameras"], seed_features=seed)
+    mm, kp = res["matches"], res["keypoints"]
+    ref_mm, ref_kp = v["mm0"], v["kp0"]
+    assert abs(len(mm) - len(ref_mm)) <= 0.01 * len(ref_mm)
+
+    def groups(kparr, mmarr):
+        return {tuple((int(k["parentId"]), float(k["loc"][0]), float(k["loc"][1])) for k in kparr[i: i + n])
+                for n, i in zip(mmarr["numKeyPoints"], mmarr["index"])}
+    got, ref = groups(kp, mm), groups(ref_kp, ref_mm)
+    assert len(got & ref) >= 0.985 * len(ref)
+    pts = res["points"].cpu().numpy()
+    assert pts.shape == (len(mm), 3) and np.isfinite(pts).all()
+    if len(mm) == len(ref_mm) and np.array_equal(kp["loc"], ref_kp["loc"]):
+        diff = pts - v["points0"]
+        assert float(np.sqrt((diff.astype(np.float64) ** 2).sum(1).mean())) <= 2.5e-3
