@@ -173,6 +173,12 @@ def main():
     pyr_ms = float(np.mean([e[0].elapsed_time(e[1]) for st in events for e in st]))
 
     if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pyramid_traffic.json")
+        if W == 4096 and H_ == 4096 and os.path.exists(tpath):
+            # HBM bytes of the pyramid stage per image from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+            # same command (collected off-line: counters cannot be read from inside the timed run)
+            traffic = json.load(open(tpath))["pyramid_stage_bytes_per_image"]
         pixels_per_step = world * args.images * W * H_
         value = pixels_per_step * args.steps / dt / 1e6
         b_pyr = 362.25 * W * H_  # bytes per image
@@ -186,7 +192,7 @@ def main():
                                    "(sparse DoG path) on each image, pixels resident in HBM" % (W, H_),
                        "images_per_gpu": args.images, "features_per_image": nfeat, "parallelism": "image-pair shard"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "DoG pyramid stage = ssrlcv_hip_sift_build_dog (upsample, 24 k_gauss_fused, 3 bin, "
                                    "4 k_dog launches per image); algorithmic bytes 362.25*W*H per image",
                          "ms_per_image": pyr_ms},
