@@ -2,8 +2,8 @@
 // (include/PointCloudFactory.cuh:25-48,93-255), bound to the HIP C ABI: generateBundles, the two-view / N-view
 // triangulators and BundleAdjustTwoView.  Memory-state side effects follow upstream: generateBundles leaves the match
 // set on the cpu (src/PointCloudFactory.cu:909-914), triangulators return the cloud on the cpu and drop the gpu copies
-// of lines/bundles (:286-290).  Filters, stereo disparity, plane fitting, debug dumps and cloud scale/rotate helpers are
-// out of scope for this round (filters are section 8f item 1).
+// of lines/bundles (:286-290).  linearCutoffFilter / deterministicStatisticalFilter (section 8f item 1) are provided;
+// stereo disparity, plane fitting, debug dumps and cloud scale/rotate helpers are out of scope.
 //
 // BundleAdjustTwoView keeps upstream's control flow (:1832-2262) but evaluates all 24 + 588 finite-difference points
 // of calculateImageGradient / calculateImageHessian (:1059-1504) in ONE fused launch (ssrlcv_hip_ba_sweep2) instead of
@@ -175,6 +175,88 @@ class PointCloudFactory {
   ptr::value<Unity<float3>> nViewTriangulate(BundleSet bundleSet, ptr::value<Unity<float>> errors, float* angularError, float* angularErrorCutoff) {
     *angularError = 0;
     return triangulate(true, bundleSet, errors, angularError, angularErrorCutoff, true);
+  }
+
+  // ---- filters between triangulation and BA (src/Pipeline.cu:297-352) ----------------
+ private:
+  // shared tail of linearCutoffFilter / deterministicStatisticalFilter: drop the bundles flagged invalid and rebuild
+  // the MatchSet (2-view: re-indexed {2, 2k}; N-view: running index), src/PointCloudFactory.cu:3118-3274, :3517-3644
+  void dropInvalidBundles(MatchSet* matchSet, BundleSet& bundleSet, bool twoView, bool returnIfNoneBad) {
+    unsigned long nb = bundleSet.bundles->size();
+    Bundle* b = bundleSet.bundles->host.get();
+    unsigned long bad_bundles = 0, bad_lines = 0;
+    for (unsigned long k = 0; k < nb; ++k)
+      if (b[k].invalid) { bad_bundles++; bad_lines += b[k].numLines; }
+    if (returnIfNoneBad && !bad_bundles) return;
+    if (!(matchSet->matches->size() - bad_bundles)) return;
+    if (!twoView && !(matchSet->keyPoints->size() - bad_lines)) return;
+    ptr::value<Unity<KeyPoint>> oldKp = matchSet->keyPoints;
+    unsigned long newKp = twoView ? 2 * (matchSet->matches->size() - bad_bundles) : matchSet->keyPoints->size() - bad_lines;
+    unsigned long newMt = matchSet->matches->size() - bad_bundles;
+    matchSet->keyPoints = ptr::value<Unity<KeyPoint>>(nullptr, newKp, cpu);
+    matchSet->matches = ptr::value<Unity<MultiMatch>>(nullptr, newMt, cpu);
+    KeyPoint* src = oldKp->host.get();
+    KeyPoint* dst = matchSet->keyPoints->host.get();
+    MultiMatch* mm = matchSet->matches->host.get();
+    if (twoView) {
+      int k_adjust = 0;
+      for (unsigned long k = 0; k < nb; ++k)
+        if (!b[k].invalid) {
+          dst[2 * k_adjust] = src[2 * k];
+          dst[2 * k_adjust + 1] = src[2 * k + 1];
+          mm[k_adjust] = {2, 2 * k_adjust};
+          k_adjust++;
+        }
+    } else {
+      int k_adjust = 0, k_bundle = 0, k_keypnt = 0;
+      for (unsigned long k = 0; k < nb; ++k) {
+        unsigned int k_lines = b[k].numLines;
+        if (!b[k].invalid) {
+          mm[k_bundle] = {k_lines, k_adjust};
+          for (unsigned int j = 0; j < k_lines; ++j) dst[k_adjust + j] = src[k_keypnt + j];
+          k_adjust += (int)k_lines;
+          k_bundle++;
+        }
+        k_keypnt += (int)k_lines;
+      }
+    }
+  }
+
+ public:
+  // src/PointCloudFactory.cu:3500-3644
+  void linearCutoffFilter(MatchSet* matchSet, std::vector<ptr::value<Image>> images, float cutoff) {
+    if (cutoff < 0.0) return;
+    float linearError = 0.0, linearErrorCutoff = cutoff;
+    BundleSet bundleSet = generateBundles(matchSet, images);
+    ptr::value<Unity<float>> errors(nullptr, matchSet->matches->size(), cpu);
+    if (images.size() == 2) twoViewTriangulate(bundleSet, errors, &linearError, &linearErrorCutoff);
+    else nViewTriangulate(bundleSet, errors, &linearError, &linearErrorCutoff);
+    dropInvalidBundles(matchSet, bundleSet, images.size() == 2, true);
+  }
+  // src/PointCloudFactory.cu:3070-3275: cutoff = sigma * stddev of every (1/sampleSize)-th error (mean NOT added)
+  void deterministicStatisticalFilter(MatchSet* matchSet, std::vector<ptr::value<Image>> images, float sigma, float sampleSize) {
+    if (sampleSize > 1.0 || sampleSize < 0.0) return;
+    int sampleJump = (int)(1 / sampleSize);
+    float linearError = 0.0, linearErrorCutoff = 0.0;
+    BundleSet bundleSet = generateBundles(matchSet, images);
+    ptr::value<Unity<float>> errors(nullptr, matchSet->matches->size(), cpu);
+    const bool twoView = images.size() == 2;
+    if (twoView) twoViewTriangulate(bundleSet, errors, &linearError, &linearErrorCutoff);
+    else nViewTriangulate(bundleSet, errors, &linearError, &linearErrorCutoff);
+    size_t sample_size = (int)(errors->size() - (errors->size() % sampleJump)) / sampleJump;
+    float sample_sum = 0;
+    for (size_t k = 0; k < sample_size; k++) sample_sum += errors->host.get()[k * sampleJump];
+    float sample_mean = sample_sum / sample_size;
+    float squared_sum = 0;
+    for (size_t k = 0; k < sample_size; k++) {
+      float e = errors->host.get()[k * sampleJump];
+      squared_sum += (e - sample_mean) * (e - sample_mean);
+    }
+    float variance = squared_sum / sample_size;
+    linearErrorCutoff = sigma * sqrtf(variance);
+    if (twoView) twoViewTriangulate(bundleSet, errors, &linearError, &linearErrorCutoff);
+    else nViewTriangulate(bundleSet, errors, &linearError, &linearErrorCutoff);
+    dropInvalidBundles(matchSet, bundleSet, twoView, !twoView);
   }
 
   // f(cameras) for K parameter sets in one launch; params_host = K x (6 * images) floats

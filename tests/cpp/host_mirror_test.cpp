@@ -169,6 +169,34 @@ static int pipeline_mode(const std::string& dir, int views) {
   return 0;
 }
 
+// doFiltering (src/Pipeline.cu:297-352) from the reference's stage-0 MatchSet checkpoint
+static int filter_mode(const std::string& dir, int views) {
+  std::vector<ptr::value<Image>> images;
+  for (int i = 0; i < views; ++i)
+    images.push_back(ptr::value<Image>(dir + "/" + std::to_string(i) + "_" + typeid(Image).name() + ".cpimg", i));
+  MatchSet matchSet;
+  matchSet.keyPoints = ptr::value<Unity<KeyPoint>>(cp_path<KeyPoint>(dir, 0));
+  matchSet.matches = ptr::value<Unity<MultiMatch>>(cp_path<MultiMatch>(dir, 0));
+  PointCloudFactory pcf;
+  float err = 0;
+  ptr::value<Unity<float3>> points;
+  if (views == 2) {
+    pcf.linearCutoffFilter(&matchSet, images, 100.0);
+    pcf.deterministicStatisticalFilter(&matchSet, images, 3.0, 0.1);
+    BundleSet bs = pcf.generateBundles(&matchSet, images);
+    points = pcf.twoViewTriangulate(bs, &err);
+  } else {
+    pcf.deterministicStatisticalFilter(&matchSet, images, 3.0, 0.1);
+    BundleSet bs = pcf.generateBundles(&matchSet, images);
+    points = pcf.nViewTriangulate(bs, &err);
+  }
+  matchSet.keyPoints->checkpoint(201, dir + "/");
+  matchSet.matches->checkpoint(201, dir + "/");
+  points->checkpoint(201, dir + "/");
+  std::printf("filtered %lu error %f\nfilter ok\n", matchSet.matches->size(), err);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   std::string mode = argc > 1 ? argv[1] : "typeinfo";
   try {
@@ -177,6 +205,8 @@ int main(int argc, char** argv) {
     if (mode == "cpu") return cpu_mode(argv[2]);
     if (mode == "pipeline2") return pipeline_mode(argv[2], 2);
     if (mode == "pipeline3") return pipeline_mode(argv[2], 3);
+    if (mode == "filter2") return filter_mode(argv[2], 2);
+    if (mode == "filter3") return filter_mode(argv[2], 3);
   } catch (std::exception& e) {
     std::fprintf(stderr, "exception: %s\n", e.what());
     return 3;

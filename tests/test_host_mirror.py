@@ -120,3 +120,83 @@ def test_reference_stage_flow_through_class_api(tmp_path, views):
         # BundleAdjustTwoView is an identity on the cloud upstream (2_6float3.uty == 1_6float3.uty)
         assert adj.shape == pts.shape
         assert np.abs(adj - pts).max() <= 5e-4
+
+
+def _filter_numpy(lib, mm, kp, cams, nview):
+    """doFiltering restated with numpy + oracle primitives (test-side checker):
+    linearCutoffFilter(100) [2-view only] then deterministicStatisticalFilter(3 sigma, 10 %)."""
+    def drop(mm, kp, invalid, two):
+        keep = invalid == 0
+        if two:
+            idx = np.nonzero(keep)[0]
+            nkp = np.zeros(2 * len(idx), H.KEYPOINT)
+            nkp[0::2], nkp[1::2] = kp[2 * idx], kp[2 * idx + 1]
+            nmm = np.zeros(len(idx), H.MULTIMATCH)
+            nmm["numKeyPoints"], nmm["index"] = 2, 2 * np.arange(len(idx))
+            return nmm, nkp
+        rows = [kp[i: i + n] for n, i, k in zip(mm["numKeyPoints"], mm["index"], keep) if k]
+        nmm = np.zeros(int(keep.sum()), H.MULTIMATCH)
+        nmm["numKeyPoints"] = mm["numKeyPoints"][keep]
+        nmm["index"] = np.concatenate([[0], np.cumsum(nmm["numKeyPoints"])[:-1]])
+        return nmm, np.concatenate(rows)
+
+    def flags(mm, kp, cutoff):
+        b, l, _ = H.oracle_bundles(lib, mm, kp, cams)
+        _, errs, _ = H.oracle_triangulate(lib, nview, b, l, want_errors=True, cutoff=cutoff)
+        return b["invalid"], errs
+    two = not nview
+    if two:
+        inv, _ = flags(mm, kp, 100.0)
+        if inv.any():
+            mm, kp = drop(mm, kp, inv, True)
+    _, errs = flags(mm, kp, 0.0)
+    jump = int(1 / 0.1)
+    n = (len(errs) - len(errs) % jump) // jump
+    sample = errs[: n * jump: jump].astype(np.float32)
+    mean = np.float32(0)
+    for e in sample:
+        mean = np.float32(mean + e)
+    mean = np.float32(mean / np.float32(n))
+    sq = np.float32(0)
+    for e in sample:
+        sq = np.float32(sq + np.float32((e - mean) * (e - mean)))
+    cutoff = np.float32(3.0) * np.sqrt(np.float32(sq / np.float32(n)), dtype=np.float32)
+    inv, _ = flags(mm, kp, float(cutoff))
+    if two or inv.any():
+        mm, kp = drop(mm, kp, inv, two)
+    return mm, kp
+
+
+@pytest.mark.parametrize("views", [2, 3])
+def test_filter_semantics_pinned_by_reference_fixtures(oracle_lib, views):
+    """0_KeyPoint/0_MultiMatch -> 1_KeyPoint/1_MultiMatch (13 534 -> 13 308, 21 177 -> 21 099): pins the filters'
+    cutoff rule (3 * stddev of every 10th error, mean not added) and the MatchSet re-indexing."""
+    v = H.load_view("Pipeline%dView" % views)
+    mm, kp = _filter_numpy(oracle_lib, v["mm0"], v["kp0"], v["cameras"], views > 2)
+    assert len(mm) == len(v["mm1"])
+    assert np.array_equal(mm["numKeyPoints"], v["mm1"]["numKeyPoints"]) and np.array_equal(mm["index"], v["mm1"]["index"])
+    assert np.array_equal(kp["loc"], v["kp1"]["loc"]) and np.array_equal(kp["parentId"], v["kp1"]["parentId"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("views", [2, 3])
+def test_filter_stage_through_class_api_matches_fixture(tmp_path, views):
+    """doFiltering through PointCloudFactory::{linearCutoffFilter, deterministicStatisticalFilter} on the GPU."""
+    d = str(tmp_path)
+    info = typeinfo()
+    v = np.load(os.path.join(H.GOLDEN, "Pipeline%dView.npz" % views))
+    gv = H.load_view("Pipeline%dView" % views)
+    for i in range(views):
+        open(os.path.join(d, "%d_N6ssrlcv5ImageE.cpimg" % i), "wb").write(v["cpimg_raw"][i].tobytes())
+    write_uty(os.path.join(d, "0_%s.uty" % info["KeyPoint"][0]), *info["KeyPoint"], 1, gv["kp0"])
+    write_uty(os.path.join(d, "0_%s.uty" % info["MultiMatch"][0]), *info["MultiMatch"], 1, gv["mm0"])
+    out = subprocess.check_output([build_binary(), "filter%d" % views, d]).decode()
+    assert "filter ok" in out, out
+    kp, _, _ = read_uty(os.path.join(d, "201_N6ssrlcv8KeyPointE.uty"), H.KEYPOINT)
+    mm, _, _ = read_uty(os.path.join(d, "201_N6ssrlcv10MultiMatchE.uty"), H.MULTIMATCH)
+    pts, _, _ = read_uty(os.path.join(d, "201_6float3.uty"), np.dtype(("<f4", (3,))))
+    assert len(mm) == len(gv["mm1"])
+    assert np.array_equal(kp["loc"], gv["kp1"]["loc"]) and np.array_equal(mm["index"], gv["mm1"]["index"])
+    diff = pts - gv["points1"]
+    rms = float(np.sqrt((diff.astype(np.float64) ** 2).sum(1).mean()))
+    assert rms <= (1e-4 if views == 2 else 2.5e-3), rms
