@@ -6,3 +6,4 @@
 #include "SIFT_FeatureFactory.hpp"
 #include "MatchFactory.hpp"
 #include "PointCloudFactory.hpp"
+#include "io_util.hpp"

@@ -79,6 +79,17 @@ static int cpu_mode(const std::string& dir) {
   CHECK(pts.size() == 3 && pts.host.get()[2].z == 9.0f);
   Image img(dir + "/0_" + typeid(Image).name() + ".cpimg", 0);
   CHECK(img.id == 0 && img.size.x == 1024 && img.colorDepth == 1 && img.camera.foc > 0.85f && img.camera.foc < 0.87f);
+  // ASCII PLY writer (src/io_util.cpp:740-754)
+  {
+    ptr::value<Unity<float3>> cloud(nullptr, 2, cpu);
+    cloud->host.get()[0] = {1.5f, -2.0f, 3.25f};
+    cloud->host.get()[1] = {0.0f, 1e-3f, 400.125f};
+    writePLY("cloud", cloud, dir + "/");
+    std::ifstream in(dir + "/cloud.ply");
+    std::string all((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    CHECK(all.find("element vertex 2\n") != std::string::npos);
+    CHECK(all.find("end_header\n1.5 -2 3.25\n0 0.001 400.125\n") != std::string::npos);
+  }
   // Feature() default state that Unity(nullptr, n, gpu) relies on
   Feature<SIFT_Descriptor> f;
   CHECK(f.parent == -1 && f.loc.x == -1.0f && f.descriptor.theta == 0.0f);
