@@ -106,6 +106,57 @@ def cpu_baseline(size):
                       "cores); the reference itself has no CPU compute path" % (size, size, len(f), dt)}
 
 
+def bench_nview(args, torch, dist, capi, world, rank, dev):
+    """config[3]: V views, image/pair sharding over the ranks with the two RCCL exchanges (ssrlcv_amd/pipeline.py)."""
+    import helpers as H
+    from ssrlcv_amd import pipeline, dist as sd
+    V, S = args.views, args.size
+    base = synth_images(1, S + 64, S + 64, seed=99, device=dev)[0]
+    # every view sees the same scene shifted by a few pixels, so descriptors do match across views
+    imgs = [base[8 * v: 8 * v + S, 5 * v: 5 * v + S].contiguous() for v in range(V)]
+    cams = np.zeros(V, H.CAMERA)
+    cams["foc"], cams["fov"], cams["size"] = 0.859311, 0.0418879, S
+    cams["dpix"] = 0.859311 * np.tan(0.0418879 / 2) / (S / 2)
+    cams["cam_rot"] = [2.0567966, 0.02217786, -0.04195467]
+    for v in range(V):
+        cams["cam_pos"][v] = [-35.0 * v, 1.3 * v, 0.7 * v]
+    plans = {v: capi.SiftPlan(S, S) for v in range(V) if sd.image_owner(v, world) == rank}
+
+    def step():
+        return pipeline.reconstruct(imgs, cams, mode=0, plans=plans)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "Mpix/s N-view reconstruction (SIFT + exhaustive match + merge + N-view triangulate)",
+            "value": V * S * S * args.steps / dt / 1e6, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%d-view %dx%d, image/pair shard over %d GPU(s), all-gather of features and "
+                                   "uint2_pair arrays, replicated merge" % (V, S, S, world),
+                       "multi_matches": int(len(res["matches"])), "points": int(res["points"].shape[0]),
+                       "features_per_image": [int(f.numel() // 152) for f in res["features"]]}}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,6 +169,11 @@ def main():
     ap.add_argument("--cpu-size", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matcher", action="store_true")
+    ap.add_argument("--workload", choices=["pair", "nview"], default="pair",
+                    help="pair: SIFT on this rank's image pair (default, weak scaling).  nview: BASELINE config[3] -- "
+                         "--views images sharded over the ranks, RCCL all-gather of features and of the per-pair "
+                         "uint2_pair arrays, replicated merge, bundle-range N-view triangulation (strong scaling)")
+    ap.add_argument("--views", type=int, default=4)
     args = ap.parse_args()
 
     import torch
@@ -136,6 +192,8 @@ def main():
 
     W = H_ = args.size
     dev = torch.device("cuda", torch.cuda.current_device())
+    if args.workload == "nview":
+        return bench_nview(args, torch, dist, capi, world, rank, dev)
     imgs = synth_images(args.images, W, H_, seed=rank, device=dev)
     plans = [capi.SiftPlan(W, H_) for _ in range(args.images)]
 

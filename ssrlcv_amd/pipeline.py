@@ -42,7 +42,7 @@ def exchange_features(local, num_images):
     return sd.exchange_keyed(local, num_images, sd.image_owner)
 
 
-def match_pairs(features, cameras, seed_features=None, epsilon=25.0, delta=5.0, rel=0.6, absolute=200.0 * 200.0):
+def match_pairs(features, cameras, seed_features=None, epsilon=25.0, delta=5.0, rel=0.6, absolute=200.0 * 200.0, mode=1):
     """Exhaustive double-constrained matching (generateMatchesExhaustive, GEO_ORBIT path) of the pairs this rank owns.
     features: list of uint8 CUDA tensors (all images).  Returns {pair index: validated uint2_pair bytes}."""
     world, rank = _world()
@@ -60,7 +60,7 @@ def match_pairs(features, cameras, seed_features=None, epsilon=25.0, delta=5.0, 
             if qi not in seed_cache:  # recomputed per query image upstream (src/MatchFactory.cu:925)
                 seed_cache[qi] = capi.seed_distances(features[qi], nq, seed_d, len(seed_features))
             sdist = seed_cache[qi]
-        params = capi.make_match_params(1, qi, ti, epsilon, delta, rel, absolute, cameras[qi:qi + 1],
+        params = capi.make_match_params(mode, qi, ti, epsilon, delta, rel, absolute, cameras[qi:qi + 1],
                                         capi.projection_matrix(cameras[ti:ti + 1]))
         ws = capi.match_workspace(nq, nt)
         res = capi.match(features[qi], nq, features[ti], nt, params, capi.OUT_UINT2_PAIR, seed_d=sdist, workspace=ws)
@@ -107,13 +107,13 @@ def triangulate(mm, kp, cameras, nview):
     return torch.cat([p.view(torch.float32) for p in parts]).view(-1, 3)
 
 
-def reconstruct(pixel_tensors_all, cameras, seed_features=None, epsilon=25.0, delta=5.0):
+def reconstruct(pixel_tensors_all, cameras, seed_features=None, epsilon=25.0, delta=5.0, mode=1, plans=None):
     """Full flow.  pixel_tensors_all: list of u8 CUDA tensors (only the owner rank's entries are used)."""
     world, rank = _world()
     num_images = len(pixel_tensors_all)
     mine = {v: pixel_tensors_all[v] for v in range(num_images) if sd.image_owner(v, world) == rank}
-    feats = exchange_features(extract_features(mine), num_images)
-    pair_local = match_pairs(feats, cameras, seed_features, epsilon, delta)
+    feats = exchange_features(extract_features(mine, plans), num_images)
+    pair_local = match_pairs(feats, cameras, seed_features, epsilon, delta, mode=mode)
     pair_all = exchange_pairs(pair_local, len(sd.pair_list(num_images)))
     mm, kp = build_match_set(feats, pair_all)
     cloud = triangulate(mm, kp, cameras, nview=num_images > 2)
