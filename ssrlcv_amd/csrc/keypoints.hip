@@ -446,58 +446,69 @@ __global__ __launch_bounds__(256) void k_thetas(const OctaveState* st, const ssr
 }
 
 // ---- S14: fillDescriptors(SSKeyPoint) (src/SIFT_FeatureFactory.cu:475-549) ------------------------------------------------
-// One WAVE per key point (the reference: a 4x4x8 block of which 16 threads sweep the window).  Lanes run along x of the
-// rotated (2w+1)^2 window, one or two rows per step; each sample votes into the wave's 4x4x8 LDS histogram with
-// ds_add_f32 (the reference also uses shared-memory float atomics, :521).  The 16 rotated cell centres and the two
-// possible orientation bins are computed once per key point / once per sample instead of inside the 16 x 8 inner loops.
+// One WAVE per key point (the reference: a 4x4x8 block of which 16 threads sweep the window).  The samples of the
+// rotated (2w+1)^2 window are packed densely over the lanes, 64 per batch; each sample votes into the wave's 4x4x8 LDS
+// histogram (the reference also uses shared-memory atomics, :521).  This kernel is VALU-issue bound (about 1.6 M key
+// points x 10-40 batches per 4096^2 image), so the loop is written for instruction count:
+//   - everything that depends on the key point only (rotated cell centres, window constants) is wave-uniform and
+//     moved to SGPRs with v_readfirstlane, so the 16 cell tests are {v_sub, v_cmp} pairs on SGPR operands;
+//   - the 16 cells are visited in a uniform, fully unrolled loop: a cell's vote code runs once under the lane mask of
+//     its passing samples (typically 8-10 of the 16 cells have any) instead of a per-lane loop over set bits, the
+//     coordinate differences of the test are reused for the weights and the LDS address is lane base + immediate;
+//   - votes are 2^-31 fixed point (see to_fixed31): one v_cvt_u32_f32 instead of an emulated f32->u64 conversion.
+__device__ __forceinline__ float uniform_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+// Histogram votes in 2^-31 fixed point, accumulated with 64-bit integer LDS atomics: ds_add_f32 runs at about one lane
+// per clock on gfx950 (measured: 27 of 55 ms of the first version of this kernel), ds_add_u64 does not.  A vote is
+// wxy * wk * |grad| * gauss with wxy, wk, gauss <= 1 and |grad| <= sqrt(2) (components of a [0,1]-normalised level), so
+// vote * 2^31 < 2^32; a bin receives < 2^12 votes, so the 64-bit sum cannot overflow.  The integer sum is exact and
+// order independent, i.e. deterministic (the reference's shared float atomicAdd is not); the truncation error is
+// < 2^-31 per vote, far below the float rounding of the reference's own running sum.
+__device__ __forceinline__ unsigned long long to_fixed31(float v) { return (unsigned long long)(unsigned)(v * 2147483648.0f); }
+__device__ __forceinline__ float from_fixed31(unsigned long long t) { return (float)t * 4.656612873077393e-10f; }
+
 __global__ __launch_bounds__(256) void k_descriptors(const OctaveState* st, const ssrlcv_sskeypoint* kps, LevelSet L,
                                                      float pixelWidth, float lambda, const uint32_t* featBase, int octave,
                                                      ssrlcv_sift_feature* __restrict__ features, uint32_t maxFeatures) {
-  // The 4x4x8 histogram is accumulated in 2^-40 fixed point with 64-bit integer LDS atomics: ds_add_f32 runs at about
-  // one lane per clock on gfx950 (measured: 27 of 55 ms of this kernel), ds_add_u64 does not.  Every vote is >= 0 and
-  // < 4, a bin sums < 2^12 votes, so 2^40 * vote never overflows; the integer sum is exact and order-independent, i.e.
-  // deterministic (the reference's shared float atomicAdd is not).  8 lane-private copies (copy = lane & 7) keep
-  // same-address conflicts low.  8 KiB per wave.
+  // 8 lane-private copies of the 128 bins (copy = lane & 7, bin-major / copy-minor) keep same-address conflicts low;
+  // 8 KiB per wave
   __shared__ unsigned long long s_bins[4][128 * 8];
   __shared__ __attribute__((aligned(8))) uint8_t s_bytes[4][128];
-  __shared__ float s_cells[4][32];
   const int n = st->hasExtrema ? st->n : 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned long long* bins = s_bins[wave];
-  float* cells = s_cells[wave];
   const int copy = lane & 7;
   const float pi = SSRLCV_PI_F;
   const float rad45 = pi / 4.0f;
+  const float inv45 = 1.0f / rad45;
+  const float2* __restrict__ polar = L.polar;  // key points live on levels 1..3, whose polar tables are always built
   for (int gi = blockIdx.x * 4 + wave; gi < n; gi += gridDim.x * 4) {
-    const int seg = segment_of(st, gi);
-    const float* px = L.dog[seg];
-    const float lmn = L.minmax[2 * seg], lmx = L.minmax[2 * seg + 1];
+    const int seg = __builtin_amdgcn_readfirstlane(segment_of(st, gi));
     const ssrlcv_sskeypoint kp = kps[gi];
-    const float kx = kp.loc.x, ky = kp.loc.y;
-    const float windowWidth = ceilf(kp.sigma * lambda / pixelWidth);
-    const float theta = kp.theta;
-    const float binWidth = windowWidth / 2.0f;
-    const float c = cosf(-theta), s = sinf(-theta);
+    const float kx = uniform_f(kp.loc.x), ky = uniform_f(kp.loc.y);
+    const float theta = uniform_f(kp.theta);
+    const float windowWidth = uniform_f(ceilf(kp.sigma * lambda / pixelWidth));
+    const float binWidth = uniform_f(windowWidth / 2.0f);
+    const float c = uniform_f(cosf(-theta)), s = uniform_f(sinf(-theta));
+    const float2* __restrict__ pl = polar + (size_t)(seg - 1) * L.h * L.w;
 #pragma unroll
     for (int i = 0; i < 16; ++i) bins[i * 64 + lane] = 0ull;
-    // rotated cell centres (:511-512), identical expressions to the reference's per-sample recomputation; kept in
-    // LDS so the per-lane loop over passing cells can index them
-    if (lane < 16) {
-      const int nxi = lane >> 2, nyi = lane & 3;
-      float hx = ((float)nxi * 0.5f - 0.75f) * windowWidth, hy = ((float)nyi * 0.5f - 0.75f) * windowWidth;
-      cells[lane] = (hx * c) + (hy * s);
-      cells[16 + lane] = (-hx * s) + (hy * c);
-    }
-    __builtin_amdgcn_wave_barrier();
+    // rotated cell centres (:511-512), identical expressions to the reference's per-sample recomputation
     float rcx[16], rcy[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { rcx[i] = cells[i]; rcy[i] = cells[16 + i]; }
-    const float invBin = 1.0f / binWidth;   // hx / binWidth is evaluated as hx * (1/binWidth): <= 1 ulp from the division
-    const float inv45 = 1.0f / rad45;
+    for (int cell = 0; cell < 16; ++cell) {
+      const float hx = ((float)(cell >> 2) * 0.5f - 0.75f) * windowWidth, hy = ((float)(cell & 3) * 0.5f - 0.75f) * windowWidth;
+      rcx[cell] = uniform_f((hx * c) + (hy * s));
+      rcy[cell] = uniform_f((-hx * s) + (hy * c));
+    }
+    const float invBin = uniform_f(1.0f / binWidth);  // hx / binWidth is evaluated as hx * (1/binWidth): <= 1 ulp off
+    // exp(-(r^2) / (2 w^2)) is evaluated as exp2(r^2 * k2) with k2 = -log2(e) / (2 w^2): <= 3 ulp from expf of the quotient
+    const float k2 = uniform_f(-1.4426950408889634f / (2.0f * windowWidth * windowWidth));
     const int S = 2 * (int)windowWidth + 1;
-    // Samples are packed densely over the lanes (sample index -> (row, col) with a multiply-high by a per-key-point
-    // magic constant), so every lane works until the tail of the (2w+1)^2 window; votes are exact integers, so the
-    // visiting order does not matter.  The polar gather of the next batch is issued before the current one is used.
+    // sample index -> (row, col) with a multiply-high by a per-key-point magic constant; votes are exact integers,
+    // so the visiting order does not matter.  The polar gather of the next batch is issued before the current one
+    // is used.
     const unsigned total = (unsigned)(S * S);
     const unsigned magic = (unsigned)((0x100000000ull + (unsigned long long)S - 1ull) / (unsigned long long)S);
     auto sample = [&](unsigned sidx, float& cx, float& cy, bool& ok) {
@@ -509,54 +520,52 @@ __global__ __launch_bounds__(256) void k_descriptors(const OctaveState* st, cons
       cy = (-x * s) + (y * c);
       ok = sidx < total && !(fabsf(cx) > windowWidth || fabsf(cy) > windowWidth);
     };
+    auto gather = [&](float cx, float cy) {
+      // llroundf of the reference; in-range by checkKeyPoints (window + 1 pixel inside the level)
+      return pl[(size_t)(int)roundf(cy + ky) * L.w + (int)roundf(cx + kx)];
+    };
     float ncx, ncy;
     bool nok;
     sample((unsigned)lane, ncx, ncy, nok);
     float2 npg = make_float2(0.0f, 0.0f);
-    if (nok) npg = polar_at(L, seg, px, lmn, lmx, (int)roundf(ncx + kx), (int)roundf(ncy + ky));  // roundf == llroundf
+    if (nok) npg = gather(ncx, ncy);
     for (unsigned base = 0; base < total; base += 64) {
       const float cx = ncx, cy = ncy;
       const bool ok = nok;
       const float2 pg = npg;
       sample(base + 64 + (unsigned)lane, ncx, ncy, nok);
-      if (nok) npg = polar_at(L, seg, px, lmn, lmx, (int)roundf(ncx + kx), (int)roundf(ncy + ky));
-      if (ok) {
-        float mag = pg.x * expf(-((cx * cx) + (cy * cy)) / (2.0f * windowWidth * windowWidth));
-        float ang = fmod_2pi(pg.y - theta + (2.0f * pi), 2.0f * pi);
-        // orientation bins: every k with |ang - k*rad45| < rad45 (at most two).  Only k0-1..k0+1 around
-        // k0 = floor(ang/rad45) can pass (any other k is >= 1.99 rad45 away); the test itself is the reference's
-        int ka = -1, kb = -1;
-        float wa = 0.0f, wb = 0.0f;
-        const int k0 = (int)(ang * inv45);
+      if (nok) npg = gather(ncx, ncy);
+      const float mag = pg.x * __builtin_amdgcn_exp2f(((cx * cx) + (cy * cy)) * k2);
+      const float ang = fmod_2pi(pg.y - theta + (2.0f * pi), 2.0f * pi);
+      // orientation bins: every k with |ang - k*rad45| < rad45 (at most two).  Only k0-1..k0+1 around
+      // k0 = floor(ang/rad45) can pass (any other k is >= 1.99 rad45 away); the test itself is the reference's
+      int ka = -1, kb = -1;
+      float wa = 0.0f, wb = 0.0f;
+      const int k0 = (int)(ang * inv45);
 #pragma unroll
-        for (int dk = -1; dk <= 1; ++dk) {
-          int k = k0 + dk;
-          float angle = fabsf(ang - ((float)k * rad45));
-          if (k >= 0 && k < 8 && angle < rad45) {
-            if (ka < 0) { ka = k; wa = angle; }
-            else if (kb < 0) { kb = k; wb = angle; }
-          }
-        }
-        wa = 1.0f - (wa * inv45);
-        wb = 1.0f - (wb * inv45);
-        // cells whose rotated centre lies within binWidth of the sample on both axes (:513-514): branch-free mask,
-        // then a per-lane loop over the (typically 4) set bits
-        unsigned pass = 0;
+      for (int dk = -1; dk <= 1; ++dk) {
+        const int k = k0 + dk;
+        const float angle = fabsf(ang - ((float)k * rad45));
+        const bool hit = k >= 0 && k < 8 && angle < rad45;
+        const bool first = hit && ka < 0, second = hit && !first && kb < 0;
+        ka = first ? k : ka;
+        wa = first ? angle : wa;
+        kb = second ? k : kb;
+        wb = second ? angle : wb;
+      }
+      // a missing bin votes 0 into bin 0 (no branch); reference association (wxy * wk) * mag
+      const float ma = ka >= 0 ? 1.0f - (wa * inv45) : 0.0f;
+      const float mb = kb >= 0 ? 1.0f - (wb * inv45) : 0.0f;
+      unsigned long long* pa = bins + (ka < 0 ? 0 : ka) * 8 + copy;
+      unsigned long long* pb = bins + (kb < 0 ? 0 : kb) * 8 + copy;
+      // cells whose rotated centre lies within binWidth of the sample on both axes (:513-514)
 #pragma unroll
-        for (int cell = 0; cell < 16; ++cell) {
-          bool in = (fabsf(rcx[cell] - cx) <= binWidth) && (fabsf(rcy[cell] - cy) <= binWidth);
-          pass |= in ? (1u << cell) : 0u;
-        }
-        while (pass) {
-          const int cell = __ffs((int)pass) - 1;
-          pass &= pass - 1;
-          // rotated centre of this cell, recomputed with the same expressions as above (no LDS read in this loop)
-          const float ux = ((float)(cell >> 2) * 0.5f - 0.75f) * windowWidth, uy = ((float)(cell & 3) * 0.5f - 0.75f) * windowWidth;
-          const float qx = (ux * c) + (uy * s), qy = (-ux * s) + (uy * c);
-          float hx = fabsf(qx - cx) * invBin, hy = fabsf(qy - cy) * invBin;
-          float wxy = (1.0f - hx) * (1.0f - hy);
-          if (ka >= 0) atomicAdd(&bins[(cell * 8 + ka) * 8 + copy], to_fixed(wxy * wa * mag));  // reference association
-          if (kb >= 0) atomicAdd(&bins[(cell * 8 + kb) * 8 + copy], to_fixed(wxy * wb * mag));
+      for (int cell = 0; cell < 16; ++cell) {
+        const float tx = fabsf(rcx[cell] - cx), ty = fabsf(rcy[cell] - cy);
+        if (ok && tx <= binWidth && ty <= binWidth) {
+          const float wxy = (1.0f - (tx * invBin)) * (1.0f - (ty * invBin));
+          atomicAdd(pa + cell * 64, to_fixed31(wxy * ma * mag));
+          atomicAdd(pb + cell * 64, to_fixed31(wxy * mb * mag));
         }
       }
     }
@@ -568,7 +577,7 @@ __global__ __launch_bounds__(256) void k_descriptors(const OctaveState* st, cons
       t0 += bins[lane * 8 + cpy];
       t1 += bins[(lane + 64) * 8 + cpy];
     }
-    float v0 = from_fixed(t0), v1 = from_fixed(t1);
+    float v0 = from_fixed31(t0), v1 = from_fixed31(t1);
     float sq = sqrtf(sv::wave_sum((v0 * v0) + (v1 * v1)));
     v0 = v0 / sq;
     v1 = v1 / sq;

@@ -15,6 +15,7 @@
 #include <float.h>
 #include <math.h>
 #include <new>
+#include <stdlib.h>
 #include <string.h>
 #include "device_math.h"
 #include "sift_plan.h"
@@ -253,6 +254,171 @@ __global__ __launch_bounds__(kTX) void k_gauss_fused(ConvArgs a) {
   if (a.minmax) block_minmax_commit(mn, mx, a.minmax, s_h);
 }
 
+// ---- S4 on the matrix cores ----------------------------------------------------------------------------------------------
+// The two 1-D passes as banded-Toeplitz products on v_mfma_f32_16x16x4_f32.  An f32 MFMA is bit-for-bit a k-ordered
+// fmaf chain (one rounding per product-add), so D[i][j] = sum_kk A[i][kk] * T[kk][j] with T[kk][j] = w[kk - j]
+// (0 outside the band: fmaf(x, 0, acc) == acc) is exactly the reference's `sum += p * k` loop in its tap order.  Plain
+// v_fma_f32 peaks at 75 TFLOP/s on MI355X (tools/valu_rate.hip); the f32 MFMA pipe delivers 2x that per SIMD, and
+// the band fills 65/80 of a 16-wide tile at R = 32.
+//   horizontal: D[16 rows][16 cols] = In[16 rows][16+2R cols] x T      A from the LDS row stage, B = per-lane constants
+//   vertical  : D[16 rows][16 cols] = T^T[16 rows][16+2R] x H[16+2R rows][16 cols]   A = constants, B from the LDS ring
+// A block owns a 256-column strip and marches down 16 rows per step; each wave owns 4 of the 16 column tiles.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMT = 16;  // rows per marching step of the MFMA kernel
+
+template <int R>
+struct MfmaCfg {
+  static constexpr int K = 16 + 2 * R;            // Toeplitz depth
+  static constexpr int KS = (K + 3) / 4;          // MFMA k-steps
+  static constexpr int KP = KS * 4;
+  static constexpr int RP = (R + 3) / 4 * 4;
+  // staged row width: 256 + halo + padding for the KP - K overshoot, == 2 (mod 32) so that the A reads
+  // (16 rows x 2 columns per 32-lane half) are bank-conflict free
+  static constexpr int SWmin = kTX + 2 * RP + (KP - K) + 4;
+  static constexpr int SW = (SWmin + 29) / 32 * 32 + 2;
+  static constexpr int RINGROWS = (2 * R + kMT + kMT - 1) / kMT * kMT;
+  static constexpr int RSTR = kTX + 16;           // ring row stride (== 16 mod 32: B reads conflict free)
+  static constexpr int TOT = kMT * SW;
+  static constexpr int STG = (TOT + kTX - 1) / kTX;
+  static constexpr size_t ldsBytes = sizeof(float) * ((size_t)kMT * SW + (size_t)RINGROWS * RSTR);
+};
+
+template <int R>
+__global__ __launch_bounds__(kTX) void k_gauss_mfma(ConvArgs a) {
+  using C = MfmaCfg<R>;
+  extern __shared__ __attribute__((aligned(16))) float s_mem[];
+  float* s_in = s_mem;                         // [kMT][SW]
+  float* s_ring = s_mem + kMT * C::SW;         // [RINGROWS][RSTR]
+  const int W = (int)a.w, H = (int)a.h;
+  const int x0 = blockIdx.x * kTX;
+  const int y0 = blockIdx.y * (int)a.rowsPerBlock;
+  int nrows = (int)a.rowsPerBlock;
+  if (y0 + nrows > H) nrows = H - y0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+
+  // per-lane Toeplitz constants: tz[s] = w[4s + lk - li] (0 outside 0..2R); w is symmetric, R+1 taps in the kernarg
+  float tz[C::KS];
+#pragma unroll
+  for (int s = 0; s < C::KS; ++s) {
+    int t = 4 * s + lk - li;
+    int ti = t <= R ? t : 2 * R - t;
+    tz[s] = (t >= 0 && t <= 2 * R) ? a.wgt[ti < 0 ? 0 : ti] : 0.0f;
+  }
+  // zero the ring and the stage once: band zeros multiply whatever sits there, it must be finite
+  for (int i = tid; i < C::RINGROWS * C::RSTR; i += kTX) s_ring[i] = 0.0f;
+  for (int i = tid; i < kMT * C::SW; i += kTX) s_in[i] = 0.0f;
+
+  int gxs[C::STG], rws[C::STG], cls[C::STG];
+#pragma unroll
+  for (int e = 0; e < C::STG; ++e) {
+    int idx = e * kTX + tid;
+    int r = idx / C::SW, c = idx - r * C::SW;
+    int x = x0 - C::RP + c;
+    x = x > W - 1 + R ? W - 1 + R : x;
+    x = x < 0 ? -1 - x : x;
+    x = x > W - 1 ? 2 * W - 1 - x : x;
+    gxs[e] = x;
+    rws[e] = r;
+    cls[e] = c;
+  }
+  float pre[C::STG];
+  auto fetch = [&](int s) {
+    const int ybase = y0 - R + s * kMT;
+#pragma unroll
+    for (int e = 0; e < C::STG; ++e) {
+      int y = ybase + rws[e];
+      y = y > H - 1 + R ? H - 1 + R : y;
+      y = y < 0 ? -1 - y : y;
+      y = y > H - 1 ? 2 * H - 1 - y : y;
+      bool in = ((e + 1) * kTX <= C::TOT || e * kTX + tid < C::TOT) && cls[e] < kTX + 2 * C::RP;
+      pre[e] = in ? a.in[(size_t)y * W + gxs[e]] : 0.0f;
+    }
+  };
+  float mn = FLT_MAX, mx = -FLT_MAX;
+  const int steps = (nrows + 2 * R + kMT - 1) / kMT;
+  fetch(0);
+  __syncthreads();
+  for (int s = 0; s < steps; ++s) {
+#pragma unroll
+    for (int e = 0; e < C::STG; ++e)
+      if ((e + 1) * kTX <= C::TOT || e * kTX + tid < C::TOT) s_in[e * kTX + tid] = pre[e];
+    __syncthreads();
+    if (s + 1 < steps) fetch(s + 1);
+    // ---- horizontal pass: H rows 16s .. 16s+15 of this strip into the ring
+    const int slot0 = (s * kMT) % C::RINGROWS;
+    {
+      // the wave's four column tiles run as four independent accumulation chains (a dependent f32 MFMA chain issues
+      // every 40 cycles, independent ones every 32) and their LDS reads are batched ahead of the MFMAs
+      const float* arow = s_in + li * C::SW + (wave * 4) * 16 + (C::RP - R) + lk;
+      f32x4 acc[4];
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) acc[t4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        float av[4];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) av[t4] = arow[t4 * 16 + 4 * ks];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) acc[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4], tz[ks], acc[t4], 0, 0, 0);
+      }
+      // D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) {
+        float* dst = s_ring + (size_t)(slot0 + lk * 4) * C::RSTR + (wave * 4 + t4) * 16 + li;
+        dst[0] = acc[t4][0];
+        dst[C::RSTR] = acc[t4][1];
+        dst[2 * C::RSTR] = acc[t4][2];
+        dst[3 * C::RSTR] = acc[t4][3];
+      }
+    }
+    __syncthreads();
+    // ---- vertical pass: output rows j = 16s - 2R + ii, ii = 0..15; B row kk is H row 16s - 2R + kk
+    const int jbase = s * kMT - 2 * R;
+    if (jbase + kMT > 0 && jbase < nrows) {
+      int hslot[C::KS];
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        int kk = 4 * ks + lk;
+        kk = kk > C::K - 1 ? C::K - 1 : kk;               // padded k-steps re-read a valid row (their weight is 0)
+        int hidx = jbase + kk;                            // H row index (>= -2R)
+        hslot[ks] = ((hidx % C::RINGROWS) + C::RINGROWS) % C::RINGROWS;
+      }
+      f32x4 acc[4];
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) acc[t4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        const float* brow = s_ring + (size_t)hslot[ks] * C::RSTR + (wave * 4) * 16 + li;
+        float bv[4];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) bv[t4] = brow[t4 * 16];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) acc[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(tz[ks], bv[t4], acc[t4], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) {
+        const int gx = x0 + (wave * 4 + t4) * 16 + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int j = jbase + lk * 4 + r;
+          if (j >= 0 && j < nrows && gx < W) {
+            float v = acc[t4][r];
+            a.out[(size_t)(y0 + j) * W + gx] = v;
+            mn = fminf(mn, v);
+            mx = fmaxf(mx, v);
+          }
+        }
+      }
+    }
+    // no barrier needed here: the next iteration's stage write is followed by one, and the ring is only rewritten
+    // after it
+  }
+  __syncthreads();
+  if (a.minmax) block_minmax_commit(mn, mx, a.minmax, s_mem);
+}
+
 // Generic two-pass fallback for tap counts the pipeline never produces (taps > 65): one 1-D pass per launch.
 __global__ __launch_bounds__(256) void k_conv1d(const float* __restrict__ in, float* __restrict__ out, uint32_t w,
                                                 uint32_t h, int taps, const float* __restrict__ wgt, int vertical,
@@ -367,13 +533,41 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
   rows = (rows + kNR - 1) / kNR * kNR;
   a.rowsPerBlock = rows;
   dim3 grid(bx, (h + rows - 1) / rows);
-  switch (RT) {
-    case 6: hipLaunchKernelGGL(k_gauss_fused<6>, grid, dim3(kTX), 0, st, a); break;
-    case 8: hipLaunchKernelGGL(k_gauss_fused<8>, grid, dim3(kTX), 0, st, a); break;
-    case 11: hipLaunchKernelGGL(k_gauss_fused<11>, grid, dim3(kTX), 0, st, a); break;
-    case 16: hipLaunchKernelGGL(k_gauss_fused<16>, grid, dim3(kTX), 0, st, a); break;
-    case 23: hipLaunchKernelGGL(k_gauss_fused<23>, grid, dim3(kTX), 0, st, a); break;
-    default: hipLaunchKernelGGL(k_gauss_fused<32>, grid, dim3(kTX), 0, st, a); break;
+  // The f32-MFMA banded-Toeplitz variant is bit-identical but measured no faster than the VALU marching kernel on
+  // MI355X (8192^2: 0.19-0.43 ms vs 0.15-0.38 ms per level), so it stays an opt-in (SSRLCV_GAUSS_MFMA=1).
+  static const bool useMfma = getenv("SSRLCV_GAUSS_MFMA") != nullptr;
+  if (!useMfma) {
+    switch (RT) {
+      case 6: hipLaunchKernelGGL(k_gauss_fused<6>, grid, dim3(kTX), 0, st, a); break;
+      case 8: hipLaunchKernelGGL(k_gauss_fused<8>, grid, dim3(kTX), 0, st, a); break;
+      case 11: hipLaunchKernelGGL(k_gauss_fused<11>, grid, dim3(kTX), 0, st, a); break;
+      case 16: hipLaunchKernelGGL(k_gauss_fused<16>, grid, dim3(kTX), 0, st, a); break;
+      case 23: hipLaunchKernelGGL(k_gauss_fused<23>, grid, dim3(kTX), 0, st, a); break;
+      default: hipLaunchKernelGGL(k_gauss_fused<32>, grid, dim3(kTX), 0, st, a); break;
+    }
+  } else {
+    rows = (rows + kMT - 1) / kMT * kMT;
+    a.rowsPerBlock = rows;
+    grid = dim3(bx, (h + rows - 1) / rows);
+#define SSRLCV_LAUNCH_MFMA(RR)                                                                                   \
+  do {                                                                                                            \
+    static bool attr = false;                                                                                     \
+    if (!attr) {                                                                                                  \
+      SSRLCV_HIP_TRY(hipFuncSetAttribute((const void*)k_gauss_mfma<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         (int)MfmaCfg<RR>::ldsBytes));                                            \
+      attr = true;                                                                                                \
+    }                                                                                                             \
+    hipLaunchKernelGGL(k_gauss_mfma<RR>, grid, dim3(kTX), MfmaCfg<RR>::ldsBytes, st, a);                          \
+  } while (0)
+    switch (RT) {
+      case 6: SSRLCV_LAUNCH_MFMA(6); break;
+      case 8: SSRLCV_LAUNCH_MFMA(8); break;
+      case 11: SSRLCV_LAUNCH_MFMA(11); break;
+      case 16: SSRLCV_LAUNCH_MFMA(16); break;
+      case 23: SSRLCV_LAUNCH_MFMA(23); break;
+      default: SSRLCV_LAUNCH_MFMA(32); break;
+    }
+#undef SSRLCV_LAUNCH_MFMA
   }
   SSRLCV_LAUNCH_CHECK();
   return SSRLCV_OK;
