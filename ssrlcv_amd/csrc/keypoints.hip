@@ -455,7 +455,8 @@ __global__ __launch_bounds__(256) void k_thetas(const OctaveState* st, const ssr
 //   - the 16 cells are visited in a uniform, fully unrolled loop: a cell's vote code runs once under the lane mask of
 //     its passing samples (typically 8-10 of the 16 cells have any) instead of a per-lane loop over set bits, the
 //     coordinate differences of the test are reused for the weights and the LDS address is lane base + immediate;
-//   - votes are 2^-31 fixed point (see to_fixed31): one v_cvt_u32_f32 instead of an emulated f32->u64 conversion.
+//   - votes are 2^-31 fixed point: one v_cvt_u32_f32 instead of an emulated f32->u64 conversion;
+//   - the x / y halves of the cell arithmetic and the two orientation votes use packed fp32 instructions.
 __device__ __forceinline__ float uniform_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
@@ -465,20 +466,24 @@ __device__ __forceinline__ float uniform_f(float v) {
 // vote * 2^31 < 2^32; a bin receives < 2^12 votes, so the 64-bit sum cannot overflow.  The integer sum is exact and
 // order independent, i.e. deterministic (the reference's shared float atomicAdd is not); the truncation error is
 // < 2^-31 per vote, far below the float rounding of the reference's own running sum.
-__device__ __forceinline__ unsigned long long to_fixed31(float v) { return (unsigned long long)(unsigned)(v * 2147483648.0f); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// roundf / llroundf of a non-negative coordinate: floor + (fraction >= 0.5), 4 instructions instead of 8
+__device__ __forceinline__ int round_pos(float v) { return (int)v + (__builtin_amdgcn_fractf(v) >= 0.5f ? 1 : 0); }
 __device__ __forceinline__ float from_fixed31(unsigned long long t) { return (float)t * 4.656612873077393e-10f; }
 
-__global__ __launch_bounds__(256) void k_descriptors(const OctaveState* st, const ssrlcv_sskeypoint* kps, LevelSet L,
+// 4 lane-private copies of the 128 bins (4 KiB per wave) and <= 64 VGPRs: 8 waves per SIMD.  Measured on MI355X
+// (1.6 M key points of a 4096^2 image): 8 copies / 4 waves 10.4 ms, 4 copies / 8 waves 9.7 ms, 2 copies / 8 waves 10.1 ms.
+constexpr int kDescCopies = 4;
+__global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, const ssrlcv_sskeypoint* kps, LevelSet L,
                                                      float pixelWidth, float lambda, const uint32_t* featBase, int octave,
                                                      ssrlcv_sift_feature* __restrict__ features, uint32_t maxFeatures) {
-  // 8 lane-private copies of the 128 bins (copy = lane & 7, bin-major / copy-minor) keep same-address conflicts low;
-  // 8 KiB per wave
-  __shared__ unsigned long long s_bins[4][128 * 8];
+  // lane-private copies of the 128 bins (copy = lane & 3, bin-major / copy-minor) keep same-address conflicts low
+  __shared__ unsigned long long s_bins[4][128 * kDescCopies];
   __shared__ __attribute__((aligned(8))) uint8_t s_bytes[4][128];
   const int n = st->hasExtrema ? st->n : 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned long long* bins = s_bins[wave];
-  const int copy = lane & 7;
+  const int copy = lane & (kDescCopies - 1);
   const float pi = SSRLCV_PI_F;
   const float rad45 = pi / 4.0f;
   const float inv45 = 1.0f / rad45;
@@ -490,17 +495,24 @@ __global__ __launch_bounds__(256) void k_descriptors(const OctaveState* st, cons
     const float theta = uniform_f(kp.theta);
     const float windowWidth = uniform_f(ceilf(kp.sigma * lambda / pixelWidth));
     const float binWidth = uniform_f(windowWidth / 2.0f);
-    const float c = uniform_f(cosf(-theta)), s = uniform_f(sinf(-theta));
+    float sv_, cv_;
+    sincosf(-theta, &sv_, &cv_);
+    const float c = uniform_f(cv_), s = uniform_f(sv_);
     const float2* __restrict__ pl = polar + (size_t)(seg - 1) * L.h * L.w;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) bins[i * 64 + lane] = 0ull;
-    // rotated cell centres (:511-512), identical expressions to the reference's per-sample recomputation
-    float rcx[16], rcy[16];
+    for (int i = 0; i < 2 * kDescCopies; ++i) bins[i * 64 + lane] = 0ull;
+    // rotated cell centres (:511-512), identical expressions to the reference's per-sample recomputation: lane i
+    // evaluates cell i & 15, the 16 {x, y} pairs are then broadcast into SGPR pairs
+    f32x2 rc[16];
+    {
+      const int ci = lane & 15;
+      const float hx = ((float)(ci >> 2) * 0.5f - 0.75f) * windowWidth, hy = ((float)(ci & 3) * 0.5f - 0.75f) * windowWidth;
+      const float rx = (hx * c) + (hy * s), ry = (-hx * s) + (hy * c);
 #pragma unroll
-    for (int cell = 0; cell < 16; ++cell) {
-      const float hx = ((float)(cell >> 2) * 0.5f - 0.75f) * windowWidth, hy = ((float)(cell & 3) * 0.5f - 0.75f) * windowWidth;
-      rcx[cell] = uniform_f((hx * c) + (hy * s));
-      rcy[cell] = uniform_f((-hx * s) + (hy * c));
+      for (int cell = 0; cell < 16; ++cell) {
+        rc[cell].x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rx), cell));
+        rc[cell].y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ry), cell));
+      }
     }
     const float invBin = uniform_f(1.0f / binWidth);  // hx / binWidth is evaluated as hx * (1/binWidth): <= 1 ulp off
     // exp(-(r^2) / (2 w^2)) is evaluated as exp2(r^2 * k2) with k2 = -log2(e) / (2 w^2): <= 3 ulp from expf of the quotient
@@ -522,7 +534,7 @@ __global__ __launch_bounds__(256) void k_descriptors(const OctaveState* st, cons
     };
     auto gather = [&](float cx, float cy) {
       // llroundf of the reference; in-range by checkKeyPoints (window + 1 pixel inside the level)
-      return pl[(size_t)(int)roundf(cy + ky) * L.w + (int)roundf(cx + kx)];
+      return pl[(size_t)round_pos(cy + ky) * L.w + round_pos(cx + kx)];
     };
     float ncx, ncy;
     bool nok;
@@ -535,37 +547,40 @@ __global__ __launch_bounds__(256) void k_descriptors(const OctaveState* st, cons
       const float2 pg = npg;
       sample(base + 64 + (unsigned)lane, ncx, ncy, nok);
       if (nok) npg = gather(ncx, ncy);
-      const float mag = pg.x * __builtin_amdgcn_exp2f(((cx * cx) + (cy * cy)) * k2);
+      // gaussian-weighted magnitude, pre-scaled by 2^31 for the fixed-point votes (a power of two: same mantissas)
+      const float mag31 = (pg.x * __builtin_amdgcn_exp2f(((cx * cx) + (cy * cy)) * k2)) * 2147483648.0f;
       const float ang = fmod_2pi(pg.y - theta + (2.0f * pi), 2.0f * pi);
-      // orientation bins: every k with |ang - k*rad45| < rad45 (at most two).  Only k0-1..k0+1 around
-      // k0 = floor(ang/rad45) can pass (any other k is >= 1.99 rad45 away); the test itself is the reference's
-      int ka = -1, kb = -1;
-      float wa = 0.0f, wb = 0.0f;
+      // orientation bins: every k in 0..7 with |ang - k*rad45| < rad45 (:515-518), at most two.  Only k0-1..k0+1
+      // around k0 = trunc(ang/rad45) can pass (any other k is >= 1.99 rad45 away) and k0-1, k0+1 never both do, so
+      // the votes are {k0 if it passes} and {k0+1, else k0-1, if it passes}; the tests are the reference's.  A
+      // missing vote adds 0 to an in-range bin instead of branching.
       const int k0 = (int)(ang * inv45);
-#pragma unroll
-      for (int dk = -1; dk <= 1; ++dk) {
-        const int k = k0 + dk;
-        const float angle = fabsf(ang - ((float)k * rad45));
-        const bool hit = k >= 0 && k < 8 && angle < rad45;
-        const bool first = hit && ka < 0, second = hit && !first && kb < 0;
-        ka = first ? k : ka;
-        wa = first ? angle : wa;
-        kb = second ? k : kb;
-        wb = second ? angle : wb;
-      }
-      // a missing bin votes 0 into bin 0 (no branch); reference association (wxy * wk) * mag
-      const float ma = ka >= 0 ? 1.0f - (wa * inv45) : 0.0f;
-      const float mb = kb >= 0 ? 1.0f - (wb * inv45) : 0.0f;
-      unsigned long long* pa = bins + (ka < 0 ? 0 : ka) * 8 + copy;
-      unsigned long long* pb = bins + (kb < 0 ? 0 : kb) * 8 + copy;
-      // cells whose rotated centre lies within binWidth of the sample on both axes (:513-514)
+      const float f0 = (float)k0;
+      const float a0 = fabsf(ang - (f0 * rad45));
+      const float am = fabsf(ang - ((f0 - 1.0f) * rad45));
+      const float ap = fabsf(ang - ((f0 + 1.0f) * rad45));
+      const bool h0 = (unsigned)k0 < 8u && a0 < rad45;
+      const bool hm = (unsigned)(k0 - 1) < 8u && am < rad45;
+      const bool hp = (unsigned)(k0 + 1) < 8u && ap < rad45;
+      const float aB = hp ? ap : am;
+      f32x2 mab;  // orientation weights of the two votes
+      mab.x = h0 ? 1.0f - (a0 * inv45) : 0.0f;
+      mab.y = (hp || hm) ? 1.0f - (aB * inv45) : 0.0f;
+      unsigned long long* pa = bins + (k0 & 7) * kDescCopies + copy;
+      unsigned long long* pb = bins + ((hp ? k0 + 1 : k0 - 1) & 7) * kDescCopies + copy;
+      // cells whose rotated centre lies within binWidth of the sample on both axes (:513-514); the x and y halves
+      // of the test / weight arithmetic are packed (v_pk_add_f32 / v_pk_mul_f32: same IEEE operations)
+      // `ok` is folded into the lane's threshold and the two axis tests into one compare of max(|tx|, |ty|), so a
+      // cell costs {2 v_sub, v_max, v_cmp} + {s_and_saveexec, s_cbranch_execz, s_or}: on gfx950 a scalar instruction
+      // costs 2-3 cycles of the wave's issue, not much less than a vector one (tools/valu_rate.hip)
+      const float bwl = ok ? binWidth : -1.0f;
 #pragma unroll
       for (int cell = 0; cell < 16; ++cell) {
-        const float tx = fabsf(rcx[cell] - cx), ty = fabsf(rcy[cell] - cy);
-        if (ok && tx <= binWidth && ty <= binWidth) {
+        const float tx = fabsf(rc[cell].x - cx), ty = fabsf(rc[cell].y - cy);
+        if (fmaxf(tx, ty) <= bwl) {
           const float wxy = (1.0f - (tx * invBin)) * (1.0f - (ty * invBin));
-          atomicAdd(pa + cell * 64, to_fixed31(wxy * ma * mag));
-          atomicAdd(pb + cell * 64, to_fixed31(wxy * mb * mag));
+          atomicAdd(pa + cell * 8 * kDescCopies, (unsigned long long)(unsigned)((wxy * mab.x) * mag31));  // (wxy * wk) * mag
+          atomicAdd(pb + cell * 8 * kDescCopies, (unsigned long long)(unsigned)((wxy * mab.y) * mag31));
         }
       }
     }
@@ -573,9 +588,9 @@ __global__ __launch_bounds__(256) void k_descriptors(const OctaveState* st, cons
     // normalise, clamp at 0.2, renormalise, quantise (:529-542); each lane owns bins lane and lane + 64
     unsigned long long t0 = 0ull, t1 = 0ull;
 #pragma unroll
-    for (int cpy = 0; cpy < 8; ++cpy) {
-      t0 += bins[lane * 8 + cpy];
-      t1 += bins[(lane + 64) * 8 + cpy];
+    for (int cpy = 0; cpy < kDescCopies; ++cpy) {
+      t0 += bins[lane * kDescCopies + cpy];
+      t1 += bins[(lane + 64) * kDescCopies + cpy];
     }
     float v0 = from_fixed31(t0), v1 = from_fixed31(t1);
     float sq = sqrtf(sv::wave_sum((v0 * v0) + (v1 * v1)));
