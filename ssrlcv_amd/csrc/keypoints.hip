@@ -305,20 +305,16 @@ __global__ __launch_bounds__(256) void k_polar(LevelSet L, float2* __restrict__ 
   r.y = atan2f(g.y, g.x);
   out[((size_t)blockIdx.z * L.h + y) * L.w + x] = r;
 }
-// {|grad|, atan2} at a pixel of the level of segment `seg`
-__device__ __forceinline__ float2 polar_at(const LevelSet& L, int seg, const float* __restrict__ px, float mn, float mx,
-                                           int x, int y) {
-  if (L.polar && seg >= 1 && seg <= 3) return L.polar[((size_t)(seg - 1) * L.h + y) * L.w + x];
-  float2 g = pixel_gradient(px, mn, mx, L.w, L.h, x, y);
-  float2 r;
-  r.x = sqrtf((g.x * g.x) + (g.y * g.y));
-  r.y = atan2f(g.y, g.x);
-  return r;
-}
-
-// 2^-40 fixed point for histogram votes (see k_descriptors)
-__device__ __forceinline__ unsigned long long to_fixed(float v) { return (unsigned long long)(v * 1099511627776.0f); }
-__device__ __forceinline__ float from_fixed(unsigned long long t) { return (float)t * 9.094947017729282e-13f; }
+// Histogram votes in 2^-31 fixed point, accumulated with 64-bit integer LDS atomics: ds_add_f32 runs at about one lane
+// per clock on gfx950 (measured: 27 of 55 ms of the first version of k_descriptors), ds_add_u64 does not.  A vote is
+// weight * |grad| with weight <= 1 and |grad| <= sqrt(2) (components of a [0,1]-normalised level), so
+// vote * 2^31 < 2^32; a bin receives < 2^12 votes, so the 64-bit sum cannot overflow.  The integer sum is exact and
+// order independent, i.e. deterministic (the reference's shared float atomicAdd is not); the truncation error is
+// < 2^-31 per vote, far below the float rounding of the reference's own running sum.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// roundf / llroundf of a non-negative coordinate: floor + (fraction >= 0.5), 4 instructions instead of 8
+__device__ __forceinline__ int round_pos(float v) { return (int)v + (__builtin_amdgcn_fractf(v) >= 0.5f ? 1 : 0); }
+__device__ __forceinline__ float from_fixed31(unsigned long long t) { return (float)t * 4.656612873077393e-10f; }
 
 // fmodf(v, p) for |v| < 2p, exact: fmod is an exact operation and v - p is exact for p <= v < 2p (Sterbenz)
 __device__ __forceinline__ float fmod_2pi(float v, float p) {
@@ -326,17 +322,16 @@ __device__ __forceinline__ float fmod_2pi(float v, float p) {
 }
 
 // ---- S13: computeThetas(SSKeyPoint) (src/FeatureFactory.cu:1004-1112) -----------------------------------------------------
-// One WAVE per key point (the reference: one thread).  The (2w+1)^2 window is swept one row (two rows when the window is
-// at most 32 samples wide) per step with lanes along x; the 36-bin histogram lives in LDS and is accumulated with
-// ds_add_f32.  Sample coordinates are generated by the same sequence of +1.0f additions as the reference's loops so
-// llroundf() sees identical values.  Peak tests run one bin per lane; only the insertion of the (1-4) surviving peaks
-// into the best-N list is sequential, in ascending bin order like the reference.
+// One WAVE per key point (the reference: one thread).  The (2w+1)^2 window samples are packed densely over the lanes,
+// 64 per batch (sample index -> row, column by a multiply-high); the 36-bin histogram lives in LDS as 2^-31 fixed-point
+// integers (see k_descriptors).  Sample coordinates are minx + column: for coordinates below 2^23 that is the value the
+// reference's repeated `+= 1.0f` produces (an addition of 1 is exact except when it crosses a binade, where both round
+// the same exact sum).  Peak tests run one bin per lane; only the insertion of the (1-4) surviving peaks into the
+// best-N list is sequential, in ascending bin order like the reference.
 template <int MAXO>
 __global__ __launch_bounds__(256) void k_thetas(const OctaveState* st, const ssrlcv_sskeypoint* kps, LevelSet L,
                                                 float pixelWidth, float lambda, float orientationThreshold,
                                                 float* __restrict__ thetas, uint32_t* __restrict__ thetaCnt) {
-  // 2^-40 fixed-point votes with 64-bit integer LDS atomics (float LDS atomics are ~30x slower on gfx950, see
-  // k_descriptors); 8 lane-private copies (copy = lane & 7, bin-major / copy-minor)
   __shared__ unsigned long long s_hist[4][36 * 8];
   const int n = st->hasExtrema ? st->n : 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -344,10 +339,9 @@ __global__ __launch_bounds__(256) void k_thetas(const OctaveState* st, const ssr
   const int copy = lane & 7;
   const float pi = SSRLCV_PI_F;
   const float rad10 = pi / 18.0f;
+  const float2* __restrict__ polar = L.polar;  // key points live on levels 1..3, whose polar tables are always built
   for (int gi = blockIdx.x * 4 + wave; gi < n; gi += gridDim.x * 4) {
-    const int seg = segment_of(st, gi);
-    const float* px = L.dog[seg];
-    const float lmn = L.minmax[2 * seg], lmx = L.minmax[2 * seg + 1];
+    const int seg = __builtin_amdgcn_readfirstlane(segment_of(st, gi));
     const ssrlcv_sskeypoint kp = kps[gi];
     const float kx = kp.loc.x, ky = kp.loc.y;
     const float windowWidth = ceilf(kp.sigma * 3.0f * lambda / pixelWidth);
@@ -361,31 +355,35 @@ __global__ __launch_bounds__(256) void k_thetas(const OctaveState* st, const ssr
       for (int i = 0; i < 5; ++i)
         if (i * 64 + lane < 36 * 8) hist[i * 64 + lane] = 0ull;
       __builtin_amdgcn_wave_barrier();
+      const float2* __restrict__ pl = polar + (size_t)(seg - 1) * L.h * L.w;
       const float weight = 2.0f * lambda * lambda * kp.sigma * kp.sigma;
+      // exp(-(r^2) / weight) is evaluated as exp2(r^2 * k2), k2 = -log2(e) / weight: <= 3 ulp from expf of the quotient
+      const float k2 = -1.4426950408889634f / weight;
       const int S = 2 * (int)windowWidth + 1;
-      const bool two = S <= 32;
-      const int c = two ? (lane & 31) : lane;
-      const int rsub = two ? (lane >> 5) : 0;
-      // x of this lane's column: minx + 1 + 1 ... (c additions), as the reference's inner loop produces it
-      float x = minx;
-      for (int i = 1; i < S; ++i)
-        if (i <= c) x += 1.0f;
-      float y = miny;
-      if (rsub) y += 1.0f;
-      const bool colOk = c < S;
-      for (int r0 = 0; r0 < S; r0 += (two ? 2 : 1)) {
-        const int r = r0 + rsub;
-        if (colOk && r < S) {
-          float2 pg = polar_at(L, seg, px, lmn, lmx, (int)roundf(x), (int)roundf(y));  // roundf == llroundf here
-          float tx = x - kx, ty = y - ky;
-          float angle = fmod_2pi(pg.y + (2.0f * pi), 2.0f * pi);
-          int bin = (int)floorf(angle / rad10);
-          float mag = pg.x;
-          float wgt = expf(-((tx * tx) + (ty * ty)) / weight);
-          if (bin >= 0 && bin < 36) atomicAdd(&hist[bin * 8 + copy], to_fixed(mag * wgt));
-        }
-        y += 1.0f;
-        if (two) y += 1.0f;
+      const unsigned total = (unsigned)(S * S);
+      const unsigned magic = (unsigned)((0x100000000ull + (unsigned long long)S - 1ull) / (unsigned long long)S);
+      auto sample = [&](unsigned sidx, float& x, float& y) {
+        const unsigned r = __umulhi(sidx, magic);  // sidx / S, exact for sidx < 2^16
+        const unsigned cc = sidx - r * (unsigned)S;
+        x = minx + (float)cc;
+        y = miny + (float)r;
+      };
+      float nx, ny;
+      sample((unsigned)lane, nx, ny);
+      float2 npg = make_float2(0.0f, 0.0f);
+      if ((unsigned)lane < total) npg = pl[(size_t)round_pos(ny) * L.w + round_pos(nx)];
+      for (unsigned base = 0; base < total; base += 64) {
+        const float x = nx, y = ny;
+        const float2 pg = npg;
+        const bool ok = base + (unsigned)lane < total;
+        sample(base + 64 + (unsigned)lane, nx, ny);
+        if (base + 64 + (unsigned)lane < total) npg = pl[(size_t)round_pos(ny) * L.w + round_pos(nx)];
+        const float tx = x - kx, ty = y - ky;
+        const float angle = fmod_2pi(pg.y + (2.0f * pi), 2.0f * pi);
+        const int bin = (int)floorf(angle / rad10);
+        const float wgt = __builtin_amdgcn_exp2f(((tx * tx) + (ty * ty)) * k2);
+        if (ok && bin >= 0 && bin < 36)
+          atomicAdd(&hist[bin * 8 + copy], (unsigned long long)(unsigned)((pg.x * wgt) * 2147483648.0f));
       }
       __builtin_amdgcn_wave_barrier();
       float hb = 0.0f;
@@ -393,7 +391,7 @@ __global__ __launch_bounds__(256) void k_thetas(const OctaveState* st, const ssr
         unsigned long long t = 0ull;
 #pragma unroll
         for (int cpy = 0; cpy < 8; ++cpy) t += hist[lane * 8 + cpy];
-        hb = from_fixed(t);
+        hb = from_fixed31(t);
       }
       const float hprev = __shfl(hb, (lane + 35) % 36, 64);
       const float hnext = __shfl(hb, (lane + 1) % 36, 64);
@@ -460,17 +458,6 @@ __global__ __launch_bounds__(256) void k_thetas(const OctaveState* st, const ssr
 __device__ __forceinline__ float uniform_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
-// Histogram votes in 2^-31 fixed point, accumulated with 64-bit integer LDS atomics: ds_add_f32 runs at about one lane
-// per clock on gfx950 (measured: 27 of 55 ms of the first version of this kernel), ds_add_u64 does not.  A vote is
-// wxy * wk * |grad| * gauss with wxy, wk, gauss <= 1 and |grad| <= sqrt(2) (components of a [0,1]-normalised level), so
-// vote * 2^31 < 2^32; a bin receives < 2^12 votes, so the 64-bit sum cannot overflow.  The integer sum is exact and
-// order independent, i.e. deterministic (the reference's shared float atomicAdd is not); the truncation error is
-// < 2^-31 per vote, far below the float rounding of the reference's own running sum.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// roundf / llroundf of a non-negative coordinate: floor + (fraction >= 0.5), 4 instructions instead of 8
-__device__ __forceinline__ int round_pos(float v) { return (int)v + (__builtin_amdgcn_fractf(v) >= 0.5f ? 1 : 0); }
-__device__ __forceinline__ float from_fixed31(unsigned long long t) { return (float)t * 4.656612873077393e-10f; }
-
 // 4 lane-private copies of the 128 bins (4 KiB per wave) and <= 64 VGPRs: 8 waves per SIMD.  Measured on MI355X
 // (1.6 M key points of a 4096^2 image): 8 copies / 4 waves 10.4 ms, 4 copies / 8 waves 9.7 ms, 2 copies / 8 waves 10.1 ms.
 constexpr int kDescCopies = 4;
@@ -676,16 +663,33 @@ int ssrlcv_sift_plan_keypoints(const ssrlcv_sift_plan* plan, void* workspace, in
 int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrlcv_sift_feature* features,
                              uint32_t* numFeatures, ssrlcv_stream_t stream) {
   if (!plan || !workspace || !numFeatures) return SSRLCV_ERR_INVALID_ARG;
-  hipStream_t s = (hipStream_t)stream;
   char* ws = (char*)workspace;
   OctaveState* states = (OctaveState*)(ws + plan->off_state);
   const float noiseThreshold = 0.01f;  // src/SIFT_FeatureFactory.cu:58
   const float edgeThreshold = 12.1f;   // :59
   const int stop = plan->stopStage;
   const uint32_t maxO = plan->params.maxOrientations;
+  // The four octaves' chains are independent until the feature offsets are summed, and each is a long run of small
+  // launches (bookkeeping kernels, compactions of short lists): they run side by side on the plan's side streams, the
+  // polar tables on a fifth, all forked from and joined back into the caller's stream.
+  svp::PlanAsync* as = svp::plan_async(plan);
+  const hipStream_t caller = (hipStream_t)stream;
+  if (as) {
+    SSRLCV_HIP_TRY(hipEventRecord(as->fork, caller));
+    for (hipStream_t sd : as->side) SSRLCV_HIP_TRY(hipStreamWaitEvent(sd, as->fork, 0));
+    if (stop >= 6) {
+      for (int o = 0; o < svp::kOctaves; ++o) {
+        const svp::OctavePlan& oc = plan->oct[o];
+        hipLaunchKernelGGL(k_polar, dim3((oc.w + 255) / 256, oc.h, 3), dim3(256), 0, as->side[svp::kOctaves],
+                           make_levels(plan, ws, o), (float2*)(ws + oc.off_polar));
+        SSRLCV_HIP_TRY(hipEventRecord(as->polarDone[o], as->side[svp::kOctaves]));
+      }
+    }
+  }
   for (int o = 0; o < svp::kOctaves; ++o) {
     const svp::OctavePlan& oc = plan->oct[o];
     OctaveState* st = states + o;
+    const hipStream_t s = as ? as->side[o] : caller;
     LevelSet L = make_levels(plan, ws, o);
     ssrlcv_sskeypoint* A = (ssrlcv_sskeypoint*)(ws + oc.off_kpA);
     ssrlcv_sskeypoint* B = (ssrlcv_sskeypoint*)(ws + oc.off_kpB);
@@ -773,7 +777,8 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
       swap();
     }
     if (stop >= 6) {  // computeKeyPointOrientations (src/FeatureFactory.cu:540-632)
-      hipLaunchKernelGGL(k_polar, dim3((oc.w + 255) / 256, oc.h, 3), dim3(256), 0, s, L, (float2*)(ws + oc.off_polar));
+      if (as) SSRLCV_HIP_TRY(hipStreamWaitEvent(s, as->polarDone[o], 0));
+      else hipLaunchKernelGGL(k_polar, dim3((oc.w + 255) / 256, oc.h, 3), dim3(256), 0, s, L, (float2*)(ws + oc.off_polar));
       float* thetas = (float*)(ws + oc.off_theta);
       uint32_t* thetaCnt = (uint32_t*)(ws + oc.off_thetaCnt);
       dim3 g(list_blocks(cap) * 2);
@@ -806,15 +811,25 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
       swap();
     }
     if (cur != A) return SSRLCV_ERR_INVALID_ARG;  // cannot happen: nswaps accounts for every swap above
+    if (as) {
+      SSRLCV_HIP_TRY(hipEventRecord(as->join[o], s));
+      SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->join[o], 0));
+    }
+  }
+  if (as) {  // the polar stream joins too (its tables are read by the descriptor kernels below even when stop < 6 ran none)
+    SSRLCV_HIP_TRY(hipEventRecord(as->join[svp::kOctaves], as->side[svp::kOctaves]));
+    SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->join[svp::kOctaves], 0));
   }
   uint32_t* featBase = (uint32_t*)(ws + plan->oct[0].off_featBase);
-  hipLaunchKernelGGL(k_book_featbase, dim3(1), dim3(1), 0, s, states, featBase, numFeatures, plan->maxFeatures);
+  hipLaunchKernelGGL(k_book_featbase, dim3(1), dim3(1), 0, caller, states, featBase, numFeatures, plan->maxFeatures);
   if (stop >= 7) {
     if (!features) return SSRLCV_ERR_INVALID_ARG;
+    // back to back on the caller's stream: run side by side the four persistent grids only took wave slots from each
+    // other (measured 11.0 ms instead of 9.5 ms for a 4096^2 image)
     for (int o = 0; o < svp::kOctaves; ++o) {
       const svp::OctavePlan& oc = plan->oct[o];
       LevelSet L = make_levels(plan, ws, o);
-      hipLaunchKernelGGL(k_descriptors, dim3(list_blocks(oc.cap) * 2), dim3(256), 0, s, states + o,
+      hipLaunchKernelGGL(k_descriptors, dim3(list_blocks(oc.cap) * 2), dim3(256), 0, caller, states + o,
                          (const ssrlcv_sskeypoint*)(ws + oc.off_kpA), L, oc.pixelWidth,
                          plan->params.descriptorContribWidth, featBase, o, features, plan->maxFeatures);
     }

@@ -12,6 +12,7 @@
 //   * both normalisations + the DoG subtraction are one streaming kernel reading 6 levels and writing 5 (float4
 //     lanes), which also reduces the DoG levels' min/max for findKeyPoints' second normalisation.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <float.h>
 #include <math.h>
 #include <new>
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(kTX) void k_gauss_fused(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < kNR; ++i) win[2 * R + i] = s_h[i * kTX + tid];
     const int gx = x0 + tid;
-    {
+    if (s * kNR + kNR - 1 >= 2 * R) {  // the first 2R / kNR steps only fill the window: every output row is < 0
       // k outer / i inner: eight independent fmaf chains in flight (each output's own chain still runs k = 0..2R)
       float vs[kNR];
 #pragma unroll
@@ -526,7 +527,8 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
     if (weights_host[k] != weights_host[taps - 1 - k]) return SSRLCV_ERR_UNSUPPORTED;  // symmetric taps only
     a.wgt[(RT - R) + k] = weights_host[k];
   }
-  // rows per block: aim for >= 1024 blocks, never below 64 rows (halo recompute = 2R / rows)
+  // rows per block: aim for >= 1024 blocks, never below 64 rows (halo recompute = 2R / rows).  Sizing the launch to
+  // whole rounds of resident blocks (768 slots) was tried and measured no different on MI355X.
   uint32_t bx = (w + kTX - 1) / kTX;
   uint32_t rows = h;
   while (rows > 64 && bx * ((h + rows - 1) / rows) < 1024) rows = (rows + 1) / 2;
@@ -576,6 +578,37 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
 inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
 }  // namespace
+
+namespace svp {
+PlanAsync* plan_async(const ssrlcv_sift_plan* plan) {
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  if (plan->asyncState == 0) {
+    plan->asyncState = -1;
+    if (!getenv("SSRLCV_SIFT_SERIAL")) {
+      PlanAsync* a = new (std::nothrow) PlanAsync();
+      bool ok = a != nullptr;
+      auto mk = [&](hipEvent_t& e) { ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
+      if (ok) {
+        for (hipStream_t& st : a->side) ok = ok && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+        mk(a->fork);
+        for (hipEvent_t& e : a->join) mk(e);
+        for (hipEvent_t& e : a->convDone) mk(e);
+        for (hipEvent_t& e : a->dogDone) mk(e);
+        for (hipEvent_t& e : a->polarDone) mk(e);
+      }
+      if (ok) {
+        plan->async = a;
+        plan->asyncState = 1;
+      } else {
+        delete a;  // a partially created set leaks its handles; creation only fails when the device is unusable
+        (void)hipGetLastError();
+      }
+    }
+  }
+  return plan->asyncState == 1 ? plan->async : nullptr;
+}
+}  // namespace svp
 
 extern "C" {
 
@@ -679,6 +712,8 @@ int ssrlcv_sift_plan_create(uint32_t w, uint32_t h, const ssrlcv_sift_params* pa
   p->H = h;
   p->params = *params;
   p->stopStage = 7;
+  p->async = nullptr;
+  p->asyncState = 0;
   // sigma ladder: SIFT_FeatureFactory.cu:63-64 + FeatureFactory.cu:383-399
   float sigmas[svp::kGauss];
   float mulY = sqrtf(2.0f), mulX = 2;
@@ -694,6 +729,7 @@ int ssrlcv_sift_plan_create(uint32_t w, uint32_t h, const ssrlcv_sift_params* pa
   p->off_in1 = take(P0 / 4 * 4);
   p->off_in2 = take(P0 / 16 * 4);
   for (int b = 0; b < svp::kGauss; ++b) p->off_gauss[b] = take(P0 * 4);
+  for (int b = 0; b < svp::kGauss; ++b) p->off_gauss1[b] = take(P0);  // P_1 = P_0 / 4 floats
   p->off_minmax = take(sizeof(float) * 2 * (svp::kGauss + svp::kDog) * svp::kOctaves);
   p->off_state = take(sizeof(svp::OctaveState) * svp::kOctaves);
   uint32_t maxFeat = 0;
@@ -738,7 +774,20 @@ int ssrlcv_sift_plan_create(uint32_t w, uint32_t h, const ssrlcv_sift_params* pa
   return SSRLCV_OK;
 }
 
-void ssrlcv_sift_plan_destroy(ssrlcv_sift_plan* plan) { delete plan; }
+void ssrlcv_sift_plan_destroy(ssrlcv_sift_plan* plan) {
+  if (!plan) return;
+  if (plan->async) {
+    svp::PlanAsync* a = plan->async;
+    for (hipStream_t st : a->side) (void)hipStreamDestroy(st);
+    (void)hipEventDestroy(a->fork);
+    for (hipEvent_t e : a->join) (void)hipEventDestroy(e);
+    for (hipEvent_t e : a->convDone) (void)hipEventDestroy(e);
+    for (hipEvent_t e : a->dogDone) (void)hipEventDestroy(e);
+    for (hipEvent_t e : a->polarDone) (void)hipEventDestroy(e);
+    delete a;
+  }
+  delete plan;
+}
 size_t ssrlcv_sift_plan_workspace_bytes(const ssrlcv_sift_plan* plan) { return plan ? plan->total : 0; }
 uint32_t ssrlcv_sift_plan_max_features(const ssrlcv_sift_plan* plan) { return plan ? plan->maxFeatures : 0; }
 void ssrlcv_sift_plan_set_stop_stage(ssrlcv_sift_plan* plan, int stage) { if (plan) plan->stopStage = stage; }
@@ -755,7 +804,7 @@ int ssrlcv_sift_plan_level(const ssrlcv_sift_plan* plan, void* workspace, int ki
     if (minmax_dev) *minmax_dev = mm + 2 * (svp::kGauss + blur);
   } else if (kind == 1) {
     if (blur < 0 || blur >= svp::kGauss) return SSRLCV_ERR_INVALID_ARG;
-    if (data) *data = (float*)(ws + plan->off_gauss[blur]);
+    if (data) *data = (float*)(ws + ((octave & 1) ? plan->off_gauss1[blur] : plan->off_gauss[blur]));
     if (minmax_dev) *minmax_dev = mm + 2 * blur;
   } else {
     return SSRLCV_ERR_INVALID_ARG;
@@ -773,6 +822,11 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
   char* ws = (char*)workspace;
   float* mmAll = (float*)(ws + plan->off_minmax);
   const int pairs = (svp::kGauss + svp::kDog) * svp::kOctaves;
+  // The convolutions (FMA-issue bound) stay on the caller's stream; the DoG kernel of octave o (HBM bound) runs on a
+  // side stream beside the convolutions of octave o+1, which only need level 3 of octave o.  Octaves alternate between
+  // two sets of gaussian buffers so that octave o+1 never overwrites what DoG(o) is still reading.
+  svp::PlanAsync* as = svp::plan_async(plan);
+  hipStream_t sd = as ? as->side[svp::kOctaves] : st;
   hipLaunchKernelGGL(k_init_minmax, dim3(1), dim3(64), 0, st, mmAll, pairs);
   // S1+S2: u8 -> f32 + one 2x upsample (startingOctave = -1)
   float* in = (float*)(ws + plan->off_in0);
@@ -782,10 +836,12 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
   for (int o = 0; o < svp::kOctaves; ++o) {
     const svp::OctavePlan& oc = plan->oct[o];
     float* mm = mmAll + (size_t)o * 2 * (svp::kGauss + svp::kDog);
+    const size_t* offGauss = (o & 1) ? plan->off_gauss1 : plan->off_gauss;
+    if (as && o >= 2) SSRLCV_HIP_TRY(hipStreamWaitEvent(st, as->dogDone[o - 2], 0));  // buffer set free again
     const float* src = in;
     const float* lv[svp::kGauss];
     for (int b = 0; b < svp::kGauss; ++b) {
-      float* dst = (float*)(ws + plan->off_gauss[b]);
+      float* dst = (float*)(ws + offGauss[b]);
       rc = launch_conv(src, dst, nullptr, oc.w, oc.h, oc.taps[b], oc.weights[b], mm + 2 * b, st);
       if (rc) return rc;
       lv[b] = dst;
@@ -797,11 +853,17 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
       if (rc) return rc;
       in = nextIn[o];
     }
+    if (as) {
+      SSRLCV_HIP_TRY(hipEventRecord(as->convDone[o], st));
+      SSRLCV_HIP_TRY(hipStreamWaitEvent(sd, as->convDone[o], 0));
+    }
     float* dogs[svp::kDog];
     for (int b = 0; b < svp::kDog; ++b) dogs[b] = (float*)(ws + oc.off_dog[b]);
-    rc = ssrlcv_hip_dog_normalised_sub(lv, mm, oc.w, oc.h, dogs, mm + 2 * svp::kGauss, stream);
+    rc = ssrlcv_hip_dog_normalised_sub(lv, mm, oc.w, oc.h, dogs, mm + 2 * svp::kGauss, (ssrlcv_stream_t)sd);
     if (rc) return rc;
+    if (as) SSRLCV_HIP_TRY(hipEventRecord(as->dogDone[o], sd));
   }
+  if (as) SSRLCV_HIP_TRY(hipStreamWaitEvent(st, as->dogDone[svp::kOctaves - 1], 0));  // sd is in order: joins every DoG
   return SSRLCV_OK;
 }
 

@@ -4,7 +4,8 @@
 //   octave o (0..3) works at (2W >> o) x (2H >> o); P_o pixels, sum P = 5.3125 W H
 //   in0        f32  P_0        octave-0 input (2x bilinear upsample of the u8 image)
 //   in1        f32  P_1        input of octaves 1..3 (2x2 bin of the previous octave's un-normalised level 3); reused
-//   gauss[6]   f32  6 P_0      the six gaussian levels of the octave being built (un-normalised); reused per octave
+//   gauss[6]   f32  6 P_0      the six gaussian levels of the octave being built (un-normalised); octaves 0 and 2
+//   gauss1[6]  f32  6 P_1      same for octaves 1 and 3, so that octave o+1 can be convolved while octave o's DoG runs
 //   dog[o][5]  f32  5 sum P    raw DoG levels of every octave (kept: extrema, refinement, gradients read them)
 //   flags[o]   u8   sum P      3 extremum bits per pixel (levels 1..3)
 //   polar[o]   f32x2 3 sum P   gradient magnitude / direction of DoG levels 1..3 (shared by orientation + descriptors)
@@ -13,6 +14,7 @@
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
+#include <hip/hip_runtime.h>
 #include "ssrlcv_hip.h"
 
 namespace svp {
@@ -51,6 +53,16 @@ struct OctavePlan {
   size_t off_featBase;     // uint32: first feature index of this octave
 };
 
+// Side streams and events of one plan.  build_dog runs the HBM-bound DoG kernel of octave o beside the FMA-bound
+// convolutions of octave o+1; describe runs the four octaves' key-point chains (many tiny launches) and the polar
+// tables side by side.  Everything is forked from and joined back into the caller's stream, so the calls keep their
+// stream-ordered semantics.  One call per plan may be in flight at a time.
+struct PlanAsync {
+  hipStream_t side[kOctaves + 1];
+  hipEvent_t fork;
+  hipEvent_t join[kOctaves + 1], convDone[kOctaves], dogDone[kOctaves], polarDone[kOctaves];
+};
+
 }  // namespace svp
 
 struct ssrlcv_sift_plan {
@@ -58,11 +70,19 @@ struct ssrlcv_sift_plan {
   ssrlcv_sift_params params;
   svp::OctavePlan oct[svp::kOctaves];
   size_t off_in0, off_in1, off_in2;
-  size_t off_gauss[svp::kGauss];
+  size_t off_gauss[svp::kGauss];   // octaves 0, 2
+  size_t off_gauss1[svp::kGauss];  // octaves 1, 3
   size_t off_minmax;   // floats: [oct][kGauss + kDog][2]
   size_t off_state;    // OctaveState[kOctaves]
   size_t off_extremaCounts;  // scratch for the pixel-domain partition
   size_t total;
   uint32_t maxFeatures;
   int stopStage;
+  mutable svp::PlanAsync* async;  // created on first use (needs a device); see svp::plan_async
+  mutable int asyncState;         // 0 not tried, 1 ready, -1 serial (SSRLCV_SIFT_SERIAL set or creation failed)
 };
+
+namespace svp {
+// -> the plan's side streams, or nullptr when the calls must run serially on the caller's stream
+PlanAsync* plan_async(const ssrlcv_sift_plan* plan);
+}  // namespace svp
