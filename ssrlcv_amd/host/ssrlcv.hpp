@@ -7,3 +7,4 @@
 #include "MatchFactory.hpp"
 #include "PointCloudFactory.hpp"
 #include "io_util.hpp"
+#include "Pipeline.hpp"

@@ -118,44 +118,40 @@ static int pipeline_mode(const std::string& dir, int views) {
     allFeatures.push_back(feats);
     std::printf("features %d %lu\n", im->id, feats->size());
   }
-  ptr::value<Unity<Feature<SIFT_Descriptor>>> seedFeatures(cp_path<Feature<SIFT_Descriptor>>(dir, -1));
-  MatchFactory<SIFT_Descriptor> matchFactory(0.6f, 200.0f * 200.0f);  // src/Pipeline.cu:175
-  matchFactory.setSeedFeatures(seedFeatures);
-  const float epsilon = 25.0f, delta = 5.0f;
-  MatchSet matchSet;
-  PointCloudFactory pcf;
-  float error = 0;
-  if (views == 2) {
-    auto seedDistances = matchFactory.getSeedDistances(allFeatures[0]);
-    auto dm = matchFactory.generateDistanceMatchesDoubleConstrained(images[0], allFeatures[0], images[1], allFeatures[1],
-                                                                    epsilon, delta, seedDistances);
-    CHECK(allFeatures[0]->getMemoryState() == both);  // origin state restored
-    auto matches = matchFactory.getRawMatches(dm);
-    matches->setMemoryState(cpu);
-    // 2-view MatchSet assembly (src/Pipeline.cu:198-224)
-    matchSet.keyPoints = ptr::value<Unity<KeyPoint>>(nullptr, matches->size() * 2, cpu);
-    matchSet.matches = ptr::value<Unity<MultiMatch>>(nullptr, matches->size(), cpu);
-    for (unsigned long i = 0; i < matches->size(); ++i) {
-      matchSet.keyPoints->host.get()[2 * i] = matches->host.get()[i].keyPoints[0];
-      matchSet.keyPoints->host.get()[2 * i + 1] = matches->host.get()[i].keyPoints[1];
-      matchSet.matches->host.get()[i] = {2, (int)(2 * i)};
-    }
-  } else {
-    matchSet = matchFactory.generateMatchesExhaustive(images, allFeatures, epsilon, delta);
-    matchSet.matches->setMemoryState(cpu);
-    matchSet.keyPoints->setMemoryState(cpu);
-  }
+  // the reference's stage flow (src/SFM.cu:131-230, test/Pipeline.cu) through the Pipeline.hpp glue
+  pipelineOutputDir() = dir + "/";
+  PoseEstimationInput poseInput;
+  poseInput.seedFeatures = ptr::value<Unity<Feature<SIFT_Descriptor>>>(cp_path<Feature<SIFT_Descriptor>>(dir, -1));
+  poseInput.allFeatures = allFeatures;
+  poseInput.images = images;
+  PoseEstimationOutput poseOutput;  // pose estimation skipped, as `SFM` does without --pose
+  FeatureMatchingInput matchInput;
+  matchInput.fromPreviousStage(&poseInput, &poseOutput, 25.0f, 5.0f);
+  FeatureMatchingOutput matchOutput;
+  doFeatureMatching(&matchInput, &matchOutput);
+  if (views == 2) CHECK(allFeatures[0]->getMemoryState() == both);  // origin state restored by the match factory
+  MatchSet& matchSet = matchOutput.matchSet;
   matchSet.keyPoints->checkpoint(100, dir + "/");
   matchSet.matches->checkpoint(100, dir + "/");
-  BundleSet bundleSet = pcf.generateBundles(&matchSet, images);
-  CHECK(matchSet.matches->getMemoryState() == cpu && bundleSet.lines->getMemoryState() == cpu);
-  ptr::value<Unity<float3>> points = views == 2 ? pcf.twoViewTriangulate(bundleSet, &error) : pcf.nViewTriangulate(bundleSet, &error);
+  TriangulationInput triInput;
+  triInput.fromPreviousStage(&matchInput, &matchOutput);
+  TriangulationOutput triOutput;
+  doTriangulation(&triInput, &triOutput);
+  CHECK(triInput.matchSet.matches->getMemoryState() == cpu);
+  ptr::value<Unity<float3>> points = triOutput.points;
   CHECK(points->getMemoryState() == cpu);
   points->checkpoint(100, dir + "/");
-  std::printf("matches %lu error %f\n", matchSet.matches->size(), error);
+  std::printf("matches %lu\n", matchSet.matches->size());
+  PointCloudFactory pcf;
   if (views == 2) {
     // doBundleAdjust (src/Pipeline.cu:371-384): 10 iterations requested
-    auto adjusted = pcf.BundleAdjustTwoView(&matchSet, images, 10, "");
+    FilteringInput unfiltered;  // BA on the unfiltered set here; the filters have their own modes below
+    unfiltered.fromPreviousStage(&triInput);
+    BundleAdjustInput baInput;
+    baInput.fromPreviousStage(&unfiltered);
+    BundleAdjustOutput baOutput;
+    doBundleAdjust(&baInput, &baOutput);
+    auto adjusted = baOutput.points;
     CHECK(adjusted != nullptr && adjusted->size() == points->size());
     adjusted->checkpoint(101, dir + "/");
     // pseudo-inverse self check: H H+ H ~ H on a symmetric rank-deficient matrix
@@ -182,29 +178,15 @@ static int pipeline_mode(const std::string& dir, int views) {
 
 // doFiltering (src/Pipeline.cu:297-352) from the reference's stage-0 MatchSet checkpoint
 static int filter_mode(const std::string& dir, int views) {
-  std::vector<ptr::value<Image>> images;
-  for (int i = 0; i < views; ++i)
-    images.push_back(ptr::value<Image>(dir + "/" + std::to_string(i) + "_" + typeid(Image).name() + ".cpimg", i));
-  MatchSet matchSet;
-  matchSet.keyPoints = ptr::value<Unity<KeyPoint>>(cp_path<KeyPoint>(dir, 0));
-  matchSet.matches = ptr::value<Unity<MultiMatch>>(cp_path<MultiMatch>(dir, 0));
-  PointCloudFactory pcf;
-  float err = 0;
-  ptr::value<Unity<float3>> points;
-  if (views == 2) {
-    pcf.linearCutoffFilter(&matchSet, images, 100.0);
-    pcf.deterministicStatisticalFilter(&matchSet, images, 3.0, 0.1);
-    BundleSet bs = pcf.generateBundles(&matchSet, images);
-    points = pcf.twoViewTriangulate(bs, &err);
-  } else {
-    pcf.deterministicStatisticalFilter(&matchSet, images, 3.0, 0.1);
-    BundleSet bs = pcf.generateBundles(&matchSet, images);
-    points = pcf.nViewTriangulate(bs, &err);
-  }
-  matchSet.keyPoints->checkpoint(201, dir + "/");
-  matchSet.matches->checkpoint(201, dir + "/");
-  points->checkpoint(201, dir + "/");
-  std::printf("filtered %lu error %f\nfilter ok\n", matchSet.matches->size(), err);
+  pipelineOutputDir() = dir + "/";
+  FilteringInput in;
+  in.fromCheckpoint(dir, dir, views);  // <dir>/i_Image.cpimg + 0_KeyPoint / 0_MultiMatch, like test/Pipeline.cu
+  FilteringOutput out;
+  doFiltering(&in, &out);
+  in.matchSet.keyPoints->checkpoint(201, dir + "/");
+  in.matchSet.matches->checkpoint(201, dir + "/");
+  out.points->checkpoint(201, dir + "/");
+  std::printf("filtered %lu\nfilter ok\n", in.matchSet.matches->size());
   return 0;
 }
 
