@@ -80,6 +80,7 @@ typedef struct { uint32_t numKeyPoints; int index; } ssrlcv_multimatch;
 typedef struct { uint8_t invalid; ssrlcv_keypoint keyPoints[2]; } ssrlcv_match;
 typedef struct { uint8_t invalid; ssrlcv_keypoint keyPoints[2]; float distance; } ssrlcv_dmatch;
 typedef struct { ssrlcv_uint2 a, b; } ssrlcv_uint2_pair;
+typedef struct { float roll, pitch, yaw, x, y, z; } ssrlcv_pose;  /* ssrlcv::Pose (include/PoseEstimator.cuh:21-28) */
 typedef struct { ssrlcv_float3 vec, pnt; } ssrlcv_line;
 typedef struct { uint32_t numLines; int index; uint8_t invalid; } ssrlcv_bundle;
 

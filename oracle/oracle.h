@@ -137,6 +137,10 @@ void oracle_match_pairs(int mode, uint32_t queryID, uint32_t nq, const o_feature
                         o_uint2_pair* out);
 
 /* src/MatchFactory.cu:1240-1277 getEpipolarEndpoints (exposed for kernel-level tests) */
+void oracle_match_match(int mode, uint32_t queryID, uint32_t nq, const o_feature* query, uint32_t targetID, uint32_t nt,
+                        const o_feature* target, const o_camera* queryCam, const o_float4* targetP, float epsilon,
+                        float delta, const float* seedDistances, float relativeThreshold, float absoluteThreshold,
+                        o_match* out);
 void oracle_epipolar_endpoints(const o_camera* qc, const o_float4* P, const o_float2* loc, float delta, o_float2* p1,
                                o_float2* p2);
 /* src/MatchFactory.cu:943-1020: host adjacency merge of generateMatchesExhaustive.  pairs = validated uint2_pair
@@ -147,6 +151,15 @@ int oracle_exhaustive_merge(uint32_t numImages, const uint32_t* numFeatures, uin
 void oracle_free(void* p);
 
 /* ------------------------------- SIFT (S) -------------------------------------------- */
+/* ---- pose estimator (oracle_pose.c; reference src/PoseEstimator.cu) ---- */
+typedef struct { float roll, pitch, yaw, x, y, z; } o_pose;          /* ssrlcv::Pose, include/PoseEstimator.cuh:21-28 */
+void oracle_pose_residual(const o_pose* pose, const o_camera* query, const o_camera* target, const o_float2* q_loc,
+                          const o_float2* t_loc, float out[4]);
+float oracle_pose_cost(const o_match* matches, uint32_t n, const o_pose* pose, const o_camera* query,
+                       const o_camera* target);
+void oracle_pose_lm_terms(const o_match* matches, uint32_t n, const o_pose* pose, const o_camera* query,
+                          const o_camera* target, float JTJ[36], float JTf[6], float* cost);
+
 typedef struct oracle_sift oracle_sift;   /* opaque scale-space + keypoint state */
 /* src/SIFT_FeatureFactory.cu:17-31,55-169 sparse branch.  Returns number of features; *out is malloc'd. */
 int oracle_sift_generate(const uint8_t* pixels, uint32_t width, uint32_t height, uint32_t maxOrientations,

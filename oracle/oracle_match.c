@@ -190,6 +190,36 @@ void oracle_match_dmatch(int mode, uint32_t queryID, uint32_t nq, const o_featur
   free(dist);
 }
 
+/* Match output (no distance field): matchFeaturesBruteForce :1659-1708 compares with relativeThreshold, the
+ * double-constrained kernel :1777-1873 with its square. */
+void oracle_match_match(int mode, uint32_t queryID, uint32_t nq, const o_feature* query, uint32_t targetID, uint32_t nt,
+                        const o_feature* target, const o_camera* queryCam, const o_float4* targetP, float epsilon,
+                        float delta, const float* seedDistances, float relativeThreshold, float absoluteThreshold,
+                        o_match* out) {
+  int* idx = (int*)malloc(sizeof(int) * (nq ? nq : 1));
+  float* dist = (float*)malloc(sizeof(float) * (nq ? nq : 1));
+  oracle_match_core(mode, nq, query, nt, target, queryCam, targetP, epsilon, delta, absoluteThreshold, idx, dist);
+  const float limit = mode == 0 ? relativeThreshold : relativeThreshold * relativeThreshold;
+  for (uint32_t q = 0; q < nq; ++q) {
+    o_match m;
+    memset(&m, 0, sizeof m);
+    if (dist[q] >= absoluteThreshold || idx[q] == -1) {
+      m.invalid = 1;
+    } else if (seedDistances && (dist[q] / seedDistances[q] > limit)) {
+      m.invalid = 1;
+    } else {
+      m.invalid = 0;
+      m.keyPoints[0].loc = query[q].loc;
+      m.keyPoints[1].loc = target[idx[q]].loc;
+      m.keyPoints[0].parentId = (int)queryID;
+      m.keyPoints[1].parentId = (int)targetID;
+    }
+    out[q] = m;
+  }
+  free(idx);
+  free(dist);
+}
+
 void oracle_match_pairs(int mode, uint32_t queryID, uint32_t nq, const o_feature* query, uint32_t targetID, uint32_t nt,
                         const o_feature* target, const o_camera* queryCam, const o_float4* targetP, float epsilon,
                         float delta, const float* seedDistances, float relativeThreshold, float absoluteThreshold,

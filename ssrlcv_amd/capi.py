@@ -116,6 +116,32 @@ def ba_sweep2(matches_d, keypoints_d, num_bundles, cameras_d, num_cameras, param
     return sums
 
 
+# ------------------------------------------------------------------ pose refinement
+def _host_bytes(a, n):
+    return np.ascontiguousarray(a).view(np.uint8).reshape(-1)[:n].copy()
+
+
+def pose_lm_terms(matches_d, n, pose6, query_cam_np, target_cam_np):
+    """-> (JTJ[6,6] with JTJ[j, i] = out[i + 6 j], JTf[6], cost) of PoseEstimator::LM_iteration at `pose6`
+    (roll, pitch, yaw, x, y, z)."""
+    pose = np.asarray(pose6, np.float32).copy()
+    q, t = _host_bytes(query_cam_np, 80), _host_bytes(target_cam_np, 80)
+    out = torch.empty(43, dtype=torch.float32, device="cuda")
+    check(LIB.ssrlcv_hip_pose_lm_terms(ptr(matches_d), c_u32(n), pose.ctypes.data_as(c_vp), q.ctypes.data_as(c_vp),
+                                       t.ctypes.data_as(c_vp), ptr(out), stream_ptr()))
+    o = out.cpu().numpy()
+    return o[:36].reshape(6, 6).copy(), o[36:42].copy(), float(o[42])
+
+
+def pose_cost(matches_d, n, pose6, query_cam_np, target_cam_np):
+    pose = np.asarray(pose6, np.float32).copy()
+    q, t = _host_bytes(query_cam_np, 80), _host_bytes(target_cam_np, 80)
+    out = torch.empty(1, dtype=torch.float32, device="cuda")
+    check(LIB.ssrlcv_hip_pose_cost(ptr(matches_d), c_u32(n), pose.ctypes.data_as(c_vp), q.ctypes.data_as(c_vp),
+                                   t.ctypes.data_as(c_vp), ptr(out), stream_ptr()))
+    return float(out.item())
+
+
 # ------------------------------------------------------------------ matching
 def projection_matrix(camera_np):
     cam = np.ascontiguousarray(camera_np).view(np.uint8).reshape(-1)[:80].copy()

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void k_finalize(const unsigned long long* __re
                                                   const ssrlcv_sift_feature* __restrict__ target,
                                                   const float* __restrict__ seedDistances, uint32_t queryID,
                                                   uint32_t targetID, float rel, float absThreshold, int outKind,
-                                                  void* __restrict__ out) {
+                                                  int mode, void* __restrict__ out) {
   uint32_t q = blockIdx.x * 256 + threadIdx.x;
   if (q >= nq) return;
   unsigned long long k = bestKey[q];
@@ -337,8 +337,8 @@ __global__ __launch_bounds__(256) void k_finalize(const unsigned long long* __re
   m.distance = dist;
   if (dist >= absThreshold || matchIndex == -1) {
     m.invalid = 1;
-  } else if (seedDistances && (dist / seedDistances[q] > rel * rel)) {
-    m.invalid = 1;
+  } else if (seedDistances && (dist / seedDistances[q] > ((outKind == SSRLCV_OUT_MATCH && mode == 0) ? rel : rel * rel))) {
+    m.invalid = 1;  // rel^2 everywhere except the brute-force Match kernel (src/MatchFactory.cu:1695)
   } else {
     m.invalid = 0;
     m.keyPoints[0].loc = query[q].loc;
@@ -458,7 +458,7 @@ int ssrlcv_hip_match_u8x128(const ssrlcv_sift_feature* query, uint32_t numQuery,
   hipLaunchKernelGGL(k_finalize, dim3((numQuery + 255) / 256), dim3(256), 0, st,
                      (const unsigned long long*)((char*)workspace + L.off_key), numQuery, query, target, seedDistances,
                      params_host->queryImageID, params_host->targetImageID, params_host->relativeThreshold,
-                     params_host->absoluteThreshold, outKind, out);
+                     params_host->absoluteThreshold, outKind, params_host->mode, out);
   SSRLCV_LAUNCH_CHECK();
   return SSRLCV_OK;
 }

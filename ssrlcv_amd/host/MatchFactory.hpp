@@ -152,6 +152,20 @@ class MatchFactory {
     return run<uint2_pair>(1, SSRLCV_OUT_UINT2_PAIR, query, queryFeatures, target, targetFeatures, epsilon, delta, seedDistances);
   }
 
+  // Match outputs (src/MatchFactory.cu:349-395 brute force, :447-503 double-constrained): the pose-estimation stage's
+  // matcher (src/Pipeline.cu:94)
+  ptr::value<Unity<Match>> generateMatches(ptr::value<Image> query, ptr::value<Unity<Feature<T>>> queryFeatures,
+                                           ptr::value<Image> target, ptr::value<Unity<Feature<T>>> targetFeatures,
+                                           ptr::value<Unity<float>> seedDistances = nullptr) {
+    return run<Match>(0, SSRLCV_OUT_MATCH, query, queryFeatures, target, targetFeatures, 0.0f, 0.0f, seedDistances);
+  }
+  ptr::value<Unity<Match>> generateMatchesDoubleConstrained(ptr::value<Image> query, ptr::value<Unity<Feature<T>>> queryFeatures,
+                                                            ptr::value<Image> target, ptr::value<Unity<Feature<T>>> targetFeatures,
+                                                            float epsilon, float delta,
+                                                            ptr::value<Unity<float>> seedDistances = nullptr) {
+    return run<Match>(1, SSRLCV_OUT_MATCH, query, queryFeatures, target, targetFeatures, epsilon, delta, seedDistances);
+  }
+
   // convertMatchToRaw (src/MatchFactory.cu:257-280, :2921-2926): slice the DMatch base
   ptr::value<Unity<Match>> getRawMatches(ptr::value<Unity<DMatch>> matches) {
     MemoryState origin = matches->getMemoryState();

@@ -7,8 +7,8 @@
 //    checkpoints plus `<id>_h.uty` pixel checkpoints when an image path names a directory entry of that form, and
 //    otherwise fails like the reference does on an unreadable image; the overload taking ready `Image`s is what the
 //    tests and the Python driver use;
-//  - doPoseEstimation needs PoseEstimator (section 8f item 3), which is not built: it computes the seed distances the
-//    way the reference does and leaves the cameras untouched;
+//  - doPoseEstimation runs the reference's flow (seed distances, double-constrained matches, LM refinement from the
+//    cameras' relative pose); PoseEstimator::estimatePoseRANSAC, commented out upstream, is not built;
 //  - MeshFactory::setPoints + savePoints("name") is the ASCII PLY dump, done with writePLY.
 #pragma once
 #include <sys/stat.h>
@@ -20,6 +20,7 @@
 #include "Image.hpp"
 #include "MatchFactory.hpp"
 #include "PointCloudFactory.hpp"
+#include "PoseEstimator.hpp"
 #include "SIFT_FeatureFactory.hpp"
 #include "io_util.hpp"
 
@@ -139,11 +140,47 @@ struct PoseEstimationOutput {
 };
 
 inline void doPoseEstimation(PoseEstimationInput* in, PoseEstimationOutput* out) {
+  logger.info << "Starting pose estimation...";
   logger.logState("POSE");
-  MatchFactory<SIFT_Descriptor> matchFactory = MatchFactory<SIFT_Descriptor>(0.6f, 10.0f * 10.0f);  // src/Pipeline.cu:84
+  MatchFactory<SIFT_Descriptor> matchFactory = MatchFactory<SIFT_Descriptor>(0.6f, 10.0f * 10.0f);
   if (in->seedFeatures != nullptr) matchFactory.setSeedFeatures(in->seedFeatures);
   out->seedDistances = (in->seedFeatures != nullptr) ? matchFactory.getSeedDistances(in->allFeatures[0]) : nullptr;
-  logger.warn << "PoseEstimator (LM refinement of the second camera) is not part of this build: cameras left as given";
+  logger.logState("matching images");
+  ptr::value<Unity<Match>> matches = matchFactory.generateMatchesDoubleConstrained(
+      in->images[0], in->allFeatures[0], in->images[1], in->allFeatures[1], 100, 3, out->seedDistances);
+  logger.logState("done matching images");
+  matches->transferMemoryTo(cpu);
+  PoseEstimator estim(in->images.at(0), in->images.at(1), matches);
+  // starting pose = the cameras' relative pose (the RANSAC estimate is commented out upstream, src/Pipeline.cu:101)
+  Pose pose;
+  float3 pos = in->images.at(0)->camera.cam_pos - in->images.at(1)->camera.cam_pos;
+  pos = rotatePointArbitrary(pos, {0, 0, 1}, -in->images.at(0)->camera.cam_rot.z);
+  pos = rotatePointArbitrary(pos, {0, 1, 0}, -in->images.at(0)->camera.cam_rot.y);
+  pos = rotatePointArbitrary(pos, {1, 0, 0}, -in->images.at(0)->camera.cam_rot.x);
+  pose.x = pos.x;
+  pose.y = pos.y;
+  pose.z = pos.z;
+  float C0[3][3], C0t[3][3], C1[3][3], relative[3][3];
+  getRotationMatrix(in->images.at(0)->camera.cam_rot, C0);
+  transpose(C0, C0t);
+  getRotationMatrix(in->images.at(1)->camera.cam_rot, C1);
+  multiply(C0t, C1, relative);
+  float3 rot = getAxisRotations(relative);
+  pose.roll = rot.x;
+  pose.pitch = rot.y;
+  pose.yaw = rot.z;
+  logger.info.printf("Original pose: %f %f %f", pose.roll, pose.pitch, pose.yaw);
+  estim.LM_optimize(&pose);
+  // write the refined pose back into the second camera (src/Pipeline.cu:127-136)
+  float R1[3][3], R2[3][3], R[3][3];
+  in->images.at(1)->camera.cam_pos =
+      in->images.at(0)->camera.cam_pos + rotatePoint({1000 * pose.x, 1000 * pose.y, 1000 * pose.z}, in->images.at(0)->camera.cam_rot);
+  getRotationMatrix({pose.roll, pose.pitch, pose.yaw}, R1);
+  getRotationMatrix(in->images.at(0)->camera.cam_rot, R2);
+  multiply(R2, R1, R);
+  in->images.at(1)->camera.cam_rot = getAxisRotations(R);
+  logger.info.printf("Rotation: %f %f %f", in->images.at(1)->camera.cam_rot.x, in->images.at(1)->camera.cam_rot.y, in->images.at(1)->camera.cam_rot.z);
+  logger.info.printf("Position: %f %f %f", in->images.at(1)->camera.cam_pos.x, in->images.at(1)->camera.cam_pos.y, in->images.at(1)->camera.cam_pos.z);
   logger.logState("POSE");
 }
 

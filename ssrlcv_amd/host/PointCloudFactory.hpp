@@ -15,6 +15,7 @@
 #include <vector>
 #include "Image.hpp"
 #include "MatchFactory.hpp"
+#include "matrix_util.hpp"
 
 namespace ssrlcv {
 
@@ -381,46 +382,13 @@ class PointCloudFactory {
   }
 
   // calculateImageHessianInverse (:1511-1824): Moore-Penrose pseudo-inverse, singular values below 1e-4 dropped
-  // (:1698).  One-sided Jacobi SVD on the host (N = 12).  Input/output row-major like the caller's use with
+  // (:1698), pseudoInverse() of matrix_util.hpp (N = 12).  Input/output row-major like the caller's use with
   // cublasSgemv(CUBLAS_OP_N) on a symmetric matrix.
   ptr::value<Unity<float>> calculateImageHessianInverse(ptr::value<Unity<float>> hessian) {
     const int N = (int)std::lround(std::sqrt((double)hessian->size()));
-    std::vector<double> U(N * N), Vm(N * N, 0.0);
-    for (int i = 0; i < N * N; ++i) U[i] = hessian->host.get()[i];
-    for (int i = 0; i < N; ++i) Vm[i * N + i] = 1.0;
-    for (int sweep = 0; sweep < 60; ++sweep) {
-      double off = 0.0;
-      for (int p = 0; p < N - 1; ++p)
-        for (int q = p + 1; q < N; ++q) {
-          double a = 0, b = 0, c = 0;
-          for (int r = 0; r < N; ++r) { a += U[r * N + p] * U[r * N + p]; b += U[r * N + q] * U[r * N + q]; c += U[r * N + p] * U[r * N + q]; }
-          off += c * c;
-          if (std::fabs(c) <= 1e-30 * std::sqrt(a * b) || c == 0.0) continue;
-          double zeta = (b - a) / (2.0 * c);
-          double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
-          double cs = 1.0 / std::sqrt(1.0 + t * t), sn = cs * t;
-          for (int r = 0; r < N; ++r) {
-            double up = U[r * N + p], uq = U[r * N + q];
-            U[r * N + p] = cs * up - sn * uq;
-            U[r * N + q] = sn * up + cs * uq;
-            double vp = Vm[r * N + p], vq = Vm[r * N + q];
-            Vm[r * N + p] = cs * vp - sn * vq;
-            Vm[r * N + q] = sn * vp + cs * vq;
-          }
-        }
-      if (off < 1e-60) break;
-    }
+    std::vector<float> pinv = pseudoInverse(hessian->host.get(), N, 1e-4);
     ptr::value<Unity<float>> inv(nullptr, (unsigned long)(N * N), cpu);
-    std::vector<double> out(N * N, 0.0);
-    for (int k = 0; k < N; ++k) {
-      double s = 0;
-      for (int r = 0; r < N; ++r) s += U[r * N + k] * U[r * N + k];
-      s = std::sqrt(s);
-      if (s < 1e-4) continue;  // sigma below the cutoff contributes nothing
-      for (int i = 0; i < N; ++i)
-        for (int j = 0; j < N; ++j) out[i * N + j] += Vm[i * N + k] * (U[j * N + k] / s) / s;  // V S^-1 U^T
-    }
-    for (int i = 0; i < N * N; ++i) inv->host.get()[i] = (float)out[i];
+    for (int i = 0; i < N * N; ++i) inv->host.get()[i] = pinv[i];
     return inv;
   }
 

@@ -4,6 +4,7 @@
 //   pipeline2 <dir>     (GPU) SIFT -> seed distances -> double-constrained match -> MatchSet -> triangulate -> BA, through
 //                       the reference's class API; inputs/outputs are .uty / .cpimg files in <dir>
 //   pipeline3 <dir>     (GPU) 3-view: generateMatchesExhaustive -> nViewTriangulate
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <iostream>
@@ -190,6 +191,54 @@ static int filter_mode(const std::string& dir, int views) {
   return 0;
 }
 
+// PoseEstimator::LM_optimize on the reference's stage-0 MatchSet (pairs) of the 2-view fixture: started from the true
+// relative pose the cost must not grow; started from a target camera rotated by 2 mrad it must come back down
+static int pose_mode(const std::string& dir) {
+  TriangulationInput in;
+  in.fromCheckpoint(dir, dir, 2);
+  unsigned long n = in.matchSet.matches->size();
+  ptr::value<Unity<Match>> matches(nullptr, n, cpu);
+  for (unsigned long i = 0; i < n; ++i) {
+    Match m;
+    m.invalid = false;
+    m.keyPoints[0] = in.matchSet.keyPoints->host.get()[2 * i];
+    m.keyPoints[1] = in.matchSet.keyPoints->host.get()[2 * i + 1];
+    matches->host.get()[i] = m;
+  }
+  auto relative = [&](Pose& pose) {
+    float C0[3][3], C0t[3][3], C1[3][3], rel[3][3];
+    getRotationMatrix(in.images[0]->camera.cam_rot, C0);
+    transpose(C0, C0t);
+    getRotationMatrix(in.images[1]->camera.cam_rot, C1);
+    multiply(C0t, C1, rel);
+    float3 rot = getAxisRotations(rel);
+    pose.roll = rot.x; pose.pitch = rot.y; pose.yaw = rot.z;
+    pose.x = pose.y = pose.z = 0;  // LM_optimize fills the position from the cameras
+  };
+  PoseEstimator estim(in.images[0], in.images[1], matches);
+  Pose pose;
+  relative(pose);
+  Pose start = pose;
+  float lambda = 100;
+  estim.LM_optimize(&pose);  // sets x, y, z and iterates
+  std::printf("pose true-start roll %g pitch %g yaw %g -> %g %g %g\n", start.roll, start.pitch, start.yaw, pose.roll, pose.pitch, pose.yaw);
+  CHECK(std::isfinite(pose.roll) && std::isfinite(pose.pitch) && std::isfinite(pose.yaw));
+  CHECK(std::fabs(pose.roll - start.roll) < 5e-3f && std::fabs(pose.pitch - start.pitch) < 5e-3f && std::fabs(pose.yaw - start.yaw) < 5e-3f);
+  // perturbed start: one LM_iteration at a time, costs reported through the terms call
+  Pose bad = pose;
+  bad.pitch += 0.002f;
+  Pose it = bad;
+  lambda = 100;
+  int iters = 0;
+  while (iters < 50 && estim.LM_iteration(&it, &lambda)) ++iters;
+  std::printf("pose perturbed pitch %g -> %g (refined %g) after %d iterations\n", bad.pitch, it.pitch, pose.pitch, iters);
+  CHECK(iters >= 1);
+  CHECK(std::fabs(it.pitch - pose.pitch) < 0.5f * std::fabs(bad.pitch - pose.pitch));  // moved back towards the optimum
+  CHECK(matches->getMemoryState() == cpu);  // origin state restored
+  std::printf("pose ok\n");
+  return 0;
+}
+
 int main(int argc, char** argv) {
   std::string mode = argc > 1 ? argv[1] : "typeinfo";
   try {
@@ -200,6 +249,7 @@ int main(int argc, char** argv) {
     if (mode == "pipeline3") return pipeline_mode(argv[2], 3);
     if (mode == "filter2") return filter_mode(argv[2], 2);
     if (mode == "filter3") return filter_mode(argv[2], 3);
+    if (mode == "pose") return pose_mode(argv[2]);
   } catch (std::exception& e) {
     std::fprintf(stderr, "exception: %s\n", e.what());
     return 3;

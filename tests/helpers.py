@@ -154,6 +154,15 @@ def oracle_match_dmatch(lib, mode, qid, q, tid, t, qcam, tproj, eps, delta, seed
     return out
 
 
+def oracle_match_match(lib, mode, qid, q, tid, t, qcam, tproj, eps, delta, seed, rel, absolute):
+    out = np.zeros(len(q), MATCH)
+    lib.oracle_match_match(ctypes.c_int(mode), ctypes.c_uint32(qid), ctypes.c_uint32(len(q)), P(q), ctypes.c_uint32(tid),
+                           ctypes.c_uint32(len(t)), P(t), P(qcam) if qcam is not None else None,
+                           P(tproj) if tproj is not None else None, ctypes.c_float(eps), ctypes.c_float(delta),
+                           P(seed) if seed is not None else None, ctypes.c_float(rel), ctypes.c_float(absolute), P(out))
+    return out
+
+
 def oracle_match_pairs(lib, mode, qid, q, tid, t, qcam, tproj, eps, delta, seed, rel, absolute):
     out = np.zeros(len(q), UINT2_PAIR)
     lib.oracle_match_pairs(ctypes.c_int(mode), ctypes.c_uint32(qid), ctypes.c_uint32(len(q)), P(q),
@@ -176,6 +185,46 @@ def oracle_merge(lib, num_features, pair_lists):
     lib.oracle_free(mm_p)
     lib.oracle_free(mem_p)
     return mm, mem
+
+
+def oracle_pose_terms(lib, matches, pose6, qcam, tcam):
+    pose = np.asarray(pose6, np.float32).copy()
+    jtj, jtf, cost = np.zeros(36, np.float32), np.zeros(6, np.float32), ctypes.c_float(0)
+    lib.oracle_pose_lm_terms(P(matches), ctypes.c_uint32(len(matches)), P(pose), P(qcam), P(tcam), P(jtj), P(jtf),
+                             ctypes.byref(cost))
+    return jtj.reshape(6, 6), jtf, float(cost.value)
+
+
+def oracle_pose_cost(lib, matches, pose6, qcam, tcam):
+    pose = np.asarray(pose6, np.float32).copy()
+    lib.oracle_pose_cost.restype = ctypes.c_float
+    return float(lib.oracle_pose_cost(P(matches), ctypes.c_uint32(len(matches)), P(pose), P(qcam), P(tcam)))
+
+
+def relative_pose(cams):
+    """Starting pose of PoseEstimator::LM_optimize / doPoseEstimation (src/Pipeline.cu:105-121, PoseEstimator.cu:323-329):
+    rotation of camera 1 relative to camera 0, position in the frame of camera 0 in units of 1000 km."""
+    def rot(a):
+        x, y, z = [float(v) for v in a]
+        cx, sx, cy, sy, cz, sz = np.cos(x), np.sin(x), np.cos(y), np.sin(y), np.cos(z), np.sin(z)
+        return np.array([[cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx],
+                         [sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx],
+                         [-sy, cy * sx, cy * cx]])
+    R0, R1 = rot(cams["cam_rot"][0]), rot(cams["cam_rot"][1])
+    rel = R0.T @ R1
+    x = np.arctan2(rel[2, 1], rel[2, 2])
+    y = np.arctan2(-rel[2, 0], rel[2, 2] / np.cos(x))
+    z = np.arctan2(rel[1, 0], rel[0, 0])
+    pos = R0.T @ (cams["cam_pos"][1].astype(np.float64) - cams["cam_pos"][0].astype(np.float64))
+    return np.array([x, y, z, pos[0] / 1000.0, pos[1] / 1000.0, pos[2] / 1000.0], np.float32)
+
+
+def matches_from_matchset(kp):
+    """2-view MatchSet key points (pairs) -> MATCH[]"""
+    m = np.zeros(len(kp) // 2, MATCH)
+    m["kp0_parent"], m["kp0_loc"] = kp["parentId"][0::2], kp["loc"][0::2]
+    m["kp1_parent"], m["kp1_loc"] = kp["parentId"][1::2], kp["loc"][1::2]
+    return m
 
 
 def oracle_bundles(lib, mm, kp, cams):

@@ -103,12 +103,13 @@ def test_absolute_threshold_and_seed_ratio(capi, oracle_lib):
                 assert_dmatch_equal(g, o)
             else:
                 assert np.array_equal(g["a"], o["a"]) and np.array_equal(g["b"], o["b"])
-    # Match output kind (no distance field)
-    g = run_gpu(capi, 0, q, t, capi.OUT_MATCH, absolute=absolute)
-    o = H.oracle_match_dmatch(oracle_lib, 0, 3, q, 7, t, None, None, 0, 0, None, REL, absolute)
-    assert np.array_equal(g["invalid"], o["invalid"])
-    ok = o["invalid"] == 0
-    assert np.array_equal(g["kp1_loc"][ok], o["kp1_loc"][ok])
+    # Match output kind (no distance field): the brute-force kernel compares with rel, not rel^2
+    for seed in (None, sd_o):
+        g = run_gpu(capi, 0, q, t, capi.OUT_MATCH, seed=seed, rel=0.97, absolute=absolute)
+        o = H.oracle_match_match(oracle_lib, 0, 3, q, 7, t, None, None, 0, 0, seed, 0.97, absolute)
+        assert np.array_equal(g["invalid"], o["invalid"])
+        ok = o["invalid"] == 0
+        assert np.array_equal(g["kp1_loc"][ok], o["kp1_loc"][ok]) and np.array_equal(g["kp0_loc"][ok], o["kp0_loc"][ok])
 
 
 def test_empty_target_set_and_seed_flt_max(capi):

@@ -200,3 +200,19 @@ def test_filter_stage_through_class_api_matches_fixture(tmp_path, views):
     diff = pts - gv["points1"]
     rms = float(np.sqrt((diff.astype(np.float64) ** 2).sum(1).mean()))
     assert rms <= (1e-4 if views == 2 else 2.5e-3), rms
+
+
+@pytest.mark.gpu
+def test_pose_estimator_lm_through_class_api(tmp_path):
+    """PoseEstimator::LM_optimize / LM_iteration (src/PoseEstimator.cu:314-515) over the fused HIP terms kernel, on the
+    reference's 2-view stage-0 MatchSet: stays at the cameras' relative pose, recovers from a 2 mrad pitch error."""
+    d = str(tmp_path)
+    info = typeinfo()
+    v = np.load(os.path.join(H.GOLDEN, "Pipeline2View.npz"))
+    gv = H.load_view("Pipeline2View")
+    for i in range(2):
+        open(os.path.join(d, "%d_N6ssrlcv5ImageE.cpimg" % i), "wb").write(v["cpimg_raw"][i].tobytes())
+    write_uty(os.path.join(d, "0_%s.uty" % info["KeyPoint"][0]), *info["KeyPoint"], 1, gv["kp0"])
+    write_uty(os.path.join(d, "0_%s.uty" % info["MultiMatch"][0]), *info["MultiMatch"], 1, gv["mm0"])
+    out = subprocess.check_output([build_binary(), "pose", d]).decode()
+    assert "pose ok" in out, out
