@@ -108,7 +108,8 @@ void oracle_epipolar_endpoints(const o_camera* qc, const o_float4* P, const o_fl
 }
 
 /* The scan + lane-0 reduction shared by every matcher kernel
- * (brute force: src/MatchFactory.cu:1462-1506, 2073-2125; double constrained: :2194-2291, :2824-2916). */
+ * (brute force: src/MatchFactory.cu:1462-1506, 2073-2125; double constrained: :2194-2291, :2824-2916; F-matrix
+ * constrained, mode 2: :1599-1657, :1710-1775 -- `targetP` then points at the 9 floats of the fundamental matrix). */
 void oracle_match_core(int mode, uint32_t nq, const o_feature* query, uint32_t nt, const o_feature* target,
                        const o_camera* queryCam, const o_float4* targetP, float epsilon, float delta,
                        float absoluteThreshold, int* best_index, float* best_dist) {
@@ -127,6 +128,13 @@ void oracle_match_core(int mode, uint32_t nq, const o_feature* query, uint32_t n
         slope = (left.y - right.y) / (left.x - right.x);
       }
     }
+    o_float3 epipolar = {0.0f, 0.0f, 0.0f};
+    if (mode == 2) {
+      const float* fundamental = (const float*)targetP;
+      epipolar.x = (fundamental[0] * query[q].loc.x) + (fundamental[1] * query[q].loc.y) + fundamental[2];
+      epipolar.y = (fundamental[3] * query[q].loc.x) + (fundamental[4] * query[q].loc.y) + fundamental[5];
+      epipolar.z = (fundamental[6] * query[q].loc.x) + (fundamental[7] * query[q].loc.y) + fundamental[8];
+    }
     float regEpsilon = epsilon;
     for (int l = 0; l < 32; ++l) {
       localMatch[l] = -1;
@@ -141,6 +149,11 @@ void oracle_match_core(int mode, uint32_t nq, const o_feature* query, uint32_t n
             y_line = slope * (target[f].loc.x - left.x) + left.y;
             if (fabsf(y_line - target[f].loc.y) > regEpsilon) continue;
           }
+        }
+        if (mode == 2) {
+          /* ax + by + c = 0 */
+          float p = -1 * ((epipolar.x * target[f].loc.x) + epipolar.z) / epipolar.y;
+          if (fabsf(target[f].loc.y - p) > regEpsilon) continue;
         }
         float d = oracle_dist_protocol(query[q].values, target[f].values, localDist[l]);
         if (localDist[l] > d) {
@@ -190,8 +203,8 @@ void oracle_match_dmatch(int mode, uint32_t queryID, uint32_t nq, const o_featur
   free(dist);
 }
 
-/* Match output (no distance field): matchFeaturesBruteForce :1659-1708 compares with relativeThreshold, the
- * double-constrained kernel :1777-1873 with its square. */
+/* Match output (no distance field): matchFeaturesBruteForce :1659-1708 and matchFeaturesConstrained
+ * :1710-1775 compare with relativeThreshold, the double-constrained kernel :1777-1873 with its square. */
 void oracle_match_match(int mode, uint32_t queryID, uint32_t nq, const o_feature* query, uint32_t targetID, uint32_t nt,
                         const o_feature* target, const o_camera* queryCam, const o_float4* targetP, float epsilon,
                         float delta, const float* seedDistances, float relativeThreshold, float absoluteThreshold,
@@ -199,7 +212,7 @@ void oracle_match_match(int mode, uint32_t queryID, uint32_t nq, const o_feature
   int* idx = (int*)malloc(sizeof(int) * (nq ? nq : 1));
   float* dist = (float*)malloc(sizeof(float) * (nq ? nq : 1));
   oracle_match_core(mode, nq, query, nt, target, queryCam, targetP, epsilon, delta, absoluteThreshold, idx, dist);
-  const float limit = mode == 0 ? relativeThreshold : relativeThreshold * relativeThreshold;
+  const float limit = mode == 1 ? relativeThreshold * relativeThreshold : relativeThreshold;
   for (uint32_t q = 0; q < nq; ++q) {
     o_match m;
     memset(&m, 0, sizeof m);

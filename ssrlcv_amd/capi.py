@@ -64,10 +64,11 @@ class MatchParams(ctypes.Structure):
     _fields_ = [("mode", c_int), ("queryImageID", c_u32), ("targetImageID", c_u32), ("epsilon", c_f32),
                 ("delta", c_f32), ("relativeThreshold", c_f32), ("absoluteThreshold", c_f32),
                 ("pad0", c_u32),  # ssrlcv_camera is 8-byte aligned
-                ("queryCamera", ctypes.c_uint8 * 80), ("targetProjection", c_f32 * 12)]
+                ("queryCamera", ctypes.c_uint8 * 80), ("targetProjection", c_f32 * 12), ("fundamental", c_f32 * 9),
+                ("pad1", c_u32 * 3)]  # the float4 member makes the struct 16-byte aligned
 
 
-assert ctypes.sizeof(MatchParams) == 32 + 80 + 48, ctypes.sizeof(MatchParams)
+assert ctypes.sizeof(MatchParams) == 32 + 80 + 48 + 48, ctypes.sizeof(MatchParams)
 
 
 class SiftParams(ctypes.Structure):
@@ -163,7 +164,7 @@ def seed_distances(query_d, nq, seed_d, ns, workspace=None):
 
 
 def make_match_params(mode, query_id, target_id, epsilon=0.0, delta=0.0, rel=0.0, absolute=0.0, query_camera=None,
-                      target_projection=None):
+                      target_projection=None, fundamental=None):
     p = MatchParams()
     p.mode, p.queryImageID, p.targetImageID = mode, query_id, target_id
     p.epsilon, p.delta, p.relativeThreshold, p.absoluteThreshold = epsilon, delta, rel, absolute
@@ -173,6 +174,9 @@ def make_match_params(mode, query_id, target_id, epsilon=0.0, delta=0.0, rel=0.0
     if target_projection is not None:
         tp = np.ascontiguousarray(target_projection, dtype=np.float32).reshape(-1)
         ctypes.memmove(p.targetProjection, tp.ctypes.data, 48)
+    if fundamental is not None:
+        f9 = np.ascontiguousarray(fundamental, dtype=np.float32).reshape(-1)
+        ctypes.memmove(p.fundamental, f9.ctypes.data, 36)
     return p
 
 

@@ -50,7 +50,7 @@ constexpr int kWaves = 4;        // waves per block
 constexpr int kQPerBlock = kWaves * kQT * 32;  // 512 queries per block
 constexpr unsigned long long kNoKey = ~0ull;
 
-struct Geom {  // per-query epipolar segment parameters (mode 1)
+struct Geom {  // per-query epipolar segment parameters (mode 1); mode 2 keeps the line (a, b, c) in lo_x, hi_x, left_x
   float lo_x, hi_x;       // left.x - eps, right.x + eps
   float left_x, left_y;
   float slope;
@@ -169,7 +169,25 @@ __global__ __launch_bounds__(256) void k_geom(const ssrlcv_sift_feature* __restr
   geom[q] = g;
 }
 
-__device__ __forceinline__ bool passes_prefilter(const Geom& g, ssrlcv_float2 t, float epsilon) {
+// matchFeaturesConstrained's epipolar line of a query (src/MatchFactory.cu:1722-1724)
+__global__ __launch_bounds__(256) void k_geom_fundamental(const ssrlcv_sift_feature* __restrict__ query, uint32_t nq,
+                                                          const float* __restrict__ F9, Geom* __restrict__ geom) {
+  uint32_t q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= nq) return;
+  ssrlcv_float2 loc = query[q].loc;
+  Geom g;
+  g.lo_x = (F9[0] * loc.x) + (F9[1] * loc.y) + F9[2];
+  g.hi_x = (F9[3] * loc.x) + (F9[4] * loc.y) + F9[5];
+  g.left_x = (F9[6] * loc.x) + (F9[7] * loc.y) + F9[8];
+  g.left_y = g.slope = g.top = g.bottom = g.vertical = 0.0f;
+  geom[q] = g;
+}
+
+__device__ __forceinline__ bool passes_prefilter(const Geom& g, ssrlcv_float2 t, float epsilon, int mode) {
+  if (mode == 2) {  // src/MatchFactory.cu:1735-1737: ax + by + c = 0
+    float p = -1 * ((g.lo_x * t.x) + g.left_x) / g.hi_x;
+    return !(fabsf(t.y - p) > epsilon);
+  }
   // src/MatchFactory.cu:2239-2254
   if (t.x < g.lo_x || t.x > g.hi_x) return false;
   if (g.vertical != 0.0f) {
@@ -234,7 +252,7 @@ __global__ __launch_bounds__(256, SSRLCV_MATCH_WPS) void k_match(const _Float16*
     if (__any(m <= bestAcc[qt])) {
       // slow path: decode rows.  C/D layout of the 32x32 MFMA: row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
       Geom g;
-      if (mode == 1) g = geom[qbase + qt * 32 + col];
+      if (mode != 0) g = geom[qbase + qt * 32 + col];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = acc[r];
@@ -242,7 +260,7 @@ __global__ __launch_bounds__(256, SSRLCV_MATCH_WPS) void k_match(const _Float16*
           uint32_t f = tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kgrp;
           float d = na[qt] + v;  // exact integer
           bool ok = (f < nt) && (d < absThreshold);
-          if (ok && mode == 1) ok = passes_prefilter(g, locT[f], epsilon);
+          if (ok && mode != 0) ok = passes_prefilter(g, locT[f], epsilon, mode);
           if (ok) {
             unsigned long long k = make_key(d, f);
             if (k < key[qt]) {
@@ -337,8 +355,8 @@ __global__ __launch_bounds__(256) void k_finalize(const unsigned long long* __re
   m.distance = dist;
   if (dist >= absThreshold || matchIndex == -1) {
     m.invalid = 1;
-  } else if (seedDistances && (dist / seedDistances[q] > ((outKind == SSRLCV_OUT_MATCH && mode == 0) ? rel : rel * rel))) {
-    m.invalid = 1;  // rel^2 everywhere except the brute-force Match kernel (src/MatchFactory.cu:1695)
+  } else if (seedDistances && (dist / seedDistances[q] > ((outKind == SSRLCV_OUT_MATCH && mode != 1) ? rel : rel * rel))) {
+    m.invalid = 1;  // rel^2 except in the brute-force / F-matrix Match kernels (src/MatchFactory.cu:1695, :1762)
   } else {
     m.invalid = 0;
     m.keyPoints[0].loc = query[q].loc;
@@ -407,6 +425,12 @@ int run_match(const ssrlcv_sift_feature* query, uint32_t nq, const ssrlcv_sift_f
     hipLaunchKernelGGL(k_geom, dim3((nq + 255) / 256), dim3(256), 0, st, query, nq, p->queryCamera,
                        p->targetProjection[0], p->targetProjection[1], p->targetProjection[2], p->epsilon, p->delta, geom);
   }
+  if (mode == 2) {
+    eps = p->epsilon;
+    float* F9 = (float*)(ws + L.off_scratch);
+    SSRLCV_HIP_TRY(hipMemcpyAsync(F9, p->fundamental, 9 * sizeof(float), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_geom_fundamental, dim3((nq + 255) / 256), dim3(256), 0, st, query, nq, F9, geom);
+  }
   uint32_t qblocks = L.nq_pad / kQPerBlock;
   uint32_t numTiles = L.nt_pad / 32;
   // split the target range until the grid has >= 1024 blocks (4 per CU) or tiles run out
@@ -447,7 +471,7 @@ int ssrlcv_hip_match_u8x128(const ssrlcv_sift_feature* query, uint32_t numQuery,
                             uint32_t numTarget, const float* seedDistances, const ssrlcv_match_params* params_host,
                             int outKind, void* out, void* workspace, size_t workspaceBytes, ssrlcv_stream_t stream) {
   if (!query || !out || !workspace || !params_host || (numTarget && !target)) return SSRLCV_ERR_INVALID_ARG;
-  if (outKind < 0 || outKind > 2 || params_host->mode < 0 || params_host->mode > 1) return SSRLCV_ERR_INVALID_ARG;
+  if (outKind < 0 || outKind > 2 || params_host->mode < 0 || params_host->mode > 2) return SSRLCV_ERR_INVALID_ARG;
   if (numQuery == 0) return SSRLCV_OK;
   Layout L = make_layout(numQuery, numTarget);
   if (workspaceBytes < L.total) return SSRLCV_ERR_WORKSPACE;

@@ -1,7 +1,7 @@
 // ssrlcv_amd/host/MatchFactory.hpp -- MatchFactory<T> with the reference's signatures (include/MatchFactory.cuh:23-309),
 // bound to the fp16-MFMA matcher of the HIP C ABI.  Provided for T = SIFT_Descriptor (the pipeline's only
-// instantiation, src/Pipeline.cu:175); Window_* descriptors, FeatureMatch outputs, the F-matrix constrained matcher,
-// disparity matchers and match-file IO are out of scope.
+// instantiation, src/Pipeline.cu:175); Window_* descriptors, FeatureMatch outputs, disparity matchers and match-file
+// IO are out of scope.
 //
 // Every method keeps upstream's memory-state contract: inputs are moved to the gpu for the call and restored to their
 // origin state before returning; results are fresh Unity objects on the gpu holding only the valid matches
@@ -58,7 +58,7 @@ class MatchFactory {
   template <typename OUT>
   ptr::value<Unity<OUT>> run(int mode, int outKind, ptr::value<Image> query, ptr::value<Unity<Feature<T>>> queryFeatures,
                              ptr::value<Image> target, ptr::value<Unity<Feature<T>>> targetFeatures, float epsilon,
-                             float delta, ptr::value<Unity<float>> seedDistances) {
+                             float delta, ptr::value<Unity<float>> seedDistances, const float* fundamental = nullptr) {
     static_assert(std::is_same<T, SIFT_Descriptor>::value, "MatchFactory is provided for SIFT_Descriptor");
     MemoryState origin[2] = {queryFeatures->getMemoryState(), targetFeatures->getMemoryState()};
     if (origin[0] != gpu) queryFeatures->setMemoryState(gpu);
@@ -76,6 +76,7 @@ class MatchFactory {
       seed_d = seedDistances->device.get();
     }
     ssrlcv_match_params p = make_params(mode, query, target, epsilon, delta, relativeThreshold, absoluteThreshold);
+    if (fundamental) std::memcpy(p.fundamental, fundamental, sizeof p.fundamental);
     size_t wsBytes = ssrlcv_hip_match_workspace_bytes(nq, nt);
     ptr::device<unsigned char> ws((long)wsBytes);
     ptr::value<Unity<OUT>> matches(nullptr, (unsigned long)nq, gpu);
@@ -164,6 +165,27 @@ class MatchFactory {
                                                             float epsilon, float delta,
                                                             ptr::value<Unity<float>> seedDistances = nullptr) {
     return run<Match>(1, SSRLCV_OUT_MATCH, query, queryFeatures, target, targetFeatures, epsilon, delta, seedDistances);
+  }
+
+  // F-matrix constrained (src/MatchFactory.cu:397-445, :549-597, :802-850): candidates within epsilon px of the
+  // epipolar line F (x, y, 1) of the query feature
+  ptr::value<Unity<Match>> generateMatchesConstrained(ptr::value<Image> query, ptr::value<Unity<Feature<T>>> queryFeatures,
+                                                      ptr::value<Image> target, ptr::value<Unity<Feature<T>>> targetFeatures,
+                                                      float epsilon, float fundamental[3][3],
+                                                      ptr::value<Unity<float>> seedDistances = nullptr) {
+    return run<Match>(2, SSRLCV_OUT_MATCH, query, queryFeatures, target, targetFeatures, epsilon, 0.0f, seedDistances, &fundamental[0][0]);
+  }
+  ptr::value<Unity<DMatch>> generateDistanceMatchesConstrained(ptr::value<Image> query, ptr::value<Unity<Feature<T>>> queryFeatures,
+                                                               ptr::value<Image> target, ptr::value<Unity<Feature<T>>> targetFeatures,
+                                                               float epsilon, float fundamental[3][3],
+                                                               ptr::value<Unity<float>> seedDistances = nullptr) {
+    return run<DMatch>(2, SSRLCV_OUT_DMATCH, query, queryFeatures, target, targetFeatures, epsilon, 0.0f, seedDistances, &fundamental[0][0]);
+  }
+  ptr::value<Unity<uint2_pair>> generateMatchesConstrainedIndexOnly(ptr::value<Image> query, ptr::value<Unity<Feature<T>>> queryFeatures,
+                                                                    ptr::value<Image> target, ptr::value<Unity<Feature<T>>> targetFeatures,
+                                                                    float epsilon, float fundamental[3][3],
+                                                                    ptr::value<Unity<float>> seedDistances = nullptr) {
+    return run<uint2_pair>(2, SSRLCV_OUT_UINT2_PAIR, query, queryFeatures, target, targetFeatures, epsilon, 0.0f, seedDistances, &fundamental[0][0]);
   }
 
   // convertMatchToRaw (src/MatchFactory.cu:257-280, :2921-2926): slice the DMatch base

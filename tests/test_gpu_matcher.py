@@ -134,6 +134,38 @@ def test_double_constrained_matches_oracle(capi, oracle_lib):
     assert 0 < (o["invalid"] == 0).sum()
 
 
+def test_fundamental_constrained_matches_oracle(capi, oracle_lib):
+    """matchFeaturesConstrained (src/MatchFactory.cu:1599-1657, :1710-1775, :1921-1980, :2127-2193, :2572-2626,
+    :2762-2823): candidates within epsilon px of the epipolar line F (x, y, 1); all three output kinds with their
+    ratio rules (Match and uint2_pair vs rel, DMatch vs rel^2)."""
+    q = random_features(2000, 23, hi=48)
+    t = random_features(3000, 24, hi=48)
+    s = random_features(300, 25, hi=48)
+    # a plausible F: rectified pair rotated by a few degrees (lines of moderate slope through the image)
+    F = np.array([[0.0, -1e-4, 0.02], [1e-4, 0.0, -0.9], [-0.03, 1.0, 40.0]], np.float32)
+    sd = H.oracle_seed_distances(oracle_lib, q, s)
+    for eps in (3.0, 40.0, 800.0):
+        for kind, orc in ((capi.OUT_DMATCH, H.oracle_match_dmatch), (capi.OUT_UINT2_PAIR, H.oracle_match_pairs),
+                          (capi.OUT_MATCH, H.oracle_match_match)):
+            for seed in (None, sd):
+                params = capi.make_match_params(2, 3, 7, eps, 0.0, 0.9, 3e7, fundamental=F)
+                out_d = capi.match(capi.to_dev(q), len(q), capi.to_dev(t), len(t), params, kind,
+                                   seed_d=capi.to_dev(seed) if seed is not None else None)
+                dt = {capi.OUT_DMATCH: H.DMATCH, capi.OUT_UINT2_PAIR: H.UINT2_PAIR, capi.OUT_MATCH: H.MATCH}[kind]
+                g = capi.to_host(out_d, dt, len(q))
+                o = orc(oracle_lib, 2, 3, q, 7, t, None, F.reshape(-1), eps, 0.0, seed, 0.9, 3e7)
+                if kind == capi.OUT_DMATCH:
+                    assert_dmatch_equal(g, o)
+                elif kind == capi.OUT_UINT2_PAIR:
+                    assert np.array_equal(g["a"], o["a"]) and np.array_equal(g["b"], o["b"])
+                else:
+                    assert np.array_equal(g["invalid"], o["invalid"])
+                    ok = o["invalid"] == 0
+                    assert np.array_equal(g["kp1_loc"][ok], o["kp1_loc"][ok])
+        if eps == 3.0:
+            assert 0 < (o["invalid"] == 0).sum() < len(q)  # the constraint bites
+
+
 def test_compact_matches_is_stable(capi):
     q, t = random_features(5000, 15, hi=64), random_features(800, 16, hi=64)
     probe = run_gpu(capi, 0, q, t, capi.OUT_DMATCH, absolute=3e7)
