@@ -258,15 +258,20 @@ __global__ __launch_bounds__(kTX) void k_gauss_fused(ConvArgs a) {
 // ---- S4 on the matrix cores ----------------------------------------------------------------------------------------------
 // The two 1-D passes as banded-Toeplitz products on v_mfma_f32_16x16x4_f32.  An f32 MFMA is bit-for-bit a k-ordered
 // fmaf chain (one rounding per product-add), so D[i][j] = sum_kk A[i][kk] * T[kk][j] with T[kk][j] = w[kk - j]
-// (0 outside the band: fmaf(x, 0, acc) == acc) is exactly the reference's `sum += p * k` loop in its tap order.  Plain
-// v_fma_f32 peaks at 75 TFLOP/s on MI355X (tools/valu_rate.hip); the f32 MFMA pipe delivers 2x that per SIMD, and
-// the band fills 65/80 of a 16-wide tile at R = 32.
+// (0 outside the band: fmaf(x, 0, acc) == acc) is exactly the reference's `sum += p * k` loop in its tap order.  The
+// f32 MFMA pipe issues 32 FMA per cycle per SIMD against ~14 of the VALU formulation (tools/valu_rate.hip), and the
+// band fills 65/80 of a 16-wide tile at R = 32.
 //   horizontal: D[16 rows][16 cols] = In[16 rows][16+2R cols] x T      A from the LDS row stage, B = per-lane constants
 //   vertical  : D[16 rows][16 cols] = T^T[16 rows][16+2R] x H[16+2R rows][16 cols]   A = constants, B from the LDS ring
-// A block owns a 256-column strip and marches down 16 rows per step; each wave owns 4 of the 16 column tiles.
+// A block owns a 256-column strip and marches down 16 rows per step.  It has 8 waves in two roles, one wave of each
+// per SIMD: four waves stage the input rows and run the horizontal pass of step `it` (4 of the 16 column tiles each),
+// the other four run the vertical pass of step `it - 1` from the ring of H rows and store the result.  With a single role
+// per SIMD the matrix pipe sat idle 53 % of the time behind staging, address arithmetic, stores and barriers (PMC:
+// SQ_VALU_MFMA_BUSY_CYCLES); with two, each wave's non-MFMA work runs under the other wave's MFMAs.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kMT = 16;  // rows per marching step of the MFMA kernel
+constexpr int kMT = 16;            // rows per marching step of the MFMA kernel
+constexpr int kMfmaThreads = 512;  // 4 horizontal-pass waves + 4 vertical-pass waves
 
 template <int R>
 struct MfmaCfg {
@@ -278,25 +283,30 @@ struct MfmaCfg {
   // (16 rows x 2 columns per 32-lane half) are bank-conflict free
   static constexpr int SWmin = kTX + 2 * RP + (KP - K) + 4;
   static constexpr int SW = (SWmin + 29) / 32 * 32 + 2;
-  static constexpr int RINGROWS = (2 * R + kMT + kMT - 1) / kMT * kMT;
+  // ring of H rows: the vertical pass of step it-1 reads rows 16(it-1)-2R .. 16 it - 1 while the horizontal pass of
+  // step it writes rows 16 it .. 16 it + 15
+  static constexpr int RINGROWS = (2 * R + 2 * kMT + kMT - 1) / kMT * kMT;
   static constexpr int RSTR = kTX + 16;           // ring row stride (== 16 mod 32: B reads conflict free)
   static constexpr int TOT = kMT * SW;
-  static constexpr int STG = (TOT + kTX - 1) / kTX;
-  static constexpr size_t ldsBytes = sizeof(float) * ((size_t)kMT * SW + (size_t)RINGROWS * RSTR);
+  static constexpr int STG = (TOT + kTX - 1) / kTX;  // staged elements per horizontal-role thread
+  static constexpr size_t ldsBytes = sizeof(float) * ((size_t)2 * kMT * SW + (size_t)RINGROWS * RSTR);
 };
 
 template <int R>
-__global__ __launch_bounds__(kTX) void k_gauss_mfma(ConvArgs a) {
+__global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma(ConvArgs a) {
   using C = MfmaCfg<R>;
   extern __shared__ __attribute__((aligned(16))) float s_mem[];
-  float* s_in = s_mem;                         // [kMT][SW]
-  float* s_ring = s_mem + kMT * C::SW;         // [RINGROWS][RSTR]
+  float* s_ring = s_mem + 2 * kMT * C::SW;     // [RINGROWS][RSTR]; the two row stages [kMT][SW] sit in front
   const int W = (int)a.w, H = (int)a.h;
   const int x0 = blockIdx.x * kTX;
   const int y0 = blockIdx.y * (int)a.rowsPerBlock;
   int nrows = (int)a.rowsPerBlock;
   if (y0 + nrows > H) nrows = H - y0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // One wave of each role per SIMD, whichever way the hardware deals the 8 waves of a workgroup onto the 4 SIMDs
+  // (w % 4 or w / 2): roles differ within the pairs (w, w + 4) and (2k, 2k + 1).  Measured: with both roles on the same
+  // SIMD pair nothing overlapped (time = staging skeleton + MFMA time).
+  const int role = (wave ^ (wave >> 2)) & 1, w4 = wave >> 1, htid = w4 * 64 + lane;
   const int li = lane & 15, lk = lane >> 4;
 
   // per-lane Toeplitz constants: tz[s] = w[4s + lk - li] (0 outside 0..2R); w is symmetric, R+1 taps in the kernarg
@@ -307,24 +317,34 @@ __global__ __launch_bounds__(kTX) void k_gauss_mfma(ConvArgs a) {
     int ti = t <= R ? t : 2 * R - t;
     tz[s] = (t >= 0 && t <= 2 * R) ? a.wgt[ti < 0 ? 0 : ti] : 0.0f;
   }
-  // zero the ring and the stage once: band zeros multiply whatever sits there, it must be finite
-  for (int i = tid; i < C::RINGROWS * C::RSTR; i += kTX) s_ring[i] = 0.0f;
-  for (int i = tid; i < kMT * C::SW; i += kTX) s_in[i] = 0.0f;
-
-  int gxs[C::STG], rws[C::STG], cls[C::STG];
+  // The per-lane index turns the a.wgt reads into global loads.  Pin their completion here: otherwise the compiler's
+  // s_waitcnt pass, which only knows "tz may still be in flight" at the loop header, waits inside the MFMA loops with a
+  // vmcnt that also drains the row prefetch issued one iteration earlier (vmcnt is in order) -- measured: the matrix
+  // pipe idle 46 % of the time behind HBM latency.
 #pragma unroll
-  for (int e = 0; e < C::STG; ++e) {
-    int idx = e * kTX + tid;
-    int r = idx / C::SW, c = idx - r * C::SW;
-    int x = x0 - C::RP + c;
-    x = x > W - 1 + R ? W - 1 + R : x;
-    x = x < 0 ? -1 - x : x;
-    x = x > W - 1 ? 2 * W - 1 - x : x;
-    gxs[e] = x;
-    rws[e] = r;
-    cls[e] = c;
-  }
+  for (int s = 0; s < C::KS; ++s) asm volatile("" : "+v"(tz[s]));
+  // zero the ring and the stages once: band zeros multiply whatever sits there, it must be finite
+  for (int i = tid; i < (int)(C::ldsBytes / sizeof(float)); i += kMfmaThreads) s_mem[i] = 0.0f;
+
+  // ---- horizontal role: staging state.  Element e of this thread is float e*256 + htid of the [kMT][SW] tile; its
+  // column never changes.  Coordinates are clamped/mirrored into the image, so every load is unconditional: padding
+  // columns and the elements past the tile (dropped at the LDS store) re-read a valid pixel, their weight is 0.
+  int gxs[C::STG], rws[C::STG];
   float pre[C::STG];
+  if (role == 0) {
+#pragma unroll
+    for (int e = 0; e < C::STG; ++e) {
+      int idx = e * kTX + htid;
+      idx = idx < C::TOT ? idx : C::TOT - 1;
+      int r = idx / C::SW, c = idx - r * C::SW;
+      int x = x0 - C::RP + c;
+      x = x > W - 1 + R ? W - 1 + R : x;
+      x = x < 0 ? -1 - x : x;                 // sym_coord for -l <= i < 0
+      x = x > W - 1 ? 2 * W - 1 - x : x;      // sym_coord for l <= i < 2l
+      gxs[e] = x;
+      rws[e] = r;
+    }
+  }
   auto fetch = [&](int s) {
     const int ybase = y0 - R + s * kMT;
 #pragma unroll
@@ -333,90 +353,125 @@ __global__ __launch_bounds__(kTX) void k_gauss_mfma(ConvArgs a) {
       y = y > H - 1 + R ? H - 1 + R : y;
       y = y < 0 ? -1 - y : y;
       y = y > H - 1 ? 2 * H - 1 - y : y;
-      bool in = ((e + 1) * kTX <= C::TOT || e * kTX + tid < C::TOT) && cls[e] < kTX + 2 * C::RP;
-      pre[e] = in ? a.in[(size_t)y * W + gxs[e]] : 0.0f;
+      pre[e] = a.in[(size_t)y * W + gxs[e]];
     }
   };
-  float mn = FLT_MAX, mx = -FLT_MAX;
-  const int steps = (nrows + 2 * R + kMT - 1) / kMT;
-  fetch(0);
-  __syncthreads();
-  for (int s = 0; s < steps; ++s) {
+  auto stage_write = [&](int buf) {
+    float* s_in = s_mem + buf * kMT * C::SW;
 #pragma unroll
     for (int e = 0; e < C::STG; ++e)
-      if ((e + 1) * kTX <= C::TOT || e * kTX + tid < C::TOT) s_in[e * kTX + tid] = pre[e];
-    __syncthreads();
-    if (s + 1 < steps) fetch(s + 1);
-    // ---- horizontal pass: H rows 16s .. 16s+15 of this strip into the ring
-    const int slot0 = (s * kMT) % C::RINGROWS;
-    {
-      // the wave's four column tiles run as four independent accumulation chains (a dependent f32 MFMA chain issues
-      // every 40 cycles, independent ones every 32) and their LDS reads are batched ahead of the MFMAs
-      const float* arow = s_in + li * C::SW + (wave * 4) * 16 + (C::RP - R) + lk;
-      f32x4 acc[4];
+      if ((e + 1) * kTX <= C::TOT || e * kTX + htid < C::TOT) s_in[e * kTX + htid] = pre[e];
+  };
+  float mn = FLT_MAX, mx = -FLT_MAX;
+  // vertical role: the accumulators of the last vertical pass, stored one iteration later
+  constexpr int kNoPending = -(1 << 30);
+  f32x4 pend[4];
+  int pendJ = kNoPending;
+  auto store_pending = [&]() {
+    const int jbase = pendJ;
+    const bool whole = jbase >= 0 && jbase + kMT <= nrows && x0 + kTX <= W;  // wave-uniform
 #pragma unroll
-      for (int t4 = 0; t4 < 4; ++t4) acc[t4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int t4 = 0; t4 < 4; ++t4) {
+      const int gx = x0 + (w4 * 4 + t4) * 16 + li;
+      float* orow = a.out + ((long)(y0 + jbase + lk * 4) * W + gx);
 #pragma unroll
-      for (int ks = 0; ks < C::KS; ++ks) {
-        float av[4];
-#pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) av[t4] = arow[t4 * 16 + 4 * ks];
-#pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) acc[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4], tz[ks], acc[t4], 0, 0, 0);
-      }
-      // D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
-#pragma unroll
-      for (int t4 = 0; t4 < 4; ++t4) {
-        float* dst = s_ring + (size_t)(slot0 + lk * 4) * C::RSTR + (wave * 4 + t4) * 16 + li;
-        dst[0] = acc[t4][0];
-        dst[C::RSTR] = acc[t4][1];
-        dst[2 * C::RSTR] = acc[t4][2];
-        dst[3 * C::RSTR] = acc[t4][3];
-      }
-    }
-    __syncthreads();
-    // ---- vertical pass: output rows j = 16s - 2R + ii, ii = 0..15; B row kk is H row 16s - 2R + kk
-    const int jbase = s * kMT - 2 * R;
-    if (jbase + kMT > 0 && jbase < nrows) {
-      int hslot[C::KS];
-#pragma unroll
-      for (int ks = 0; ks < C::KS; ++ks) {
-        int kk = 4 * ks + lk;
-        kk = kk > C::K - 1 ? C::K - 1 : kk;               // padded k-steps re-read a valid row (their weight is 0)
-        int hidx = jbase + kk;                            // H row index (>= -2R)
-        hslot[ks] = ((hidx % C::RINGROWS) + C::RINGROWS) % C::RINGROWS;
-      }
-      f32x4 acc[4];
-#pragma unroll
-      for (int t4 = 0; t4 < 4; ++t4) acc[t4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-      for (int ks = 0; ks < C::KS; ++ks) {
-        const float* brow = s_ring + (size_t)hslot[ks] * C::RSTR + (wave * 4) * 16 + li;
-        float bv[4];
-#pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) bv[t4] = brow[t4 * 16];
-#pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) acc[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(tz[ks], bv[t4], acc[t4], 0, 0, 0);
-      }
-#pragma unroll
-      for (int t4 = 0; t4 < 4; ++t4) {
-        const int gx = x0 + (wave * 4 + t4) * 16 + li;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int j = jbase + lk * 4 + r;
-          if (j >= 0 && j < nrows && gx < W) {
-            float v = acc[t4][r];
-            a.out[(size_t)(y0 + j) * W + gx] = v;
-            mn = fminf(mn, v);
-            mx = fmaxf(mx, v);
-          }
+      for (int r = 0; r < 4; ++r) {
+        const int j = jbase + lk * 4 + r;
+        if (whole || (j >= 0 && j < nrows && gx < W)) {
+          const float v = pend[t4][r];
+          orow[(long)r * W] = v;
+          mn = fminf(mn, v);
+          mx = fmaxf(mx, v);
         }
       }
     }
-    // no barrier needed here: the next iteration's stage write is followed by one, and the ring is only rewritten
-    // after it
+    pendJ = kNoPending;
+  };
+  const int steps = (nrows + 2 * R + kMT - 1) / kMT;
+  if (role == 0) fetch(0);
+  __syncthreads();  // zero fill complete
+  if (role == 0) {
+    stage_write(0);
+    if (steps > 1) fetch(1);
   }
   __syncthreads();
+  for (int it = 0; it <= steps; ++it) {
+    if (role == 0) {
+      if (it < steps) {
+        // ---- horizontal pass: H rows 16 it .. 16 it + 15 of this strip into the ring.  The wave's four column tiles
+        // are four independent accumulation chains; the A operands of k-step ks+1 are read under the MFMAs of ks.
+        const float* arow = s_mem + (it & 1) * kMT * C::SW + li * C::SW + (w4 * 4) * 16 + (C::RP - R) + lk;
+        f32x4 acc[4];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) acc[t4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        float av[2][4];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) av[0][t4] = arow[t4 * 16];
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+          if (ks + 1 < C::KS) {
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) av[(ks + 1) & 1][t4] = arow[t4 * 16 + 4 * (ks + 1)];
+          }
+          __builtin_amdgcn_sched_barrier(0);  // keep the reads of the next k-step ahead of this k-step's MFMAs
+#pragma unroll
+          for (int t4 = 0; t4 < 4; ++t4) acc[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks & 1][t4], tz[ks], acc[t4], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+        const int slot0 = (it * kMT) % C::RINGROWS;
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+          float* dst = s_ring + (size_t)(slot0 + lk * 4) * C::RSTR + (w4 * 4 + t4) * 16 + li;
+          dst[0] = acc[t4][0];
+          dst[C::RSTR] = acc[t4][1];
+          dst[2 * C::RSTR] = acc[t4][2];
+          dst[3 * C::RSTR] = acc[t4][3];
+        }
+        // next step's rows into the other stage (last read one iteration ago), the step after that into registers
+        if (it + 1 < steps) {
+          stage_write((it + 1) & 1);
+          if (it + 2 < steps) fetch(it + 2);
+        }
+      }
+    } else {
+      // ---- vertical role.  The result of the previous iteration is stored first: its VALU / store work then runs
+      // while the horizontal waves occupy the matrix pipe, and this wave's MFMAs run while they stage the next rows
+      // (with both roles doing MFMAs first and bookkeeping second, neither overlapped anything).
+      if (pendJ != kNoPending) store_pending();
+      // vertical pass of step it - 1: output rows j = jbase + ii, ii = 0..15; B row kk is H row jbase + kk
+      const int jbase = (it - 1) * kMT - 2 * R;
+      if (it >= 1 && jbase + kMT > 0 && jbase < nrows) {
+        // ring slot of H row jbase + kk: one wrap at most (K <= RINGROWS)
+        const int base = ((jbase % C::RINGROWS) + C::RINGROWS) % C::RINGROWS;  // wave-uniform
+        const float* colp = s_ring + (w4 * 4) * 16 + li;
+        auto loadB = [&](int ks, float (&dst)[4]) {
+          int kk = 4 * ks + lk;
+          kk = kk > C::K - 1 ? C::K - 1 : kk;             // padded k-steps re-read a valid row (their weight is 0)
+          int slot = base + kk;
+          slot = slot >= C::RINGROWS ? slot - C::RINGROWS : slot;
+          const float* brow = colp + slot * C::RSTR;
+#pragma unroll
+          for (int t4 = 0; t4 < 4; ++t4) dst[t4] = brow[t4 * 16];
+        };
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) pend[t4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        float bv[2][4];
+        loadB(0, bv[0]);
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+          if (ks + 1 < C::KS) loadB(ks + 1, bv[(ks + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t4 = 0; t4 < 4; ++t4) pend[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(tz[ks], bv[ks & 1][t4], pend[t4], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        pendJ = jbase;
+      }
+    }
+    __syncthreads();
+  }
+  if (role == 1 && pendJ != kNoPending) store_pending();
   if (a.minmax) block_minmax_commit(mn, mx, a.minmax, s_mem);
 }
 
@@ -535,9 +590,12 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
   rows = (rows + kNR - 1) / kNR * kNR;
   a.rowsPerBlock = rows;
   dim3 grid(bx, (h + rows - 1) / rows);
-  // The f32-MFMA banded-Toeplitz variant is bit-identical but measured no faster than the VALU marching kernel on
-  // MI355X (8192^2: 0.19-0.43 ms vs 0.15-0.38 ms per level), so it stays an opt-in (SSRLCV_GAUSS_MFMA=1).
-  static const bool useMfma = getenv("SSRLCV_GAUSS_MFMA") != nullptr;
+  // Two bit-identical formulations.  Measured per 8192^2 level on MI355X (ms, taps 13/17/23/33/47/65): VALU marching
+  // kernel 0.148/0.156/0.251/0.239/0.370/0.382, f32-MFMA banded Toeplitz 0.202/0.188/0.217/0.238/0.275/0.312 -- the band
+  // wastes (16 + 2R - taps) / (16 + 2R) of the matrix pipe, more than half at R = 6.  Default: MFMA from 23 taps up.
+  // SSRLCV_GAUSS_VALU=1 / SSRLCV_GAUSS_MFMA=1 force one of them for every radius.
+  static const bool forceValu = getenv("SSRLCV_GAUSS_VALU") != nullptr, forceMfma = getenv("SSRLCV_GAUSS_MFMA") != nullptr;
+  const bool useMfma = forceMfma || (!forceValu && RT >= 11);
   if (!useMfma) {
     switch (RT) {
       case 6: hipLaunchKernelGGL(k_gauss_fused<6>, grid, dim3(kTX), 0, st, a); break;
@@ -548,18 +606,29 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
       default: hipLaunchKernelGGL(k_gauss_fused<32>, grid, dim3(kTX), 0, st, a); break;
     }
   } else {
-    rows = (rows + kMT - 1) / kMT * kMT;
-    a.rowsPerBlock = rows;
-    grid = dim3(bx, (h + rows - 1) / rows);
+    // one or two blocks are resident per CU (LDS): size the strips so that the launch is about one round of them;
+    // 16-row steps, at least 4 steps of payload per 2R halo
 #define SSRLCV_LAUNCH_MFMA(RR)                                                                                   \
   do {                                                                                                            \
-    static bool attr = false;                                                                                     \
-    if (!attr) {                                                                                                  \
+    static int blocksPerCu = 0, cus = 0;                                                                          \
+    if (!blocksPerCu) {                                                                                           \
       SSRLCV_HIP_TRY(hipFuncSetAttribute((const void*)k_gauss_mfma<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                          (int)MfmaCfg<RR>::ldsBytes));                                            \
-      attr = true;                                                                                                \
+      int dev = 0, occ = 0;                                                                                       \
+      SSRLCV_HIP_TRY(hipGetDevice(&dev));                                                                         \
+      SSRLCV_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));                    \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_gauss_mfma<RR>, kMfmaThreads,         \
+                                                       MfmaCfg<RR>::ldsBytes) != hipSuccess || occ < 1)           \
+        occ = 1;                                                                                                  \
+      blocksPerCu = occ;                                                                                          \
     }                                                                                                             \
-    hipLaunchKernelGGL(k_gauss_mfma<RR>, grid, dim3(kTX), MfmaCfg<RR>::ldsBytes, st, a);                          \
+    uint32_t by = ((uint32_t)(blocksPerCu * cus) + bx - 1) / bx;                                                  \
+    rows = (h + by - 1) / by;                                                                                     \
+    rows = rows < 64 ? 64 : rows;                                                                                 \
+    rows = (rows + kMT - 1) / kMT * kMT;                                                                          \
+    a.rowsPerBlock = rows;                                                                                        \
+    grid = dim3(bx, (h + rows - 1) / rows);                                                                       \
+    hipLaunchKernelGGL(k_gauss_mfma<RR>, grid, dim3(kMfmaThreads), MfmaCfg<RR>::ldsBytes, st, a);                 \
   } while (0)
     switch (RT) {
       case 6: SSRLCV_LAUNCH_MFMA(6); break;
