@@ -262,7 +262,7 @@ __global__ __launch_bounds__(kTX) void k_gauss_fused(ConvArgs a) {
 // f32 MFMA pipe issues 32 FMA per cycle per SIMD against ~14 of the VALU formulation (tools/valu_rate.hip), and the
 // band fills 65/80 of a 16-wide tile at R = 32.
 //   horizontal: D[16 rows][16 cols] = In[16 rows][16+2R cols] x T      A from the LDS row stage, B = per-lane constants
-//   vertical  : D[16 rows][16 cols] = T^T[16 rows][16+2R] x H[16+2R rows][16 cols]   A = constants, B from the LDS ring
+//   vertical  : D^T[16 cols][16 rows] = H^T[16 cols][16+2R rows] x T             A from the LDS ring of H rows, B = constants
 // A block owns a 256-column strip and marches down 16 rows per step.  It has 8 waves in two roles, one wave of each
 // per SIMD: four waves stage the input rows and run the horizontal pass of step `it` (4 of the 16 column tiles each),
 // the other four run the vertical pass of step `it - 1` from the ring of H rows and store the result.  With a single role
@@ -367,22 +367,27 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma(ConvArgs a) {
   constexpr int kNoPending = -(1 << 30);
   f32x4 pend[4];
   int pendJ = kNoPending;
+  // The vertical product is evaluated transposed, D^T[x][y] = sum_k H^T[x][k] * T[k][y] (same LDS reads, the ring rows
+  // as the A operand): a lane then holds four consecutive x of output row jbase + li -- one 16-byte store per tile
+  // instead of four 4-byte ones (measured 0.03-0.04 ms per 8192^2 level).
+  const bool vec4 = (W & 3) == 0 && (reinterpret_cast<size_t>(a.out) & 15) == 0;
   auto store_pending = [&]() {
     const int jbase = pendJ;
-    const bool whole = jbase >= 0 && jbase + kMT <= nrows && x0 + kTX <= W;  // wave-uniform
+    const int j = jbase + li;
+    const bool rowOk = j >= 0 && j < nrows;
 #pragma unroll
     for (int t4 = 0; t4 < 4; ++t4) {
-      const int gx = x0 + (w4 * 4 + t4) * 16 + li;
-      float* orow = a.out + ((long)(y0 + jbase + lk * 4) * W + gx);
+      const int gx = x0 + (w4 * 4 + t4) * 16 + lk * 4;
+      float* o = a.out + ((long)(y0 + j) * W + gx);
+      const f32x4 v = pend[t4];
+      if (rowOk && vec4 && gx + 3 < W) {
+        *reinterpret_cast<f32x4*>(o) = v;  // rows start 16-byte aligned when W % 4 == 0 (gx is a multiple of 4)
+        mn = fminf(fminf(mn, v[0]), fminf(v[1], fminf(v[2], v[3])));
+        mx = fmaxf(fmaxf(mx, v[0]), fmaxf(v[1], fmaxf(v[2], v[3])));
+      } else if (rowOk) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = jbase + lk * 4 + r;
-        if (whole || (j >= 0 && j < nrows && gx < W)) {
-          const float v = pend[t4][r];
-          orow[(long)r * W] = v;
-          mn = fminf(mn, v);
-          mx = fmaxf(mx, v);
-        }
+        for (int r = 0; r < 4; ++r)
+          if (gx + r < W) { o[r] = v[r]; mn = fminf(mn, v[r]); mx = fmaxf(mx, v[r]); }
       }
     }
     pendJ = kNoPending;
@@ -463,7 +468,7 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma(ConvArgs a) {
           if (ks + 1 < C::KS) loadB(ks + 1, bv[(ks + 1) & 1]);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int t4 = 0; t4 < 4; ++t4) pend[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(tz[ks], bv[ks & 1][t4], pend[t4], 0, 0, 0);
+          for (int t4 = 0; t4 < 4; ++t4) pend[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[ks & 1][t4], tz[ks], pend[t4], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
         pendJ = jbase;
@@ -591,7 +596,7 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
   a.rowsPerBlock = rows;
   dim3 grid(bx, (h + rows - 1) / rows);
   // Two bit-identical formulations.  Measured per 8192^2 level on MI355X (ms, taps 13/17/23/33/47/65): VALU marching
-  // kernel 0.148/0.156/0.251/0.239/0.370/0.382, f32-MFMA banded Toeplitz 0.202/0.188/0.217/0.238/0.275/0.312 -- the band
+  // kernel 0.148/0.156/0.251/0.239/0.370/0.382, f32-MFMA banded Toeplitz 0.172/0.159/0.186/0.209/0.237/0.269 -- the band
   // wastes (16 + 2R - taps) / (16 + 2R) of the matrix pipe, more than half at R = 6.  Default: MFMA from 23 taps up.
   // SSRLCV_GAUSS_VALU=1 / SSRLCV_GAUSS_MFMA=1 force one of them for every radius.
   static const bool forceValu = getenv("SSRLCV_GAUSS_VALU") != nullptr, forceMfma = getenv("SSRLCV_GAUSS_MFMA") != nullptr;
