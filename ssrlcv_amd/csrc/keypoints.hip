@@ -36,35 +36,56 @@ __device__ __forceinline__ float norm_sample(const float* __restrict__ lvl, floa
 
 // ---- S8: extrema ---------------------------------------------------------------------------------------------------
 // findExtrema (src/FeatureFactory.cu:847-882): a pixel of level b (1..3) is kept when it equals the max or the min of
-// its 3x3x3 neighbourhood (non-strict).  One thread per pixel computes the 3x3 max/min of all five levels once and
-// derives the three flags; bit (b-1) of flags[p].
+// its 3x3x3 neighbourhood (non-strict); bit (b-1) of flags[p].  The 27-value max / min is separable: a thread walks
+// kExtRows rows of one column, forms the 3-wide row max / min of all five levels once per row (v_max3 / v_min3), keeps
+// three rows of them in registers and combines rows, then levels -- 19 loads and ~35 VALU per pixel instead of 45 and
+// ~80 for the direct form.  max and min are exact, so the grouping does not change any flag.
+constexpr int kExtRows = 8;
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
 __global__ __launch_bounds__(256) void k_extrema_flags(LevelSet L, uint8_t* __restrict__ flags) {
-  int x = blockIdx.x * 256 + threadIdx.x;
-  int y = blockIdx.y;
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  const int y0 = blockIdx.y * kExtRows;
   if (x >= L.w) return;
-  uint8_t f = 0;
-  if (x > 0 && y > 0 && x < L.w - 1 && y < L.h - 1) {
-    float mx[svp::kDog], mn[svp::kDog], c[svp::kDog];
+  const int xm = x > 0 ? x - 1 : 0, xp = x < L.w - 1 ? x + 1 : L.w - 1;  // border pixels never flag: clamping is harmless
+  const bool xin = x > 0 && x < L.w - 1;
+  float hmx[svp::kDog][3], hmn[svp::kDog][3], ctr[3][3];  // [level][row slot]; ctr: levels 1..3
+#pragma unroll
+  for (int step = 0; step < kExtRows + 2; ++step) {
+    const int r = step % 3;  // slot of the row loaded in this step (fully unrolled: static)
+    int yy = y0 + step - 1;
+    yy = yy < 0 ? 0 : (yy > L.h - 1 ? L.h - 1 : yy);
 #pragma unroll
     for (int l = 0; l < svp::kDog; ++l) {
-      const float* p = L.dog[l] + (size_t)(y - 1) * L.w + (x - 1);
-      float a0 = p[0], a1 = p[1], a2 = p[2];
-      p += L.w;
-      float b0 = p[0], b1 = p[1], b2 = p[2];
-      p += L.w;
-      float c0 = p[0], c1 = p[1], c2 = p[2];
-      mx[l] = fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, b0)), fmaxf(fmaxf(b1, b2), fmaxf(fmaxf(c0, c1), c2)));
-      mn[l] = fminf(fminf(fminf(a0, a1), fminf(a2, b0)), fminf(fminf(b1, b2), fminf(fminf(c0, c1), c2)));
-      c[l] = b1;
+      const float* p = L.dog[l] + (size_t)yy * L.w;
+      const float a0 = p[xm], a1 = p[x], a2 = p[xp];
+      hmx[l][r] = max3f(a0, a1, a2);
+      hmn[l][r] = min3f(a0, a1, a2);
+      if (l >= 1 && l <= 3) ctr[l - 1][r] = a1;
     }
+    if (step >= 2) {
+      const int y = y0 + step - 2;         // the middle one of the three rows held
+      const int mid = (step - 1) % 3;
+      if (y < L.h) {
+        float vmx[svp::kDog], vmn[svp::kDog];
 #pragma unroll
-    for (int b = 1; b <= 3; ++b) {
-      float hi = fmaxf(fmaxf(mx[b - 1], mx[b]), mx[b + 1]);
-      float lo = fminf(fminf(mn[b - 1], mn[b]), mn[b + 1]);
-      if (hi == c[b] || lo == c[b]) f |= (uint8_t)(1u << (b - 1));
+        for (int l = 0; l < svp::kDog; ++l) {
+          vmx[l] = max3f(hmx[l][0], hmx[l][1], hmx[l][2]);
+          vmn[l] = min3f(hmn[l][0], hmn[l][1], hmn[l][2]);
+        }
+        uint8_t f = 0;
+#pragma unroll
+        for (int bl = 1; bl <= 3; ++bl) {
+          const float hi = max3f(vmx[bl - 1], vmx[bl], vmx[bl + 1]);
+          const float lo = min3f(vmn[bl - 1], vmn[bl], vmn[bl + 1]);
+          const float c = ctr[bl - 1][mid];
+          if (hi == c || lo == c) f |= (uint8_t)(1u << (bl - 1));
+        }
+        if (!(xin && y > 0 && y < L.h - 1)) f = 0;
+        flags[(size_t)y * L.w + x] = f;
+      }
     }
   }
-  flags[(size_t)y * L.w + x] = f;
 }
 
 // ---- bookkeeping kernels (one thread) ------------------------------------------------------------------------------------
@@ -700,7 +721,7 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
     const int nswaps = (stop >= 1) + 2 * (stop >= 2) + (stop >= 3) + (stop >= 4) + (stop >= 5) + (stop >= 6);
     hipLaunchKernelGGL(k_state_reset, dim3(1), dim3(1), 0, s, st);
     // --- searchForExtrema (src/FeatureFactory.cu:86-159) ---
-    hipLaunchKernelGGL(k_extrema_flags, dim3((oc.w + 255) / 256, oc.h), dim3(256), 0, s, L, flags);
+    hipLaunchKernelGGL(k_extrema_flags, dim3((oc.w + 255) / 256, (oc.h + kExtRows - 1) / kExtRows), dim3(256), 0, s, L, flags);
     {
       const uint32_t P = oc.w * oc.h;
       const int W = (int)oc.w;
