@@ -8,7 +8,7 @@ batch of synthetic u8 images already resident in HBM.  Ranks own different image
 collective inside the SIFT stage).  value = total input pixels of all ranks / max-over-ranks time.
 
 Besides the contract keys the JSON line carries
-  roofline      : the DoG-pyramid stage (ssrlcv_hip_sift_build_dog: 33 launches per image) against HBM, algorithmic
+  roofline      : the DoG-pyramid stage (ssrlcv_hip_sift_build_dog: 35 launches per image) against HBM, algorithmic
                   bytes 362.25*W*H per image (SURVEY.md section 8d), duration from HIP events inside the timed steps;
   matcher       : Mmatches/s of ssrlcv_hip_match_u8x128 (pairs compared / time) on Nq = Nt synthetic descriptors,
                   with its own fp16-MFMA roofline (2*128*Nq*Nt flop);
@@ -251,8 +251,10 @@ def main():
                        "images_per_gpu": args.images, "features_per_image": nfeat, "parallelism": "image-pair shard"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "DoG pyramid stage = ssrlcv_hip_sift_build_dog (upsample, 24 k_gauss_fused, 3 bin, "
-                                   "4 k_dog launches per image); algorithmic bytes 362.25*W*H per image",
+                         "kernel": "DoG pyramid stage = ssrlcv_hip_sift_build_dog (upsample, 24 gaussian levels: "
+                                   "k_gauss_fused up to 17 taps / k_gauss_mfma from 23 taps, 3 bin, 4 k_dog launches per "
+                                   "image; DoG(o) overlaps conv(o+1) on a side stream); algorithmic bytes 362.25*W*H "
+                                   "per image; events bracket the stage on the launching stream",
                          "ms_per_image": pyr_ms},
         }
         if not args.no_matcher:
