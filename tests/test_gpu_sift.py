@@ -44,7 +44,7 @@ def test_image_ops_bit_exact(capi, oracle_lib):
     assert mm[0] == src.min() and mm[1] == src.max()
 
 
-@pytest.mark.parametrize("w,h", [(512, 264), (64, 64), (1000, 72), (2048, 136)])
+@pytest.mark.parametrize("w,h", [(512, 264), (64, 64), (1000, 72), (2048, 136), (250, 130), (1002, 96)])
 @pytest.mark.parametrize("sigma,pw", [(0.70710678, 0.5), (1.0, 0.5), (1.4142135, 0.5), (2.0, 0.5), (2.828427, 0.5),
                                       (4.0, 0.5), (1.3, 1.0)])
 def test_separable_gaussian_bit_exact(capi, oracle_lib, w, h, sigma, pw):
