@@ -2,12 +2,14 @@
 //
 // Replaces the thrust::remove / remove_if / copy_if / stable_sort-by-small-key call sites of the hot path
 // (src/FeatureFactory.cu:126,189,250,595,597; src/MatchFactory.cu:37,63,89).  Three launches:
-//   1. k_count  : each 256-thread block owns a chunk of consecutive elements and counts, per key, how many of its
-//                 elements carry that key.  An element may carry several keys (bit mask), e.g. a pixel that is an
-//                 extremum of two DoG levels; mask 0 removes the element;
-//   2. k_scan   : one block turns the [key][block] count table into exclusive offsets in key-major order, so the
+//   1. k_count  : each WAVE owns a run of 64 * PER_THREAD consecutive elements and counts, per key, how many of them
+//                 carry that key (wave64 ballots).  An element may carry several keys (bit mask), e.g. a pixel that is
+//                 an extremum of two DoG levels; mask 0 removes the element;
+//   2. k_scan   : one block turns the [key][wave] count table into exclusive offsets in key-major order, so the
 //                 output is grouped by key and, inside a key, keeps the input order (= stable partition);
-//   3. k_scatter: each block recomputes its elements' ranks (wave64 ballots + popcounts) and emits them.
+//   3. k_scatter: each wave walks its run again, ranks its elements with ballots + popcounts and emits them.
+// Everything is wave-granular: no LDS, no barriers (the first version exchanged per-round counts through LDS with three
+// __syncthreads per 256 elements, which was 0.4 ms of the 67 Mpx extrema compaction).
 // The mask functor must be pure (it is evaluated in passes 1 and 3).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -16,41 +18,39 @@
 namespace svc {
 
 constexpr int kThreads = 256;
+constexpr int kWavesPerBlock = kThreads / 64;
 
 __host__ __device__ inline uint32_t num_chunks(uint32_t n, int perThread) {
   uint32_t chunk = (uint32_t)kThreads * (uint32_t)perThread;
   return (n + chunk - 1) / chunk;
 }
 
-// counts layout: counts[key * numBlocks + block]
+// counts layout: counts[key * numWaves + wave], wave = block * 4 + wave-in-block; numRuns = numBlocks * 4
 template <int NKEYS, int PER_THREAD, typename MaskFn>
-__global__ __launch_bounds__(kThreads) void k_count(uint32_t n, uint32_t numBlocks, MaskFn maskfn,
+__global__ __launch_bounds__(kThreads) void k_count(uint32_t n, uint32_t numRuns, MaskFn maskfn,
                                                     uint32_t* __restrict__ counts) {
-  __shared__ uint32_t s_cnt[NKEYS];
-  if (threadIdx.x < NKEYS) s_cnt[threadIdx.x] = 0;
-  __syncthreads();
-  const uint32_t base = blockIdx.x * (kThreads * PER_THREAD);
-  uint32_t local[NKEYS];
+  const unsigned lane = threadIdx.x & 63;
+  const uint32_t run = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const uint32_t base = run * (64u * PER_THREAD);
+  uint32_t cnt[NKEYS];
 #pragma unroll
-  for (int k = 0; k < NKEYS; ++k) local[k] = 0;
+  for (int k = 0; k < NKEYS; ++k) cnt[k] = 0;
   for (int r = 0; r < PER_THREAD; ++r) {
-    uint32_t i = base + r * kThreads + threadIdx.x;
+    if (base + r * 64u >= n) break;  // wave-uniform
+    uint32_t i = base + r * 64u + lane;
     uint32_t mask = (i < n) ? maskfn(i) : 0u;
 #pragma unroll
-    for (int k = 0; k < NKEYS; ++k) local[k] += (mask >> k) & 1u;
+    for (int k = 0; k < NKEYS; ++k) cnt[k] += (uint32_t)__popcll(__ballot((mask >> k) & 1u));
   }
+  if (lane < NKEYS) {
+    uint32_t v = 0;
 #pragma unroll
-  for (int k = 0; k < NKEYS; ++k) {
-    uint32_t v = local[k];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_cnt[k], v);
+    for (int k = 0; k < NKEYS; ++k) v = lane == (unsigned)k ? cnt[k] : v;
+    counts[lane * numRuns + run] = v;
   }
-  __syncthreads();
-  if (threadIdx.x < NKEYS) counts[threadIdx.x * numBlocks + blockIdx.x] = s_cnt[threadIdx.x];
 }
 
-// Exclusive scan over the NKEYS*numBlocks table in key-major order; totals[k] = number of elements with key k,
+// Exclusive scan over the NKEYS*numBlocks table (numBlocks = number of wave runs here) in key-major order; totals[k] = number of elements with key k,
 // totals[NKEYS] = grand total.  Single block of 1024 threads, each thread scanning 4 consecutive entries per round.
 template <int NKEYS>
 __global__ __launch_bounds__(1024) void k_scan(uint32_t numBlocks, uint32_t* __restrict__ counts,
@@ -99,50 +99,34 @@ __global__ __launch_bounds__(1024) void k_scan(uint32_t numBlocks, uint32_t* __r
 
 // emit(i, key, dst): writes input element i (as a member of `key`) to output slot dst.
 template <int NKEYS, int PER_THREAD, typename MaskFn, typename EmitFn>
-__global__ __launch_bounds__(kThreads) void k_scatter(uint32_t n, uint32_t numBlocks, MaskFn maskfn, EmitFn emit,
+__global__ __launch_bounds__(kThreads) void k_scatter(uint32_t n, uint32_t numRuns, MaskFn maskfn, EmitFn emit,
                                                       const uint32_t* __restrict__ offsets) {
-  __shared__ uint32_t s_base[NKEYS];     // running output offset per key for this block
-  __shared__ uint32_t s_wcnt[4][NKEYS];  // per-wave counts of the current round
-  if (threadIdx.x < NKEYS) s_base[threadIdx.x] = offsets[threadIdx.x * numBlocks + blockIdx.x];
-  __syncthreads();
-  const uint32_t base = blockIdx.x * (kThreads * PER_THREAD);
-  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned lane = threadIdx.x & 63;
+  const uint32_t run = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const uint32_t base = run * (64u * PER_THREAD);
   const unsigned long long below = (1ull << lane) - 1ull;
+  uint32_t off[NKEYS];  // running output offset per key of this wave's run (wave-uniform)
+#pragma unroll
+  for (int k = 0; k < NKEYS; ++k) off[k] = offsets[k * numRuns + run];
   for (int r = 0; r < PER_THREAD; ++r) {
-    uint32_t i = base + r * kThreads + threadIdx.x;
+    if (base + r * 64u >= n) break;  // wave-uniform
+    uint32_t i = base + r * 64u + lane;
     uint32_t mask = (i < n) ? maskfn(i) : 0u;
-    uint32_t rank[NKEYS];
+    if (__ballot(mask != 0u) == 0ull) continue;  // nothing kept in these 64 elements (the common case for pixels)
 #pragma unroll
     for (int k = 0; k < NKEYS; ++k) {
-      unsigned long long m = __ballot((mask >> k) & 1u);
-      rank[k] = __popcll(m & below);
-      if (lane == 0) s_wcnt[wave][k] = __popcll(m);
+      const bool has = (mask >> k) & 1u;
+      const unsigned long long m = __ballot(has);
+      if (has) emit(i, k, off[k] + (uint32_t)__popcll(m & below));
+      off[k] += (uint32_t)__popcll(m);
     }
-    __syncthreads();
-    if (mask) {
-#pragma unroll
-      for (int k = 0; k < NKEYS; ++k) {
-        if ((mask >> k) & 1u) {
-          uint32_t off = s_base[k];
-          for (unsigned w = 0; w < wave; ++w) off += s_wcnt[w][k];
-          emit(i, k, off + rank[k]);
-        }
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x < NKEYS) {
-      uint32_t add = 0;
-      for (int w = 0; w < 4; ++w) add += s_wcnt[w][threadIdx.x];
-      s_base[threadIdx.x] += add;
-    }
-    __syncthreads();
   }
 }
 
-// Workspace (in uint32 words): NKEYS * numBlocks counts + (NKEYS + 1) totals.
+// Workspace (in uint32 words): NKEYS * numRuns counts + (NKEYS + 1) totals.
 template <int NKEYS, int PER_THREAD>
 inline size_t workspace_words(uint32_t n) {
-  return (size_t)NKEYS * num_chunks(n, PER_THREAD) + NKEYS + 1;
+  return (size_t)NKEYS * kWavesPerBlock * num_chunks(n, PER_THREAD) + NKEYS + 1;
 }
 
 // Launches the three passes over elements [0, n).  *totals_out = device pointer to NKEYS + 1 words in the workspace.
@@ -150,14 +134,15 @@ template <int NKEYS, int PER_THREAD, typename MaskFn, typename EmitFn>
 inline hipError_t partition(uint32_t n, MaskFn maskfn, EmitFn emit, uint32_t* workspace, uint32_t** totals_out,
                             hipStream_t stream) {
   uint32_t nb = num_chunks(n, PER_THREAD);
+  uint32_t runs = nb * kWavesPerBlock;
   uint32_t* counts = workspace;
-  uint32_t* totals = workspace + (size_t)NKEYS * nb;
+  uint32_t* totals = workspace + (size_t)NKEYS * runs;
   if (totals_out) *totals_out = totals;
   if (nb == 0) return hipMemsetAsync(totals, 0, sizeof(uint32_t) * (NKEYS + 1), stream);
-  hipLaunchKernelGGL((k_count<NKEYS, PER_THREAD, MaskFn>), dim3(nb), dim3(kThreads), 0, stream, n, nb, maskfn, counts);
-  hipLaunchKernelGGL((k_scan<NKEYS>), dim3(1), dim3(1024), 0, stream, nb, counts, totals);
-  hipLaunchKernelGGL((k_scatter<NKEYS, PER_THREAD, MaskFn, EmitFn>), dim3(nb), dim3(kThreads), 0, stream, n, nb, maskfn,
-                     emit, counts);
+  hipLaunchKernelGGL((k_count<NKEYS, PER_THREAD, MaskFn>), dim3(nb), dim3(kThreads), 0, stream, n, runs, maskfn, counts);
+  hipLaunchKernelGGL((k_scan<NKEYS>), dim3(1), dim3(1024), 0, stream, runs, counts, totals);
+  hipLaunchKernelGGL((k_scatter<NKEYS, PER_THREAD, MaskFn, EmitFn>), dim3(nb), dim3(kThreads), 0, stream, n, runs,
+                     maskfn, emit, counts);
   return hipGetLastError();
 }
 

@@ -829,8 +829,9 @@ int ssrlcv_sift_plan_create(uint32_t w, uint32_t h, const ssrlcv_sift_params* pa
     oc.off_theta = take((size_t)cap * svp::kMaxOrient * sizeof(float));
     oc.off_thetaCnt = take((size_t)cap * sizeof(uint32_t));
     // partition scratch: pixel-domain (3 keys over P) is the largest user
-    size_t words = (size_t)3 * ((P + 8191) / 8192) + 16 +
-                   (size_t)svp::kDog * (((size_t)cap * svp::kMaxOrient + 2047) / 2048) + 16;
+    // (compact.h: NKEYS x 4 wave runs per 256-thread chunk; chunks of 256 x 32 pixels / 256 x 8 list entries)
+    size_t words = (size_t)3 * 4 * ((P + 8191) / 8192) + 16 +
+                   (size_t)svp::kDog * 4 * (((size_t)cap * svp::kMaxOrient + 2047) / 2048) + 16;
     oc.off_part = take(words * 4);
     oc.off_featBase = take(256);
     maxFeat += cap;
