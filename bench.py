@@ -93,6 +93,37 @@ def bench_matcher(capi, torch, nq, nt, iters):
                          "kernel": "k_match (v_mfma_f32_32x32x16_f16), whole ssrlcv_hip_match_u8x128 call"}}
 
 
+def bench_matcher_epipolar(capi, torch, n, size, iters):
+    """The orbit mode of doFeatureMatching (matchFeaturesDoubleConstrained, epsilon 25 px, delta 5 km) on the same kind
+    of synthetic sets, features spread uniformly over a size x size image seen by the fixture's camera pair rescaled
+    to that size.  Reported as effective pair comparisons per second (Nq*Nt / time): the band-culled path skips most
+    of them without computing a distance."""
+    import helpers as H
+    q, t = synth_descriptors(n, 1), synth_descriptors(n, 2)
+    rng = np.random.default_rng(5)
+    q["loc"] = rng.uniform(0, size, (n, 2)).astype(np.float32)
+    t["loc"] = rng.uniform(0, size, (n, 2)).astype(np.float32)
+    cams = H.load_view("Pipeline2View")["cameras"].copy()
+    scale = float(cams["size"][0][0]) / size
+    cams["dpix"] = cams["dpix"] * scale
+    cams["size"] = int(size)
+    params = capi.make_match_params(1, 0, 1, 25.0, 5.0, 0.6, 200.0 * 200.0, cams[0:1], capi.projection_matrix(cams[1:2]))
+    q_d, t_d = capi.to_dev(q), capi.to_dev(t)
+    ws = capi.match_workspace(n, n)
+    out = capi.dev_bytes(n * 48)
+    capi.match(q_d, n, t_d, n, params, capi.OUT_DMATCH, workspace=ws, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        capi.match(q_d, n, t_d, n, params, capi.OUT_DMATCH, workspace=ws, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    return {"value": float(n) * float(n) / (ms * 1e-3) / 1e6, "unit": "effective Mmatches/s", "nq": n, "nt": n, "ms": ms,
+            "mode": "double-constrained, epsilon 25 px, delta 5 km, %dx%d images" % (size, size)}
+
+
 def cpu_baseline(size):
     """Oracle (CPU port of the reference kernels) SIFT on ONE size x size image: bounded sample of the workload."""
     import helpers as H
@@ -259,6 +290,7 @@ def main():
         }
         if not args.no_matcher:
             line["matcher"] = bench_matcher(capi, torch, args.match_n, args.match_n, args.match_iters)
+            line["matcher_epipolar"] = bench_matcher_epipolar(capi, torch, args.match_n, W, args.match_iters)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_size)
         print(json.dumps(line))

@@ -23,11 +23,14 @@
 //   packed queries  [nq_pad][144] fp16   {q_0..q_127, 1, 1024, 32768, 0 x13}
 //   packed targets  [nt_pad][144] fp16   {-2 t_0..-2 t_127, n0, n1, 32 n2, 0 x13}; padding rows get a huge norm
 //   query norms     [nq_pad] f32, target locations [nt_pad] float2, query epipolar params [nq_pad] x 8 f32, keys [nq_pad] u64
+//   modes 1 / 2 only: spatial permutations of both sets (rows above are then in that order), one bounding box per
+//   32-target tile and per group of 32 tiles, scratch of the location sort (see "band culling" below)
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <math.h>
 #include "compact.h"
 #include "device_math.h"
+#include "spatial_sort.h"
 #include "ssrlcv_hip.h"
 
 using namespace sv;
@@ -62,15 +65,18 @@ __host__ __device__ inline uint32_t round_up(uint32_t v, uint32_t m) { return (v
 
 // ---- pack ------------------------------------------------------------------------------------------------------
 // One wave per 4 features: 16 lanes x 8 bytes per feature.  Writes the fp16 row, the norm and (targets) the location.
+// perm (nullable): packed row f holds feature perm[f] (the spatial order of the band-culled modes).
 __global__ __launch_bounds__(256) void k_pack(const ssrlcv_sift_feature* __restrict__ feats, uint32_t n, uint32_t n_pad,
-                                              int as_target, _Float16* __restrict__ packed, float* __restrict__ norms,
+                                              int as_target, const uint32_t* __restrict__ perm,
+                                              _Float16* __restrict__ packed, float* __restrict__ norms,
                                               ssrlcv_float2* __restrict__ locs) {
   uint32_t f = (blockIdx.x * 256 + threadIdx.x) >> 4;  // 16 lanes per feature
   unsigned sub = threadIdx.x & 15;
   if (f >= n_pad) return;
   _Float16* row = packed + (size_t)f * kKPad;
   if (f < n) {
-    const uint8_t* v = feats[f].values + sub * 8;
+    const uint32_t src = perm ? perm[f] : f;
+    const uint8_t* v = feats[src].values + sub * 8;
     uint2 raw = *reinterpret_cast<const uint2*>(v);  // values[] sits at offset 24 of a 152-byte struct: 8-byte aligned
     uint32_t b[8] = {raw.x & 255u, (raw.x >> 8) & 255u, (raw.x >> 16) & 255u, raw.x >> 24,
                      raw.y & 255u, (raw.y >> 8) & 255u, (raw.y >> 16) & 255u, raw.y >> 24};
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(256) void k_pack(const ssrlcv_sift_feature* __restr
         e0[0] = (_Float16)(float)(nsq & 1023u);
         e0[1] = (_Float16)(float)((nsq >> 10) & 1023u);
         e0[2] = (_Float16)(float)((nsq >> 20) * 32u);
-        if (locs) locs[f] = feats[f].loc;
+        if (locs) locs[f] = feats[src].loc;
       } else {
         e0[0] = (_Float16)1.0f;
         e0[1] = (_Float16)1024.0f;
@@ -124,12 +130,20 @@ __global__ __launch_bounds__(256) void k_pack(const ssrlcv_sift_feature* __restr
 // ---- epipolar parameters per query (src/MatchFactory.cu:1240-1277 + :2209-2232) ---------------------------------
 #define EARTH_MAX_KM_FROM_CENT 6384.4
 #define EARTH_MIN_KM_FROM_CENT 6356.77
-__global__ __launch_bounds__(256) void k_geom(const ssrlcv_sift_feature* __restrict__ query, uint32_t nq,
-                                              ssrlcv_camera qc, f4 P0, f4 P1, f4 P2, float epsilon, float delta,
-                                              Geom* __restrict__ geom) {
+// geom[s] belongs to query perm[s] (perm nullable = identity); rows nq..nq_pad get a band that meets no box.
+__global__ __launch_bounds__(256) void k_geom(const ssrlcv_sift_feature* __restrict__ query, uint32_t nq, uint32_t nq_pad,
+                                              const uint32_t* __restrict__ perm, ssrlcv_camera qc, f4 P0, f4 P1, f4 P2,
+                                              float epsilon, float delta, Geom* __restrict__ geom) {
   uint32_t q = blockIdx.x * 256 + threadIdx.x;
-  if (q >= nq) return;
-  ssrlcv_float2 loc = query[q].loc;
+  if (q >= nq_pad) return;
+  if (q >= nq) {
+    Geom z;
+    z.lo_x = FLT_MAX; z.hi_x = -FLT_MAX;
+    z.left_x = z.left_y = z.slope = z.top = z.bottom = z.vertical = 0.0f;
+    geom[q] = z;
+    return;
+  }
+  ssrlcv_float2 loc = query[perm ? perm[q] : q].loc;
   f3 queryVec = mk3(qc.dpix.x * ((loc.x) - (qc.size.x / 2.0f)), qc.dpix.y * ((loc.y) - (qc.size.y / 2.0f)), qc.foc);
   queryVec = rotate_point(queryVec, qc.cam_rot);
   f3 queryCent = mk3(qc.cam_pos.x + qc.ecef_offset.x, qc.cam_pos.y + qc.ecef_offset.y, qc.cam_pos.z + qc.ecef_offset.z);
@@ -171,11 +185,18 @@ __global__ __launch_bounds__(256) void k_geom(const ssrlcv_sift_feature* __restr
 
 // matchFeaturesConstrained's epipolar line of a query (src/MatchFactory.cu:1722-1724)
 __global__ __launch_bounds__(256) void k_geom_fundamental(const ssrlcv_sift_feature* __restrict__ query, uint32_t nq,
+                                                          uint32_t nq_pad, const uint32_t* __restrict__ perm,
                                                           const float* __restrict__ F9, Geom* __restrict__ geom) {
   uint32_t q = blockIdx.x * 256 + threadIdx.x;
-  if (q >= nq) return;
-  ssrlcv_float2 loc = query[q].loc;
+  if (q >= nq_pad) return;
   Geom g;
+  if (q >= nq) {  // padding: the line y = -3e38 meets no box
+    g.lo_x = 0.0f; g.hi_x = 1.0f; g.left_x = 3.0e38f;
+    g.left_y = g.slope = g.top = g.bottom = g.vertical = 0.0f;
+    geom[q] = g;
+    return;
+  }
+  ssrlcv_float2 loc = query[perm ? perm[q] : q].loc;
   g.lo_x = (F9[0] * loc.x) + (F9[1] * loc.y) + F9[2];
   g.hi_x = (F9[3] * loc.x) + (F9[4] * loc.y) + F9[5];
   g.left_x = (F9[6] * loc.x) + (F9[7] * loc.y) + F9[8];
@@ -199,6 +220,63 @@ __device__ __forceinline__ bool passes_prefilter(const Geom& g, ssrlcv_float2 t,
   return true;
 }
 
+// ---- band culling (modes 1 / 2) ---------------------------------------------------------------------------------------
+// The reference evaluates the prefilter per (query, target) pair and skips the distance when it fails; a brute-force
+// MFMA pass computes every distance first.  With both feature sets in spatial order (spatial_sort.hip) a 32-target tile
+// has a small bounding box, and a whole tile (or a group of 32 tiles) can be skipped when no query of the wave has a
+// band that touches the box.  The test is conservative (margins for the rounding of the per-pair test, NaN geometry
+// counts as a hit), the per-pair prefilter still runs on every surviving candidate, so results are unchanged.
+struct Box { float x0, y0, x1, y1; };
+
+__global__ __launch_bounds__(256) void k_tile_boxes(const ssrlcv_float2* __restrict__ locT, uint32_t nt, uint32_t numTiles,
+                                                    Box* __restrict__ tileBox) {
+  uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= numTiles) return;
+  Box b = {FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (uint32_t j = 0; j < 32; ++j) {
+    uint32_t f = t * 32 + j;
+    if (f < nt) {
+      ssrlcv_float2 l = locT[f];
+      b.x0 = fminf(b.x0, l.x); b.y0 = fminf(b.y0, l.y); b.x1 = fmaxf(b.x1, l.x); b.y1 = fmaxf(b.y1, l.y);
+      // a NaN coordinate makes the per-pair test pass (see passes_prefilter): such a tile must never be culled
+      if (!(l.x == l.x) || !(l.y == l.y)) { b.x0 = -FLT_MAX; b.y0 = -FLT_MAX; b.x1 = FLT_MAX; b.y1 = FLT_MAX; break; }
+    }
+  }
+  tileBox[t] = b;
+}
+__global__ __launch_bounds__(256) void k_group_boxes(const Box* __restrict__ tileBox, uint32_t numTiles, uint32_t numGroups,
+                                                     Box* __restrict__ groupBox) {
+  uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= numGroups) return;
+  Box b = {FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (uint32_t j = 0; j < 32; ++j) {
+    uint32_t t = g * 32 + j;
+    if (t < numTiles) {
+      Box tb = tileBox[t];
+      b.x0 = fminf(b.x0, tb.x0); b.y0 = fminf(b.y0, tb.y0); b.x1 = fmaxf(b.x1, tb.x1); b.y1 = fmaxf(b.y1, tb.y1);
+    }
+  }
+  groupBox[g] = b;
+}
+
+// false only when no target inside `b` can pass passes_prefilter(g, ., epsilon, mode)
+__device__ __forceinline__ bool band_hits_box(const Geom& g, const Box& b, float epsilon, int mode) {
+  if (mode == 2) {
+    const float p0 = -1 * ((g.lo_x * b.x0) + g.left_x) / g.hi_x, p1 = -1 * ((g.lo_x * b.x1) + g.left_x) / g.hi_x;
+    const float m = 0.25f + 1e-5f * (fabsf(p0) + fabsf(p1));
+    const float lo = fminf(p0, p1) - epsilon - m, hi = fmaxf(p0, p1) + epsilon + m;
+    if (!(p0 == p0) || !(p1 == p1)) return true;
+    return !(lo > b.y1 || hi < b.y0);
+  }
+  if (b.x1 < g.lo_x || b.x0 > g.hi_x) return false;  // the per-pair x test, exact; false for NaN bounds
+  if (g.vertical != 0.0f) return !(g.top > b.y1 || g.bottom < b.y0);
+  const float xa = fmaxf(g.lo_x, b.x0), xb = fminf(g.hi_x, b.x1);
+  const float ya = g.slope * (xa - g.left_x) + g.left_y, yb = g.slope * (xb - g.left_x) + g.left_y;
+  if (!(ya == ya) || !(yb == yb)) return true;
+  const float m = 0.25f + 1e-5f * (fabsf(ya) + fabsf(yb));
+  return !(fminf(ya, yb) - epsilon - m > b.y1 || fmaxf(ya, yb) + epsilon + m < b.y0);
+}
+
 __device__ __forceinline__ unsigned long long make_key(float dist, uint32_t f) {
   return ((unsigned long long)(uint32_t)dist << 32) | ((unsigned long long)(f & 31u) << 27) | (unsigned long long)(f >> 5);
 }
@@ -206,11 +284,16 @@ __device__ __forceinline__ unsigned long long make_key(float dist, uint32_t f) {
 // ---- the contraction ---------------------------------------------------------------------------------------------
 // grid.x: query blocks of 512, grid.y: target splits.  256 threads = 4 waves, one per SIMD; each wave keeps kQT query
 // tiles (B operands, 36 VGPRs each) resident and streams every target tile of its split through the matrix core.
+// BAND: modes 1 / 2 on spatially ordered sets: rows are in perm order, permT maps a packed target row back to the
+// caller's index (the key and its tie-break use the caller's index), tiles / groups of tiles are culled by their boxes.
+template <bool BAND>
 __global__ __launch_bounds__(256, SSRLCV_MATCH_WPS) void k_match(const _Float16* __restrict__ packedQ, const _Float16* __restrict__ packedT,
                                                   const float* __restrict__ normQ, const ssrlcv_float2* __restrict__ locT,
                                                   const Geom* __restrict__ geom, uint32_t nq, uint32_t nt,
                                                   uint32_t tilesPerSplit, int mode, float epsilon, float absThreshold,
-                                                  unsigned long long* __restrict__ bestKey) {
+                                                  unsigned long long* __restrict__ bestKey,
+                                                  const uint32_t* __restrict__ permT, const Box* __restrict__ tileBox,
+                                                  const Box* __restrict__ groupBox) {
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned col = lane & 31, kgrp = lane >> 5;
   const uint32_t qbase = (blockIdx.x * kWaves + wave) * (kQT * 32);
@@ -242,6 +325,11 @@ __global__ __launch_bounds__(256, SSRLCV_MATCH_WPS) void k_match(const _Float16*
     return r;
   };
   // argmin epilogue of one 32x32 tile (query tile qt): v_min tree, wave-uniform branch, rare slow path
+  Geom gq[BAND ? kQT : 1];  // BAND: the wave's query bands stay in registers (culling reads them for every box)
+  if (BAND) {
+#pragma unroll
+    for (int qt = 0; qt < (BAND ? kQT : 1); ++qt) gq[qt] = geom[qbase + qt * 32 + col];
+  }
   auto epilogue = [&](uint32_t tt, int qt, const floatx16& acc) {
     float m0 = min3(acc[0], acc[1], acc[2]);
     float m1 = min3(acc[3], acc[4], acc[5]);
@@ -252,7 +340,8 @@ __global__ __launch_bounds__(256, SSRLCV_MATCH_WPS) void k_match(const _Float16*
     if (__any(m <= bestAcc[qt])) {
       // slow path: decode rows.  C/D layout of the 32x32 MFMA: row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
       Geom g;
-      if (mode != 0) g = geom[qbase + qt * 32 + col];
+      if (BAND) g = gq[BAND ? qt : 0];
+      else if (mode != 0) g = geom[qbase + qt * 32 + col];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = acc[r];
@@ -262,7 +351,7 @@ __global__ __launch_bounds__(256, SSRLCV_MATCH_WPS) void k_match(const _Float16*
           bool ok = (f < nt) && (d < absThreshold);
           if (ok && mode != 0) ok = passes_prefilter(g, locT[f], epsilon, mode);
           if (ok) {
-            unsigned long long k = make_key(d, f);
+            unsigned long long k = make_key(d, BAND ? permT[f] : f);
             if (k < key[qt]) {
               key[qt] = k;
               bestAcc[qt] = v;
@@ -297,6 +386,37 @@ __global__ __launch_bounds__(256, SSRLCV_MATCH_WPS) void k_match(const _Float16*
 #pragma unroll
     for (int s2 = 0; s2 < kKSteps; ++s2) dst[s2] = *reinterpret_cast<const half8*>(trow + s2 * 16);
   };
+  if (BAND) {
+    const uint32_t numGroups = (numTiles + 31) / 32;
+    for (uint32_t gr = tile0 / 32; gr < numGroups && gr * 32 < tile1; ++gr) {
+      const Box gb = groupBox[gr];
+      bool gh = false;
+#pragma unroll
+      for (int qt = 0; qt < (BAND ? kQT : 1); ++qt) gh = gh || band_hits_box(gq[qt], gb, epsilon, mode);
+      if (!__any(gh)) continue;
+      uint32_t t1 = (gr + 1) * 32;
+      if (t1 > tile1) t1 = tile1;
+      for (uint32_t tt = gr * 32 > tile0 ? gr * 32 : tile0; tt < t1; ++tt) {
+        const Box tb = tileBox[tt];
+        unsigned need = 0;
+#pragma unroll
+        for (int qt = 0; qt < (BAND ? kQT : 1); ++qt)
+          if (__any(band_hits_box(gq[qt], tb, epsilon, mode))) need |= 1u << qt;
+        if (!need) continue;
+        half8 a[kKSteps];
+        load_tile(tt, a);
+#pragma unroll
+        for (int qt = 0; qt < kQT; ++qt) {
+          if ((need >> qt) & 1u) {
+            floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int s2 = 0; s2 < kKSteps; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s2], bq[qt][s2], acc, 0, 0, 0);
+            epilogue(tt, qt, acc);
+          }
+        }
+      }
+    }
+  } else {
 #if SSRLCV_MATCH_WPS >= 2
   // two waves per SIMD: the partner wave hides the load latency, one register buffer suffices
   for (uint32_t tt = tile0; tt < tile1; ++tt) {
@@ -317,6 +437,7 @@ __global__ __launch_bounds__(256, SSRLCV_MATCH_WPS) void k_match(const _Float16*
     }
   }
 #endif
+  }
   // merge: lanes l and l+32 hold the same query (different target rows); other splits merge through the atomic
 #pragma unroll
   for (int qt = 0; qt < kQT; ++qt) {
@@ -331,10 +452,11 @@ __global__ __launch_bounds__(256) void k_finalize(const unsigned long long* __re
                                                   const ssrlcv_sift_feature* __restrict__ target,
                                                   const float* __restrict__ seedDistances, uint32_t queryID,
                                                   uint32_t targetID, float rel, float absThreshold, int outKind,
-                                                  int mode, void* __restrict__ out) {
-  uint32_t q = blockIdx.x * 256 + threadIdx.x;
-  if (q >= nq) return;
-  unsigned long long k = bestKey[q];
+                                                  int mode, const uint32_t* __restrict__ permQ, void* __restrict__ out) {
+  uint32_t s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= nq) return;
+  unsigned long long k = bestKey[s];       // keys are in packed-row order
+  const uint32_t q = permQ ? permQ[s] : s;  // the caller's query index
   bool found = k != kNoKey;
   float dist = found ? (float)(uint32_t)(k >> 32) : absThreshold;
   uint32_t lo = (uint32_t)(k & 0xffffffffull);
@@ -385,7 +507,8 @@ __global__ __launch_bounds__(256) void k_seed_finalize(const unsigned long long*
 
 struct Layout {
   uint32_t nq_pad, nt_pad;
-  size_t off_pq, off_pt, off_nq, off_lt, off_geom, off_key, off_scratch, total;
+  size_t off_pq, off_pt, off_nq, off_lt, off_geom, off_key, off_scratch, off_permq, off_permt, off_tilebox, off_groupbox,
+      off_sort, sort_bytes, total;
 };
 
 Layout make_layout(uint32_t nq, uint32_t nt) {
@@ -402,6 +525,13 @@ Layout make_layout(uint32_t nq, uint32_t nt) {
   L.off_key = take((size_t)L.nq_pad * 8);
   // scratch for compact_matches: a copy of the largest output struct array + partition counters
   L.off_scratch = take((size_t)nq * sizeof(ssrlcv_dmatch) + svc::workspace_words<1, 8>(nq) * 4 + 256);
+  // band-culled modes: spatial permutations, tile / group boxes, sort scratch
+  L.off_permq = take((size_t)L.nq_pad * 4);
+  L.off_permt = take((size_t)L.nt_pad * 4);
+  L.off_tilebox = take((size_t)(L.nt_pad / 32) * sizeof(Box));
+  L.off_groupbox = take((size_t)((L.nt_pad / 32 + 31) / 32) * sizeof(Box));
+  L.sort_bytes = svm::sort_scratch_bytes(nq > nt ? nq : nt);
+  L.off_sort = take(L.sort_bytes);
   L.total = o;
   return L;
 }
@@ -414,31 +544,57 @@ int run_match(const ssrlcv_sift_feature* query, uint32_t nq, const ssrlcv_sift_f
   ssrlcv_float2* lt = (ssrlcv_float2*)(ws + L.off_lt);
   Geom* geom = (Geom*)(ws + L.off_geom);
   unsigned long long* keys = (unsigned long long*)(ws + L.off_key);
-  hipLaunchKernelGGL(k_pack, dim3((L.nq_pad * 16 + 255) / 256), dim3(256), 0, st, query, nq, L.nq_pad, 0, pq, nqv,
+  const bool band = mode != 0;
+  uint32_t* permQ = band ? (uint32_t*)(ws + L.off_permq) : nullptr;
+  uint32_t* permT = band ? (uint32_t*)(ws + L.off_permt) : nullptr;
+  if (band) {
+    int rc = svm::sort_by_location(query, nq, permQ, ws + L.off_sort, L.sort_bytes, st);
+    if (rc) return rc;
+    rc = svm::sort_by_location(target, nt, permT, ws + L.off_sort, L.sort_bytes, st);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_pack, dim3((L.nq_pad * 16 + 255) / 256), dim3(256), 0, st, query, nq, L.nq_pad, 0, permQ, pq, nqv,
                      (ssrlcv_float2*)nullptr);
-  hipLaunchKernelGGL(k_pack, dim3((L.nt_pad * 16 + 255) / 256), dim3(256), 0, st, target, nt, L.nt_pad, 1, pt,
+  hipLaunchKernelGGL(k_pack, dim3((L.nt_pad * 16 + 255) / 256), dim3(256), 0, st, target, nt, L.nt_pad, 1, permT, pt,
                      (float*)nullptr, lt);
   SSRLCV_HIP_TRY(hipMemsetAsync(keys, 0xff, (size_t)L.nq_pad * 8, st));
   float eps = 0.0f;
   if (mode == 1) {
     eps = p->epsilon;
-    hipLaunchKernelGGL(k_geom, dim3((nq + 255) / 256), dim3(256), 0, st, query, nq, p->queryCamera,
+    hipLaunchKernelGGL(k_geom, dim3((L.nq_pad + 255) / 256), dim3(256), 0, st, query, nq, L.nq_pad, permQ, p->queryCamera,
                        p->targetProjection[0], p->targetProjection[1], p->targetProjection[2], p->epsilon, p->delta, geom);
   }
   if (mode == 2) {
     eps = p->epsilon;
     float* F9 = (float*)(ws + L.off_scratch);
     SSRLCV_HIP_TRY(hipMemcpyAsync(F9, p->fundamental, 9 * sizeof(float), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_geom_fundamental, dim3((nq + 255) / 256), dim3(256), 0, st, query, nq, F9, geom);
+    hipLaunchKernelGGL(k_geom_fundamental, dim3((L.nq_pad + 255) / 256), dim3(256), 0, st, query, nq, L.nq_pad, permQ, F9,
+                       geom);
   }
   uint32_t qblocks = L.nq_pad / kQPerBlock;
   uint32_t numTiles = L.nt_pad / 32;
-  // split the target range until the grid has >= 1024 blocks (4 per CU) or tiles run out
-  uint32_t splits = 1;
-  while (qblocks * splits < 1024 && splits * 2 <= numTiles && numTiles / (splits * 2) >= 16) splits *= 2;
-  uint32_t tilesPerSplit = (numTiles + splits - 1) / splits;
-  hipLaunchKernelGGL(k_match, dim3(qblocks, splits), dim3(256), 0, st, pq, pt, nqv, lt, geom, nq, nt, tilesPerSplit, mode,
-                     eps, absThreshold, keys);
+  if (band) {
+    Box* tileBox = (Box*)(ws + L.off_tilebox);
+    Box* groupBox = (Box*)(ws + L.off_groupbox);
+    const uint32_t numGroups = (numTiles + 31) / 32;
+    hipLaunchKernelGGL(k_tile_boxes, dim3((numTiles + 255) / 256), dim3(256), 0, st, lt, nt, numTiles, tileBox);
+    hipLaunchKernelGGL(k_group_boxes, dim3((numGroups + 255) / 256), dim3(256), 0, st, tileBox, numTiles, numGroups,
+                       groupBox);
+    // every wave walks all groups (most are rejected by one box test); target splits only while the grid is small
+    uint32_t splits = 1;
+    while (qblocks * splits < 512 && splits * 2 <= numGroups) splits *= 2;
+    uint32_t tilesPerSplit = ((numGroups + splits - 1) / splits) * 32;
+    hipLaunchKernelGGL(k_match<true>, dim3(qblocks, splits), dim3(256), 0, st, pq, pt, nqv, lt, geom, nq, nt,
+                       tilesPerSplit, mode, eps, absThreshold, keys, permT, tileBox, groupBox);
+  } else {
+    // split the target range until the grid has >= 1024 blocks (4 per CU) or tiles run out
+    uint32_t splits = 1;
+    while (qblocks * splits < 1024 && splits * 2 <= numTiles && numTiles / (splits * 2) >= 16) splits *= 2;
+    uint32_t tilesPerSplit = (numTiles + splits - 1) / splits;
+    hipLaunchKernelGGL(k_match<false>, dim3(qblocks, splits), dim3(256), 0, st, pq, pt, nqv, lt, geom, nq, nt,
+                       tilesPerSplit, mode, eps, absThreshold, keys, (const uint32_t*)nullptr, (const Box*)nullptr,
+                       (const Box*)nullptr);
+  }
   SSRLCV_LAUNCH_CHECK();
   return SSRLCV_OK;
 }
@@ -482,7 +638,8 @@ int ssrlcv_hip_match_u8x128(const ssrlcv_sift_feature* query, uint32_t numQuery,
   hipLaunchKernelGGL(k_finalize, dim3((numQuery + 255) / 256), dim3(256), 0, st,
                      (const unsigned long long*)((char*)workspace + L.off_key), numQuery, query, target, seedDistances,
                      params_host->queryImageID, params_host->targetImageID, params_host->relativeThreshold,
-                     params_host->absoluteThreshold, outKind, params_host->mode, out);
+                     params_host->absoluteThreshold, outKind, params_host->mode,
+                     params_host->mode != 0 ? (const uint32_t*)((char*)workspace + L.off_permq) : (const uint32_t*)nullptr, out);
   SSRLCV_LAUNCH_CHECK();
   return SSRLCV_OK;
 }
