@@ -38,8 +38,10 @@ def assert_dmatch_equal(g, o):
     assert np.array_equal(g["invalid"], o["invalid"])
     assert np.array_equal(g["distance"], o["distance"])
     ok = o["invalid"] == 0
-    for name in ("kp0_parent", "kp1_parent", "kp0_loc", "kp1_loc"):
+    for name in ("kp0_parent", "kp1_parent"):
         assert np.array_equal(g[name][ok], o[name][ok]), name
+    for name in ("kp0_loc", "kp1_loc"):  # bit patterns: locations may hold NaN in the degenerate-geometry test
+        assert np.array_equal(g[name][ok].view(np.uint32), o[name][ok].view(np.uint32)), name
 
 
 @pytest.mark.parametrize("nq,nt", [(1, 1), (37, 5), (513, 1000), (2048, 4097), (700, 33)])
@@ -164,6 +166,44 @@ def test_fundamental_constrained_matches_oracle(capi, oracle_lib):
                     assert np.array_equal(g["kp1_loc"][ok], o["kp1_loc"][ok])
         if eps == 3.0:
             assert 0 < (o["invalid"] == 0).sum() < len(q)  # the constraint bites
+
+
+def test_band_culling_is_conservative_on_degenerate_geometry(capi, oracle_lib):
+    """The spatially culled modes must give the oracle's answer whatever the locations: NaN / negative / huge
+    coordinates, all features on one spot, clusters, fewer than one tile of queries or targets, epsilon 0 and an
+    epsilon wider than the image."""
+    v = H.load_view("Pipeline2View")
+    cams = v["cameras"]
+    proj = capi.projection_matrix(cams[1:2])
+    F = np.array([[0.0, -1e-4, 0.02], [1e-4, 0.0, -0.9], [-0.03, 1.0, 40.0]], np.float32)
+    rng = np.random.default_rng(77)
+
+    def weird(n, seed):
+        f = random_features(n, seed, hi=48)
+        r = np.random.default_rng(seed)
+        loc = r.uniform(0, 1024, (n, 2)).astype(np.float32)
+        k = max(1, n // 8)
+        loc[r.choice(n, k, replace=False)] = r.uniform(300, 310, (k, 2))        # a dense cluster
+        loc[r.choice(n, max(1, n // 50), replace=False)] = np.nan
+        loc[r.choice(n, max(1, n // 50), replace=False), 0] = -50.0
+        loc[r.choice(n, max(1, n // 50), replace=False), 1] = 3.0e9
+        f["loc"] = loc
+        return f
+
+    cases = [(weird(700, 1), weird(1500, 2)), (weird(5, 3), weird(2000, 4)), (weird(900, 5), weird(7, 6))]
+    same = random_features(400, 9, hi=48)
+    same["loc"] = np.float32(512.0)
+    cases.append((same, same.copy()))
+    for q, t in cases:
+        for eps, delta in ((0.0, 0.0), (25.0, 5.0), (5000.0, 100.0)):
+            g = run_gpu(capi, 1, q, t, capi.OUT_DMATCH, eps=eps, delta=delta, cam=cams[0:1], proj=proj, absolute=3e7)
+            o = H.oracle_match_dmatch(oracle_lib, 1, 3, q, 7, t, cams[0:1], proj, eps, delta, None, REL, 3e7)
+            assert_dmatch_equal(g, o)
+            params = capi.make_match_params(2, 3, 7, eps, 0.0, REL, 3e7, fundamental=F)
+            out_d = capi.match(capi.to_dev(q), len(q), capi.to_dev(t), len(t), params, capi.OUT_UINT2_PAIR)
+            g2 = capi.to_host(out_d, H.UINT2_PAIR, len(q))
+            o2 = H.oracle_match_pairs(oracle_lib, 2, 3, q, 7, t, None, F.reshape(-1), eps, 0.0, None, REL, 3e7)
+            assert np.array_equal(g2["a"], o2["a"]) and np.array_equal(g2["b"], o2["b"])
 
 
 def test_compact_matches_is_stable(capi):
