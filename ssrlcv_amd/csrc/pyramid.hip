@@ -409,18 +409,22 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma(ConvArgs a) {
         f32x4 acc[4];
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) acc[t4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        float av[2][4];
+        float av[3][4];  // A operands are read two k-steps ahead of the MFMAs that use them
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) av[0][t4] = arow[t4 * 16];
+        if (C::KS > 1) {
+#pragma unroll
+          for (int t4 = 0; t4 < 4; ++t4) av[1][t4] = arow[t4 * 16 + 4];
+        }
 #pragma unroll
         for (int ks = 0; ks < C::KS; ++ks) {
-          if (ks + 1 < C::KS) {
+          if (ks + 2 < C::KS) {
 #pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) av[(ks + 1) & 1][t4] = arow[t4 * 16 + 4 * (ks + 1)];
+            for (int t4 = 0; t4 < 4; ++t4) av[(ks + 2) % 3][t4] = arow[t4 * 16 + 4 * (ks + 2)];
           }
-          __builtin_amdgcn_sched_barrier(0);  // keep the reads of the next k-step ahead of this k-step's MFMAs
+          __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of this k-step's MFMAs
 #pragma unroll
-          for (int t4 = 0; t4 < 4; ++t4) acc[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks & 1][t4], tz[ks], acc[t4], 0, 0, 0);
+          for (int t4 = 0; t4 < 4; ++t4) acc[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks % 3][t4], tz[ks], acc[t4], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
         // D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
@@ -447,28 +451,39 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma(ConvArgs a) {
       // vertical pass of step it - 1: output rows j = jbase + ii, ii = 0..15; B row kk is H row jbase + kk
       const int jbase = (it - 1) * kMT - 2 * R;
       if (it >= 1 && jbase + kMT > 0 && jbase < nrows) {
-        // ring slot of H row jbase + kk: one wrap at most (K <= RINGROWS)
+        // ring offsets of the H rows jbase + kk of every k-step, computed up front: left inside the loop, the
+        // add / compare / select / multiply chain sat between the MFMAs of one k-step and the LDS reads of the next
+        // and stretched a k-step from 128 to 272 cycles (measured, vertical role alone).  One wrap at most
+        // (K <= RINGROWS); padded k-steps re-read a valid row, their weight is 0.
         const int base = ((jbase % C::RINGROWS) + C::RINGROWS) % C::RINGROWS;  // wave-uniform
         const float* colp = s_ring + (w4 * 4) * 16 + li;
-        auto loadB = [&](int ks, float (&dst)[4]) {
+        int boff[C::KS];
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
           int kk = 4 * ks + lk;
-          kk = kk > C::K - 1 ? C::K - 1 : kk;             // padded k-steps re-read a valid row (their weight is 0)
+          kk = kk > C::K - 1 ? C::K - 1 : kk;
           int slot = base + kk;
           slot = slot >= C::RINGROWS ? slot - C::RINGROWS : slot;
-          const float* brow = colp + slot * C::RSTR;
+          boff[ks] = slot * C::RSTR;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        auto loadB = [&](int ks, float (&dst)[4]) {
+          const float* brow = colp + boff[ks];
 #pragma unroll
           for (int t4 = 0; t4 < 4; ++t4) dst[t4] = brow[t4 * 16];
         };
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) pend[t4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        float bv[2][4];
+        // B operands are read two k-steps ahead of the MFMAs that use them
+        float bv[3][4];
         loadB(0, bv[0]);
+        if (C::KS > 1) loadB(1, bv[1]);
 #pragma unroll
         for (int ks = 0; ks < C::KS; ++ks) {
-          if (ks + 1 < C::KS) loadB(ks + 1, bv[(ks + 1) & 1]);
+          if (ks + 2 < C::KS) loadB(ks + 2, bv[(ks + 2) % 3]);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int t4 = 0; t4 < 4; ++t4) pend[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[ks & 1][t4], tz[ks], pend[t4], 0, 0, 0);
+          for (int t4 = 0; t4 < 4; ++t4) pend[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[ks % 3][t4], tz[ks], pend[t4], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
         pendJ = jbase;
