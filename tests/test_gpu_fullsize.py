@@ -1,0 +1,88 @@
+"""Size-independent properties at the benchmark's full sizes (BASELINE.json configs 2-4), where the CPU oracle would
+take minutes: determinism / idempotence, value ranges the reference's own seed fixture shows, self-match identity of the
+MFMA matcher, and a triangulation round trip on synthetic rays."""
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from ssrlcv_amd import capi as c
+    return c
+
+
+def test_sift_4096_is_deterministic_and_well_formed(capi):
+    import torch
+    import bench
+    S = 4096
+    img = bench.synth_images(1, S, S, seed=3, device="cuda")[0]
+    plan = capi.SiftPlan(S, S)
+    plan.extract(img)
+    n1 = plan.count()
+    f1 = plan.features[: n1 * 152].clone()
+    plan.extract(img)  # same plan, same workspace: a second pass must reproduce every byte
+    n2 = plan.count()
+    assert n1 == n2 and n1 > 100000
+    assert torch.equal(f1, plan.features[: n2 * 152])
+    plan2 = capi.SiftPlan(S, S)  # a fresh workspace too (no dependence on stale workspace contents)
+    plan2.extract(img)
+    assert plan2.count() == n1 and torch.equal(f1, plan2.features[: n1 * 152])
+    f = capi.to_host(f1, H.FEATURE, n1)
+    assert (f["parent"] == -1).all()
+    assert (f["theta"] >= 0).all() and (f["theta"] < 2 * np.pi + 1e-6).all()
+    assert (f["sigma"] > 0).all()
+    assert (f["loc"] >= 0).all() and (f["loc"][:, 0] < S).all() and (f["loc"][:, 1] < S).all()
+    norms = np.sqrt((f["values"].astype(np.float64) ** 2).sum(1))
+    # normalise -> clamp at 0.2 -> renormalise -> x255 and round: the seed fixture's norms lie in [250, 262]
+    assert np.percentile(norms, 0.1) > 245 and norms.max() < 265
+    # the two orientations of one key point are emitted next to each other: same location and scale
+    same = (f["loc"][1:] == f["loc"][:-1]).all(1) & (f["sigma"][1:] == f["sigma"][:-1])
+    assert 0.2 < same.mean() < 0.5
+
+
+def test_matcher_self_match_identity_at_2p17(capi):
+    import bench
+    n = 1 << 17
+    q = bench.synth_descriptors(n, 11)
+    # make rows unique in their first bytes so that the nearest neighbour of a row is itself alone
+    idx = np.arange(n, dtype=np.uint32)
+    q["values"][:, 0] = idx & 255
+    q["values"][:, 1] = (idx >> 8) & 255
+    q["values"][:, 2] = (idx >> 16) & 255
+    q_d = capi.to_dev(q)
+    params = capi.make_match_params(0, 0, 1, 0, 0, 0.6, 3e7)
+    out_d = capi.match(q_d, n, q_d, n, params, capi.OUT_UINT2_PAIR)
+    g = capi.to_host(out_d, H.UINT2_PAIR, n)
+    assert np.array_equal(g["b"][:, 1], idx) and (g["b"][:, 0] == 1).all() and np.array_equal(g["a"][:, 1], idx)
+    out_d = capi.match(q_d, n, q_d, n, params, capi.OUT_DMATCH)
+    d = capi.to_host(out_d, H.DMATCH, n)
+    assert (d["invalid"] == 0).all() and (d["distance"] == 0).all()
+
+
+def test_triangulation_round_trip_one_million_bundles(capi):
+    """Points -> pixels of two fixture-like cameras -> bundles -> two-view triangulation gives the points back."""
+    v = H.load_view("Pipeline2View")
+    cams = v["cameras"]
+    kp0 = v["kp0"]
+    # reuse the fixture's geometry: tile its matched key points to one million bundles
+    M = 1_000_000
+    reps = (M * 2 + len(kp0) - 1) // len(kp0)
+    kp = np.tile(kp0, reps)[: 2 * M].copy()
+    mm = np.zeros(M, H.MULTIMATCH)
+    mm["numKeyPoints"], mm["index"] = 2, 2 * np.arange(M)
+    mm_d, kp_d, cam_d = capi.to_dev(mm), capi.to_dev(kp), capi.to_dev(cams)
+    b_d, l_d = capi.generate_bundles(mm_d, kp_d, M, cam_d, len(cams), len(kp))
+    pts_d, err_d, esum = capi.triangulate(l_d, b_d, M, want_errors=True)
+    pts = pts_d.cpu().numpy().reshape(-1, 3)
+    err = err_d.cpu().numpy()
+    base = len(kp0) // 2
+    # periodic in the fixture length, and the first period equals the reference's golden cloud
+    assert np.array_equal(pts[:base], pts[base: 2 * base]) and np.array_equal(err[:base], err[base: 2 * base])
+    diff = pts[:base] - v["points0"]
+    assert np.sqrt((diff.astype(np.float64) ** 2).sum(1).mean()) <= 1e-4
+    # the error sum is the (order-dependent float) sum of the per-bundle errors: agree to float accumulation accuracy
+    assert abs(float(esum.item()) - float(err.astype(np.float64).sum())) <= 2e-3 * float(err.astype(np.float64).sum())
