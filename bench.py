@@ -29,6 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (~2.5 PF)
+MFMA_I8_PEAK_TOPS = 5000.0     # dense int8 MFMA peak: twice the bf16 rate per clock (MI355X_MICROARCH.md)
 
 
 def synth_images(n, w, h, seed, device):
@@ -88,9 +89,17 @@ def bench_matcher(capi, torch, nq, nt, iters):
     tf = flops / (ms * 1e-3) / 1e12
     return {"value": pairs / (ms * 1e-3) / 1e6, "unit": "Mmatches/s", "nq": nq, "nt": nt, "ms": ms,
             "output_matches_per_s": nq / (ms * 1e-3),
-            "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tf / MFMA_F16_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "k_match (v_mfma_f32_32x32x16_f16), whole ssrlcv_hip_match_u8x128 call"}}
+            "dtype": "f16" if os.environ.get("SSRLCV_MATCH_F16") else "int8",
+            "roofline": ({"bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": tf / MFMA_F16_PEAK_TFLOPS, "traffic": None,
+                          "kernel": "k_match (v_mfma_f32_32x32x16_f16), whole ssrlcv_hip_match_u8x128 call"}
+                         if os.environ.get("SSRLCV_MATCH_F16") else
+                         {"bound": "mfma", "achieved": tf, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
+                          "frac": tf / MFMA_I8_PEAK_TOPS, "traffic": None,
+                          "frac_of_fp16_peak": tf / MFMA_F16_PEAK_TFLOPS,
+                          "kernel": "k_match_i8 (v_mfma_i32_32x32x32_i8, exact), whole ssrlcv_hip_match_u8x128 call; "
+                                    "ops = 2*128*Nq*Nt, priced against the int8 dense peak (2x the fp16 peak the "
+                                    "north star names: frac_of_fp16_peak is the same rate against that)"})}
 
 
 def bench_matcher_epipolar(capi, torch, n, size, iters):

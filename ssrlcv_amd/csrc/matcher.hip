@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <math.h>
+#include <stdlib.h>
 #include "compact.h"
 #include "device_math.h"
 #include "spatial_sort.h"
@@ -62,6 +63,8 @@ struct Geom {  // per-query epipolar segment parameters (mode 1); mode 2 keeps t
 };
 
 __host__ __device__ inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+constexpr uint32_t gcd_u32(uint32_t a, uint32_t b) { return b == 0 ? a : gcd_u32(b, a % b); }
+constexpr uint32_t lcm_u32(uint32_t a, uint32_t b) { return a / gcd_u32(a, b) * b; }
 
 // ---- pack ------------------------------------------------------------------------------------------------------
 // One wave per 4 features: 16 lanes x 8 bytes per feature.  Writes the fp16 row, the norm and (targets) the location.
@@ -417,7 +420,10 @@ __global__ __launch_bounds__(256, SSRLCV_MATCH_WPS) void k_match(const _Float16*
       }
     }
   } else {
-#if SSRLCV_MATCH_WPS >= 2
+#ifndef SSRLCV_MATCH_DB
+#define SSRLCV_MATCH_DB (SSRLCV_MATCH_WPS < 2)
+#endif
+#if !SSRLCV_MATCH_DB
   // two waves per SIMD: the partner wave hides the load latency, one register buffer suffices
   for (uint32_t tt = tile0; tt < tile1; ++tt) {
     half8 a[kKSteps];
@@ -445,6 +451,8 @@ __global__ __launch_bounds__(256, SSRLCV_MATCH_WPS) void k_match(const _Float16*
     if (q < nq && key[qt] != kNoKey) atomicMin(&bestKey[q], key[qt]);
   }
 }
+
+#include "matcher_i8.inc"
 
 // ---- finalisation: key -> reference output structs ----------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_finalize(const unsigned long long* __restrict__ bestKey, uint32_t nq,
@@ -507,19 +515,21 @@ __global__ __launch_bounds__(256) void k_seed_finalize(const unsigned long long*
 
 struct Layout {
   uint32_t nq_pad, nt_pad;
-  size_t off_pq, off_pt, off_nq, off_lt, off_geom, off_key, off_scratch, off_permq, off_permt, off_tilebox, off_groupbox,
+  size_t off_pq, off_pt, off_nq, off_nt, off_lt, off_geom, off_key, off_scratch, off_permq, off_permt, off_tilebox, off_groupbox,
       off_sort, sort_bytes, total;
 };
 
 Layout make_layout(uint32_t nq, uint32_t nt) {
   Layout L;
-  L.nq_pad = round_up(nq ? nq : 1, kQPerBlock);
+  // a multiple of both kernels' queries per block
+  L.nq_pad = round_up(nq ? nq : 1, lcm_u32(kQPerBlock, kQPerBlock8));
   L.nt_pad = round_up(nt ? nt : 1, 32);
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) / 256 * 256; return r; };
   L.off_pq = take((size_t)L.nq_pad * kKPad * 2);
   L.off_pt = take((size_t)L.nt_pad * kKPad * 2);
   L.off_nq = take((size_t)L.nq_pad * 4);
+  L.off_nt = take((size_t)L.nt_pad * 4);  // integer formulation only
   L.off_lt = take((size_t)L.nt_pad * 8);
   L.off_geom = take((size_t)L.nq_pad * sizeof(Geom));
   L.off_key = take((size_t)L.nq_pad * 8);
@@ -553,10 +563,19 @@ int run_match(const ssrlcv_sift_feature* query, uint32_t nq, const ssrlcv_sift_f
     rc = svm::sort_by_location(target, nt, permT, ws + L.off_sort, L.sort_bytes, st);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(k_pack, dim3((L.nq_pad * 16 + 255) / 256), dim3(256), 0, st, query, nq, L.nq_pad, 0, permQ, pq, nqv,
-                     (ssrlcv_float2*)nullptr);
-  hipLaunchKernelGGL(k_pack, dim3((L.nt_pad * 16 + 255) / 256), dim3(256), 0, st, target, nt, L.nt_pad, 1, permT, pt,
-                     (float*)nullptr, lt);
+  // Integer formulation (matcher_i8.inc) by default; SSRLCV_MATCH_F16=1 selects the fp16 one (same results).
+  static const bool useF16 = getenv("SSRLCV_MATCH_F16") != nullptr;
+  if (useF16) {
+    hipLaunchKernelGGL(k_pack, dim3((L.nq_pad * 16 + 255) / 256), dim3(256), 0, st, query, nq, L.nq_pad, 0, permQ, pq, nqv,
+                       (ssrlcv_float2*)nullptr);
+    hipLaunchKernelGGL(k_pack, dim3((L.nt_pad * 16 + 255) / 256), dim3(256), 0, st, target, nt, L.nt_pad, 1, permT, pt,
+                       (float*)nullptr, lt);
+  } else {
+    hipLaunchKernelGGL(k_pack_i8, dim3((L.nq_pad * 16 + 255) / 256), dim3(256), 0, st, query, nq, L.nq_pad, 0, permQ,
+                       (uint8_t*)pq, (int*)nqv, (ssrlcv_float2*)nullptr);
+    hipLaunchKernelGGL(k_pack_i8, dim3((L.nt_pad * 16 + 255) / 256), dim3(256), 0, st, target, nt, L.nt_pad, 1, permT,
+                       (uint8_t*)pt, (int*)(ws + L.off_nt), lt);
+  }
   SSRLCV_HIP_TRY(hipMemsetAsync(keys, 0xff, (size_t)L.nq_pad * 8, st));
   float eps = 0.0f;
   if (mode == 1) {
@@ -571,8 +590,9 @@ int run_match(const ssrlcv_sift_feature* query, uint32_t nq, const ssrlcv_sift_f
     hipLaunchKernelGGL(k_geom_fundamental, dim3((L.nq_pad + 255) / 256), dim3(256), 0, st, query, nq, L.nq_pad, permQ, F9,
                        geom);
   }
-  uint32_t qblocks = L.nq_pad / kQPerBlock;
+  uint32_t qblocks = L.nq_pad / (useF16 ? kQPerBlock : kQPerBlock8);
   uint32_t numTiles = L.nt_pad / 32;
+  const int* ntn = (const int*)(ws + L.off_nt);
   if (band) {
     Box* tileBox = (Box*)(ws + L.off_tilebox);
     Box* groupBox = (Box*)(ws + L.off_groupbox);
@@ -584,16 +604,26 @@ int run_match(const ssrlcv_sift_feature* query, uint32_t nq, const ssrlcv_sift_f
     uint32_t splits = 1;
     while (qblocks * splits < 512 && splits * 2 <= numGroups) splits *= 2;
     uint32_t tilesPerSplit = ((numGroups + splits - 1) / splits) * 32;
-    hipLaunchKernelGGL(k_match<true>, dim3(qblocks, splits), dim3(256), 0, st, pq, pt, nqv, lt, geom, nq, nt,
-                       tilesPerSplit, mode, eps, absThreshold, keys, permT, tileBox, groupBox);
+    if (useF16)
+      hipLaunchKernelGGL(k_match<true>, dim3(qblocks, splits), dim3(256), 0, st, pq, pt, nqv, lt, geom, nq, nt,
+                         tilesPerSplit, mode, eps, absThreshold, keys, permT, tileBox, groupBox);
+    else
+      hipLaunchKernelGGL(k_match_i8<true>, dim3(qblocks, splits), dim3(256), 0, st, (const uint8_t*)pq, (const uint8_t*)pt,
+                         (const int*)nqv, ntn, lt, geom, nq, nt, tilesPerSplit, mode, eps, absThreshold, keys, permT,
+                         tileBox, groupBox);
   } else {
     // split the target range until the grid has >= 1024 blocks (4 per CU) or tiles run out
     uint32_t splits = 1;
     while (qblocks * splits < 1024 && splits * 2 <= numTiles && numTiles / (splits * 2) >= 16) splits *= 2;
     uint32_t tilesPerSplit = (numTiles + splits - 1) / splits;
-    hipLaunchKernelGGL(k_match<false>, dim3(qblocks, splits), dim3(256), 0, st, pq, pt, nqv, lt, geom, nq, nt,
-                       tilesPerSplit, mode, eps, absThreshold, keys, (const uint32_t*)nullptr, (const Box*)nullptr,
-                       (const Box*)nullptr);
+    if (useF16)
+      hipLaunchKernelGGL(k_match<false>, dim3(qblocks, splits), dim3(256), 0, st, pq, pt, nqv, lt, geom, nq, nt,
+                         tilesPerSplit, mode, eps, absThreshold, keys, (const uint32_t*)nullptr, (const Box*)nullptr,
+                         (const Box*)nullptr);
+    else
+      hipLaunchKernelGGL(k_match_i8<false>, dim3(qblocks, splits), dim3(256), 0, st, (const uint8_t*)pq, (const uint8_t*)pt,
+                         (const int*)nqv, ntn, lt, geom, nq, nt, tilesPerSplit, mode, eps, absThreshold, keys,
+                         (const uint32_t*)nullptr, (const Box*)nullptr, (const Box*)nullptr);
   }
   SSRLCV_LAUNCH_CHECK();
   return SSRLCV_OK;

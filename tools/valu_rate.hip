@@ -68,6 +68,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define OP_CMPX(x) asm volatile("s_mov_b64 s[22:23], exec\n v_cmpx_le_f32 vcc, %0, %1\n v_fma_f32 %0, %0, %1, %2\n s_mov_b64 exec, s[22:23]" : "+v"(x) : "v"(a), "v"(b) : "s22", "s23", "vcc");
 #define OP_SALU2(x) asm volatile("v_fma_f32 %0, %0, %1, %2\n s_and_b64 s[20:21], s[20:21], exec\n s_or_b64 s[22:23], s[22:23], exec" : "+v"(x) : "v"(a), "v"(b) : "s20", "s21", "s22", "s23", "scc");
 #define OP_SMOV(x) asm volatile("v_fma_f32 %0, %0, %1, %2\n s_mov_b64 s[20:21], exec" : "+v"(x) : "v"(a), "v"(b) : "s20", "s21");
+#define OP_MADI24(x) asm volatile("v_mad_i32_i24 %0, %0, -2, %1" : "+v"(x) : "v"(iters));
+#define OP_MIN3I(x) asm volatile("v_min3_i32 %0, %0, %1, %1" : "+v"(x) : "v"(iters));
 #define OP_DSADD(x) asm volatile("ds_add_u64 %0, %1" : : "v"(ldsaddr), "v"(x64) : "memory");
 
 DEF_KERNEL(k_fma, float, INITF, OP_FMA)
@@ -87,6 +89,8 @@ DEF_KERNEL(k_fma_salu, float, INITF, OP_FMA_SALU)
 DEF_KERNEL(k_fma_nop, float, INITF, OP_FMA_NOP)
 DEF_KERNEL(k_fma_br, float, INITF, OP_FMA_BR)
 DEF_KERNEL(k_cell, float, INITF, OP_CELL)
+DEF_KERNEL(k_madi24, unsigned, INITU, OP_MADI24)
+DEF_KERNEL(k_min3i, unsigned, INITU, OP_MIN3I)
 DEF_KERNEL(k_cnd64, float, INITF, OP_CND_E64)
 DEF_KERNEL(k_cmpcnd, float, INITF, OP_CMP_CND)
 DEF_KERNEL(k_addc, unsigned, INITU, OP_ADDC)
@@ -179,7 +183,7 @@ int main() {
                  {"v_readlane_b32", k_readlane}, {"v_readfirstlane_b32", k_readfirst}, {"v_mov_b32", k_mov},
                  {"v_mov_b32 v, s", k_movs}, {"v_fma_f32 v,s,v", k_fmas}, {"v_mul_f32 s,v", k_muls},
                  {"s_mov exec; v_cmpx; v_fma; s_mov exec", k_cmpx}, {"v_fma + 2 SALU", k_salu2},
-                 {"v_fma + s_mov_b64", k_smov}, {"ds_add_u64 (conflict-free)", k_dsadd}};
+                 {"v_fma + s_mov_b64", k_smov}, {"v_mad_i32_i24", k_madi24}, {"v_min3_i32", k_min3i}, {"ds_add_u64 (conflict-free)", k_dsadd}};
   for (const Entry& e : tab) {
     printf("%-46s", e.name);
     for (int wavesPerSimd = 1; wavesPerSimd <= 8; wavesPerSimd *= 2) {
