@@ -1,6 +1,6 @@
 // ssrlcv_amd/csrc/host_merge.cpp -- host half of MatchFactory<T>::generateMatchesExhaustive
 // (src/MatchFactory.cu:943-1020): adjacency lists per (image, feature) in pair order, transitive-consistency walk
-// with std::set_intersection, flattening to MultiMatch{n,index} + member list.  Deterministic single-thread STL like
+// with std::set_intersection, flattening to MultiMatch{n,index} + member list.  Deterministic and single-threaded like
 // upstream, so every rank of a multi-GPU run reproduces the same MatchSet from the all-gathered pair arrays.
 #include <algorithm>
 #include <cstdlib>
@@ -30,42 +30,68 @@ int ssrlcv_merge_matches_host(uint32_t numImages, const uint32_t* numFeatures, u
       !numMembers)
     return SSRLCV_ERR_INVALID_ARG;
   const uint32_t V = numImages;
-  std::vector<std::vector<std::vector<U2>>> adj(V - 1);
-  for (uint32_t i = 0; i + 1 < V; ++i) adj[i].resize(numFeatures[i]);
-  const ssrlcv_uint2_pair* p = pairs;
-  for (uint32_t k = 0; k < numPairs; ++k)
-    for (uint32_t m = 0; m < pairCounts[k]; ++m, ++p) {
-      if (p->a.x >= V - 1 || p->a.y >= numFeatures[p->a.x]) return SSRLCV_ERR_INVALID_ARG;
-      adj[p->a.x][p->a.y].push_back(U2{p->b.x, p->b.y});
-    }
+  // Adjacency lists in one CSR array instead of upstream's vector<vector<vector<uint2>>> (one heap block per feature:
+  // 5 M tiny allocations for four 4096^2 views).  Entries are appended in pair order exactly like upstream's
+  // push_back, so every list has the same content and order; `len` is the mutable size (clear() = 0).
+  std::vector<size_t> base(V, 0);  // first list slot of image i (images 0..V-2 own lists)
+  for (uint32_t i = 0; i + 1 < V; ++i) base[i + 1] = base[i] + numFeatures[i];
+  const size_t numLists = base[V - 1];
+  std::vector<uint32_t> start(numLists + 1, 0), len(numLists, 0);
+  size_t total = 0;
+  {
+    const ssrlcv_uint2_pair* p = pairs;
+    for (uint32_t k = 0; k < numPairs; ++k)
+      for (uint32_t m = 0; m < pairCounts[k]; ++m, ++p) {
+        if (p->a.x >= V - 1 || p->a.y >= numFeatures[p->a.x]) return SSRLCV_ERR_INVALID_ARG;
+        ++start[base[p->a.x] + p->a.y + 1];
+        ++total;
+      }
+  }
+  if (total > 0xffffffffull) return SSRLCV_ERR_CAPACITY;
+  for (size_t l = 0; l < numLists; ++l) start[l + 1] += start[l];
+  std::vector<U2> entries(total ? total : 1);
+  {
+    const ssrlcv_uint2_pair* p = pairs;
+    for (uint32_t k = 0; k < numPairs; ++k)
+      for (uint32_t m = 0; m < pairCounts[k]; ++m, ++p) {
+        const size_t l = base[p->a.x] + p->a.y;
+        entries[start[l] + len[l]++] = U2{p->b.x, p->b.y};
+      }
+  }
+  auto list_of = [&](uint32_t img, uint32_t feat) { return base[img] + feat; };
   std::vector<ssrlcv_multimatch> mm;
   std::vector<U2> mem;
+  std::vector<U2> inter;
   for (uint32_t i = 0; i + 1 < V; ++i) {
     for (uint32_t f = 0; i + 2 < V && f < numFeatures[i]; ++f) {  // only images 0..V-3 seed multi-matches (:969)
-      std::vector<U2>* a = &adj[i][f];
-      if (a->empty()) continue;
+      const size_t a = list_of(i, f);
+      if (len[a] == 0) continue;
       bool badMatch = false;
-      std::vector<U2>* prev = a;
+      size_t prev = a;
       while (true) {
-        if (prev->begin()->x == V - 1) break;
-        std::vector<U2>* next = &adj[prev->begin()->x][prev->begin()->y];
-        if (next->empty()) break;
-        std::vector<U2> inter;
-        std::set_intersection(prev->begin(), prev->end(), next->begin(), next->end(), std::back_inserter(inter));
-        if (inter.size() != next->size()) { badMatch = true; break; }
-        else if (next->size() == 1) break;
+        const U2 head = entries[start[prev]];
+        if (head.x == V - 1) break;
+        const size_t next = list_of(head.x, head.y);
+        if (len[next] == 0) break;
+        inter.clear();
+        std::set_intersection(entries.begin() + start[prev], entries.begin() + start[prev] + len[prev],
+                              entries.begin() + start[next], entries.begin() + start[next] + len[next],
+                              std::back_inserter(inter));
+        if (inter.size() != len[next]) { badMatch = true; break; }
+        else if (len[next] == 1) break;
         else prev = next;
       }
-      if (badMatch) { a->clear(); continue; }
+      if (badMatch) { len[a] = 0; continue; }
       ssrlcv_multimatch one;
-      one.numKeyPoints = (uint32_t)a->size() + 1;
+      one.numKeyPoints = len[a] + 1;
       one.index = (int)mem.size();
       mm.push_back(one);
       mem.push_back(U2{i, f});
-      mem.insert(mem.end(), a->begin(), a->end());
-      for (auto m = a->begin(); m != a->end() - 1; ++m) {
-        if (m->x == V - 1) break;
-        adj[m->x][m->y].clear();
+      mem.insert(mem.end(), entries.begin() + start[a], entries.begin() + start[a] + len[a]);
+      for (uint32_t m = 0; m + 1 < len[a]; ++m) {
+        const U2 e = entries[start[a] + m];
+        if (e.x == V - 1) break;
+        len[list_of(e.x, e.y)] = 0;
       }
     }
   }
