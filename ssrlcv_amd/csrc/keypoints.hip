@@ -386,8 +386,8 @@ __global__ __launch_bounds__(256) void k_thetas(const OctaveState* st, const ssr
       auto sample = [&](unsigned sidx, float& x, float& y) {
         const unsigned r = __umulhi(sidx, magic);  // sidx / S, exact for sidx < 2^16
         const unsigned cc = sidx - r * (unsigned)S;
-        x = minx + (float)cc;
-        y = miny + (float)r;
+        x = minx + (float)(int)cc;  // (int): one v_cvt_f32_i32; hipcc turns the unsigned mul-hi into a 64-bit conversion
+        y = miny + (float)(int)r;
       };
       float nx, ny;
       sample((unsigned)lane, nx, ny);
@@ -534,8 +534,8 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
     auto sample = [&](unsigned sidx, float& cx, float& cy, bool& ok) {
       const unsigned r = __umulhi(sidx, magic);  // sidx / S, exact for sidx < 2^16
       const unsigned cc = sidx - r * (unsigned)S;
-      const float x = -windowWidth + (float)cc;  // integers: exact, equal to the reference's repeated += 1.0f
-      const float y = -windowWidth + (float)r;
+      const float x = -windowWidth + (float)(int)cc;  // integers: exact, equal to the reference's repeated += 1.0f
+      const float y = -windowWidth + (float)(int)r;
       cx = (x * c) + (y * s);
       cy = (-x * s) + (y * c);
       ok = sidx < total && !(fabsf(cx) > windowWidth || fabsf(cy) > windowWidth);
