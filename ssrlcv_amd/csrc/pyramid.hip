@@ -556,29 +556,49 @@ __global__ __launch_bounds__(256) void k_dog(DogArgs a) {
   for (int b = 0; b < svp::kDog; ++b) { dmn[b] = FLT_MAX; dmx[b] = -FLT_MAX; }
   size_t stride = (size_t)gridDim.x * 256 * 4;
   for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < a.n; i += stride) {
-    float4 prev = *reinterpret_cast<const float4*>(a.lvl[0] + i);
+    typedef float f32x4nt __attribute__((ext_vector_type(4)));
+    const f32x4nt p0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(a.lvl[0] + i));  // streamed once
+    float4 prev = make_float4(p0.x, p0.y, p0.z, p0.w);
     prev.x = (prev.x - lmn[0]) / (lmx[0] - lmn[0]);
     prev.y = (prev.y - lmn[0]) / (lmx[0] - lmn[0]);
     prev.z = (prev.z - lmn[0]) / (lmx[0] - lmn[0]);
     prev.w = (prev.w - lmn[0]) / (lmx[0] - lmn[0]);
 #pragma unroll
     for (int b = 0; b < svp::kDog; ++b) {
-      float4 cur = *reinterpret_cast<const float4*>(a.lvl[b + 1] + i);
+      const f32x4nt c0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(a.lvl[b + 1] + i));
+      float4 cur = make_float4(c0.x, c0.y, c0.z, c0.w);
       cur.x = (cur.x - lmn[b + 1]) / (lmx[b + 1] - lmn[b + 1]);
       cur.y = (cur.y - lmn[b + 1]) / (lmx[b + 1] - lmn[b + 1]);
       cur.z = (cur.z - lmn[b + 1]) / (lmx[b + 1] - lmn[b + 1]);
       cur.w = (cur.w - lmn[b + 1]) / (lmx[b + 1] - lmn[b + 1]);
       float4 d = make_float4(cur.x - prev.x, cur.y - prev.y, cur.z - prev.z, cur.w - prev.w);
-      *reinterpret_cast<float4*>(a.dog[b] + i) = d;
+      __builtin_nontemporal_store(f32x4nt{d.x, d.y, d.z, d.w}, reinterpret_cast<f32x4nt*>(a.dog[b] + i));
       dmn[b] = fminf(fminf(dmn[b], d.x), fminf(d.y, fminf(d.z, d.w)));
       dmx[b] = fmaxf(fmaxf(dmx[b], d.x), fmaxf(d.y, fmaxf(d.z, d.w)));
       prev = cur;
     }
   }
   if (a.dogMinMax) {
-    __shared__ float s_red[8];
+    // the five {min, max} pairs in one block reduction: wave shuffles, one barrier, ten lanes finish and commit
+    __shared__ float s_red[4][2 * svp::kDog];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int b = 0; b < svp::kDog; ++b) block_minmax_commit(dmn[b], dmx[b], a.dogMinMax + 2 * b, s_red);
+    for (int b = 0; b < svp::kDog; ++b) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        dmn[b] = fminf(dmn[b], __shfl_xor(dmn[b], o, 64));
+        dmx[b] = fmaxf(dmx[b], __shfl_xor(dmx[b], o, 64));
+      }
+      if (lane == 0) { s_red[wave][2 * b] = dmn[b]; s_red[wave][2 * b + 1] = dmx[b]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * svp::kDog) {
+      const int t = threadIdx.x;
+      float v = s_red[0][t];
+      for (int w = 1; w < 4; ++w) v = (t & 1) ? fmaxf(v, s_red[w][t]) : fminf(v, s_red[w][t]);
+      if (t & 1) atomic_max_f(a.dogMinMax + t, v);
+      else atomic_min_f(a.dogMinMax + t, v);
+    }
   }
 }
 
