@@ -115,6 +115,27 @@ __global__ __launch_bounds__(256) void k_upsample2x(const T* __restrict__ in, ui
   if (i < w * 2 && j < h * 2) out[(size_t)j * (w * 2) + i] = upsample_at(in, (int)w, (int)h, (int)i, (int)j);
 }
 
+// u8 source, four outputs per thread.  With 8-bit pixels and bilinear weights in {0, 1/4, 1/2, 1} every product and
+// partial sum of upsample_at is exact in fp32, so its result equals (sum of the four taps) / 4 evaluated in integers:
+// out(i, j) = 0.25 * (p[ym][xm] + p[ym][xp'] + p[yp'][xm] + p[yp'][xp']) with xp' = xp when i is odd, else xm (same in y).
+__global__ __launch_bounds__(256) void k_upsample2x_u8x4(const uint8_t* __restrict__ in, uint32_t w, uint32_t h,
+                                                         float* __restrict__ out) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;  // outputs 4t .. 4t+3 of row j
+  const uint32_t j = blockIdx.y;
+  if (4 * t >= 2 * w) return;
+  const uint32_t c0 = 2 * t, c1 = 2 * t + 1, c2 = (2 * t + 2 < w) ? 2 * t + 2 : w - 1;
+  const uint32_t ym = j >> 1, yp = (j & 1) ? ((ym + 1 < h) ? ym + 1 : h - 1) : ym;
+  const uint8_t* r0 = in + (size_t)ym * w;
+  const uint8_t* r1 = in + (size_t)yp * w;
+  const uint32_t a0 = r0[c0] + (uint32_t)r1[c0], a1 = r0[c1] + (uint32_t)r1[c1], a2 = r0[c2] + (uint32_t)r1[c2];
+  float4 o;
+  o.x = (float)(2 * a0) * 0.25f;
+  o.y = (float)(a0 + a1) * 0.25f;
+  o.z = (float)(2 * a1) * 0.25f;
+  o.w = (float)(a1 + a2) * 0.25f;
+  *reinterpret_cast<float4*>(out + (size_t)j * (2 * w) + 4 * t) = o;
+}
+
 // binImage(float) (src/Image.cu:1380-1392)
 __global__ __launch_bounds__(256) void k_bin2x(const float* __restrict__ in, uint32_t w, uint32_t h,
                                                float* __restrict__ out) {
@@ -750,8 +771,12 @@ int ssrlcv_hip_upsample2x(const float* in, uint32_t w, uint32_t h, float* out, s
 
 int ssrlcv_hip_upsample2x_u8(const uint8_t* in, uint32_t w, uint32_t h, float* out, ssrlcv_stream_t stream) {
   if (!in || !out || !w || !h) return SSRLCV_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(k_upsample2x<uint8_t>, dim3((2 * w + 255) / 256, 2 * h), dim3(256), 0, (hipStream_t)stream, in, w, h,
-                     out);
+  if ((w & 1) == 0 && (reinterpret_cast<size_t>(out) & 15) == 0)
+    hipLaunchKernelGGL(k_upsample2x_u8x4, dim3((2 * w / 4 + 255) / 256, 2 * h), dim3(256), 0, (hipStream_t)stream, in, w,
+                       h, out);
+  else
+    hipLaunchKernelGGL(k_upsample2x<uint8_t>, dim3((2 * w + 255) / 256, 2 * h), dim3(256), 0, (hipStream_t)stream, in, w,
+                       h, out);
   SSRLCV_LAUNCH_CHECK();
   return SSRLCV_OK;
 }
