@@ -746,7 +746,7 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
         first[d] = kp;
       };
       uint32_t* totals = nullptr;
-      hipError_t e = svc::partition<3, 32>(P, keyfn, emit, words, &totals, s);
+      hipError_t e = svc::partition<3, 64>(P, keyfn, emit, words, &totals, s);
       if (e != hipSuccess) return (int)e;
       hipLaunchKernelGGL(k_book_extrema, dim3(1), dim3(1), 0, s, st, totals, cap);
     }
