@@ -18,6 +18,8 @@
  *   filters                                   pinned by Pipeline{2,3}View/1_* fixtures
  *   S1-S14, M1-M4                             pinned jointly (consistency) by pixels fixtures + seed features + 0_KeyPoint fixtures
  *   P1c (pushbroom), P5 (SVD pseudo-inverse)  PARITY UNPINNED (no reference fixture reaches them)
+ *   F-matrix prefilter (match mode 2), Match-output ratio rules, pose LM terms (oracle_pose.c)
+ *                                             PARITY UNPINNED (restated from the reference's source only)
  */
 #ifndef SSRLCV_ORACLE_H
 #define SSRLCV_ORACLE_H

@@ -1,5 +1,7 @@
 /* oracle/oracle_match.c -- TEST INFRASTRUCTURE ONLY (see oracle.h).
  * CPU restatement of the matching leg of the hot path.
+ * Brute force + double-constrained modes and the DMatch / uint2_pair outputs are pinned by the reference's match
+ * fixtures (see oracle.h); the F-matrix constrained mode (mode 2) and the Match output kind are PARITY UNPINNED.
  */
 #include <float.h>
 #include <stdlib.h>
