@@ -195,16 +195,36 @@ __global__ __launch_bounds__(256) void k_flag_edges(const OctaveState* st, ssrlc
   }
 }
 
-// checkKeyPoints (src/SIFT_FeatureFactory.cu:449-461)
-__global__ __launch_bounds__(256) void k_flag_window(const OctaveState* st, ssrlcv_sskeypoint* kps, int w, int h,
-                                                     float pixelWidth, float lambda) {
+// removeNoise + removeEdges + checkKeyPoints (src/SIFT_FeatureFactory.cu:449-461) in one pass.  The three tests are independent per key point and the
+// compaction is stable, so one discard of their union leaves the list the three successive discards leave; used when
+// the extraction runs past stage 5 (the staged kernels above serve the per-stage stop points of the tests).
+__global__ __launch_bounds__(256) void k_flag_noise_edges_window(const OctaveState* st, ssrlcv_sskeypoint* kps, LevelSet L,
+                                                                 float noiseThr, float edgeThr, float pixelWidth,
+                                                                 float lambda) {
   int n = st->hasExtrema ? st->n : 0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     ssrlcv_sskeypoint kp = kps[i];
+    bool drop = fabsf(kp.intensity) < noiseThr;
+    {
+      int seg = segment_of(st, i);
+      const float* px = L.dog[seg];
+      float mn = L.minmax[2 * seg], mx = L.minmax[2 * seg + 1];
+      int lx = (int)roundf(kp.loc.x), ly = (int)roundf(kp.loc.y);
+      int W = L.w;
+#define NS(yy, xx) norm_sample(px, mn, mx, (size_t)(yy) * W + (xx))
+      float h00 = -2.0f * NS(ly, lx);
+      float h11 = h00 + NS(ly + 1, lx) + NS(ly - 1, lx);
+      h00 += NS(ly, lx + 1) + NS(ly, lx - 1);
+      float h01 = (NS(ly + 1, lx + 1) - NS(ly - 1, lx + 1) - NS(ly + 1, lx - 1) + NS(ly - 1, lx - 1));
+#undef NS
+      float e = h00 + h11;
+      float det = (h00 * h11) - (h01 * h01);
+      drop = drop || ((e * e / det) > edgeThr);
+    }
     float ww = kp.sigma * lambda / pixelWidth;
-    if ((kp.loc.x - ww) < 0.0f || (kp.loc.y - ww) < 0.0f || (kp.loc.x + ww) >= (unsigned)(w - 1) ||
-        (kp.loc.y + ww) >= (unsigned)(h - 1))
-      kps[i].discard = 1;
+    drop = drop || (kp.loc.x - ww) < 0.0f || (kp.loc.y - ww) < 0.0f || (kp.loc.x + ww) >= (unsigned)(L.w - 1) ||
+           (kp.loc.y + ww) >= (unsigned)(L.h - 1);
+    kps[i].discard = (uint8_t)drop;
   }
 }
 
@@ -718,7 +738,9 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
     uint32_t* words = (uint32_t*)(ws + oc.off_part);
     const uint32_t cap = oc.cap;
     // the list ping-pongs between A and B once per compaction; start so that the final list lands in A
-    const int nswaps = (stop >= 1) + 2 * (stop >= 2) + (stop >= 3) + (stop >= 4) + (stop >= 5) + (stop >= 6);
+    // stages 3-5 (noise, edges, window check) collapse into one discard when the run goes past them
+    const bool fused = stop >= 5;
+    const int nswaps = (stop >= 1) + 2 * (stop >= 2) + (fused ? 1 : (stop >= 3) + (stop >= 4)) + (stop >= 6);
     hipLaunchKernelGGL(k_state_reset, dim3(1), dim3(1), 0, s, st);
     // --- searchForExtrema (src/FeatureFactory.cu:86-159) ---
     hipLaunchKernelGGL(k_extrema_flags, dim3((oc.w + 255) / 256, (oc.h + kExtRows - 1) / kExtRows), dim3(256), 0, s, L, flags);
@@ -781,21 +803,22 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
         swap();
       }
     }
-    if (stop >= 3) {  // removeNoise(noiseThreshold)
-      hipLaunchKernelGGL(k_flag_noise, dim3(list_blocks(cap)), dim3(256), 0, s, st, cur, noiseThreshold);
+    if (fused) {  // removeNoise + removeEdges + checkKeyPoints, one discard (see k_flag_noise_edges_window)
+      hipLaunchKernelGGL(k_flag_noise_edges_window, dim3(list_blocks(cap)), dim3(256), 0, s, st, cur, L, noiseThreshold,
+                         edgeThreshold, oc.pixelWidth, plan->params.descriptorContribWidth);
       if ((e = run_discard(st, cur, oth, cap, words, s)) != hipSuccess) return (int)e;
       swap();
-    }
-    if (stop >= 4) {  // removeEdges(edgeThreshold)
-      hipLaunchKernelGGL(k_flag_edges, dim3(list_blocks(cap)), dim3(256), 0, s, st, cur, L, edgeThreshold);
-      if ((e = run_discard(st, cur, oth, cap, words, s)) != hipSuccess) return (int)e;
-      swap();
-    }
-    if (stop >= 5) {  // checkKeyPoints + discardExtrema (src/SIFT_FeatureFactory.cu:81-107)
-      hipLaunchKernelGGL(k_flag_window, dim3(list_blocks(cap)), dim3(256), 0, s, st, cur, (int)oc.w, (int)oc.h,
-                         oc.pixelWidth, plan->params.descriptorContribWidth);
-      if ((e = run_discard(st, cur, oth, cap, words, s)) != hipSuccess) return (int)e;
-      swap();
+    } else {
+      if (stop >= 3) {  // removeNoise(noiseThreshold)
+        hipLaunchKernelGGL(k_flag_noise, dim3(list_blocks(cap)), dim3(256), 0, s, st, cur, noiseThreshold);
+        if ((e = run_discard(st, cur, oth, cap, words, s)) != hipSuccess) return (int)e;
+        swap();
+      }
+      if (stop >= 4) {  // removeEdges(edgeThreshold)
+        hipLaunchKernelGGL(k_flag_edges, dim3(list_blocks(cap)), dim3(256), 0, s, st, cur, L, edgeThreshold);
+        if ((e = run_discard(st, cur, oth, cap, words, s)) != hipSuccess) return (int)e;
+        swap();
+      }
     }
     if (stop >= 6) {  // computeKeyPointOrientations (src/FeatureFactory.cu:540-632)
       if (as) SSRLCV_HIP_TRY(hipStreamWaitEvent(s, as->polarDone[o], 0));
