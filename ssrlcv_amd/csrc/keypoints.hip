@@ -357,9 +357,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int round_pos(float v) { return (int)v + (__builtin_amdgcn_fractf(v) >= 0.5f ? 1 : 0); }
 __device__ __forceinline__ float from_fixed31(unsigned long long t) { return (float)t * 4.656612873077393e-10f; }
 
-// fmodf(v, p) for |v| < 2p, exact: fmod is an exact operation and v - p is exact for p <= v < 2p (Sterbenz)
-__device__ __forceinline__ float fmod_2pi(float v, float p) {
-  return v >= p ? v - p : (v <= -p ? v + p : v);
+// fmodf(v, p) for -p < v < 2p, exact: fmod is an exact operation and v - p is exact for p <= v < 2p (Sterbenz).  That
+// range is all the sampling kernels feed it: atan2 in [-pi, pi], theta in [0, 2 pi), plus 2 pi.
+__device__ __forceinline__ float fmod_2pi_above(float v, float p) { return v >= p ? v - p : v; }
+// pixel (x, y) of a polar table: the index fits 32 bits for any level up to 65536^2, which keeps the multiply 32-bit
+__device__ __forceinline__ float2 polar_px(const float2* __restrict__ pl, int W, int x, int y) {
+  return pl[(uint32_t)y * (uint32_t)W + (uint32_t)x];
 }
 
 // ---- S13: computeThetas(SSKeyPoint) (src/FeatureFactory.cu:1004-1112) -----------------------------------------------------
@@ -412,15 +415,15 @@ __global__ __launch_bounds__(256) void k_thetas(const OctaveState* st, const ssr
       float nx, ny;
       sample((unsigned)lane, nx, ny);
       float2 npg = make_float2(0.0f, 0.0f);
-      if ((unsigned)lane < total) npg = pl[(size_t)round_pos(ny) * L.w + round_pos(nx)];
+      if ((unsigned)lane < total) npg = polar_px(pl, L.w, round_pos(nx), round_pos(ny));
       for (unsigned base = 0; base < total; base += 64) {
         const float x = nx, y = ny;
         const float2 pg = npg;
         const bool ok = base + (unsigned)lane < total;
         sample(base + 64 + (unsigned)lane, nx, ny);
-        if (base + 64 + (unsigned)lane < total) npg = pl[(size_t)round_pos(ny) * L.w + round_pos(nx)];
+        if (base + 64 + (unsigned)lane < total) npg = polar_px(pl, L.w, round_pos(nx), round_pos(ny));
         const float tx = x - kx, ty = y - ky;
-        const float angle = fmod_2pi(pg.y + (2.0f * pi), 2.0f * pi);
+        const float angle = fmod_2pi_above(pg.y + (2.0f * pi), 2.0f * pi);
         const int bin = (int)floorf(angle / rad10);
         const float wgt = __builtin_amdgcn_exp2f(((tx * tx) + (ty * ty)) * k2);
         if (ok && bin >= 0 && bin < 36)
@@ -562,7 +565,7 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
     };
     auto gather = [&](float cx, float cy) {
       // llroundf of the reference; in-range by checkKeyPoints (window + 1 pixel inside the level)
-      return pl[(size_t)round_pos(cy + ky) * L.w + round_pos(cx + kx)];
+      return polar_px(pl, L.w, round_pos(cx + kx), round_pos(cy + ky));
     };
     float ncx, ncy;
     bool nok;
@@ -577,7 +580,7 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
       if (nok) npg = gather(ncx, ncy);
       // gaussian-weighted magnitude, pre-scaled by 2^31 for the fixed-point votes (a power of two: same mantissas)
       const float mag31 = (pg.x * __builtin_amdgcn_exp2f(((cx * cx) + (cy * cy)) * k2)) * 2147483648.0f;
-      const float ang = fmod_2pi(pg.y - theta + (2.0f * pi), 2.0f * pi);
+      const float ang = fmod_2pi_above(pg.y - theta + (2.0f * pi), 2.0f * pi);
       // orientation bins: every k in 0..7 with |ang - k*rad45| < rad45 (:515-518), at most two.  Only k0-1..k0+1
       // around k0 = trunc(ang/rad45) can pass (any other k is >= 1.99 rad45 away) and k0-1, k0+1 never both do, so
       // the votes are {k0 if it passes} and {k0+1, else k0-1, if it passes}; the tests are the reference's.  A
