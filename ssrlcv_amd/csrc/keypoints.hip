@@ -714,26 +714,28 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
   const int stop = plan->stopStage;
   const uint32_t maxO = plan->params.maxOrientations;
   // The four octaves' chains are independent until the feature offsets are summed, and each is a long run of small
-  // launches (bookkeeping kernels, compactions of short lists): they run side by side on the plan's side streams, the
-  // polar tables on a fifth, all forked from and joined back into the caller's stream.
+  // launches (bookkeeping kernels, compactions of short lists): octave 0's runs on the caller's stream, the three
+  // short ones of octaves 1-3 beside it on `chain`, the polar tables on `table`, all forked from and joined back into
+  // the caller's stream.
   svp::PlanAsync* as = svp::plan_async(plan);
   const hipStream_t caller = (hipStream_t)stream;
   if (as) {
     SSRLCV_HIP_TRY(hipEventRecord(as->fork, caller));
-    for (hipStream_t sd : as->side) SSRLCV_HIP_TRY(hipStreamWaitEvent(sd, as->fork, 0));
+    SSRLCV_HIP_TRY(hipStreamWaitEvent(as->chain, as->fork, 0));
+    SSRLCV_HIP_TRY(hipStreamWaitEvent(as->table, as->fork, 0));
     if (stop >= 6) {
       for (int o = 0; o < svp::kOctaves; ++o) {
         const svp::OctavePlan& oc = plan->oct[o];
-        hipLaunchKernelGGL(k_polar, dim3((oc.w + 255) / 256, oc.h, 3), dim3(256), 0, as->side[svp::kOctaves],
+        hipLaunchKernelGGL(k_polar, dim3((oc.w + 255) / 256, oc.h, 3), dim3(256), 0, as->table,
                            make_levels(plan, ws, o), (float2*)(ws + oc.off_polar));
-        SSRLCV_HIP_TRY(hipEventRecord(as->polarDone[o], as->side[svp::kOctaves]));
+        SSRLCV_HIP_TRY(hipEventRecord(as->polarDone[o], as->table));
       }
     }
   }
   for (int o = 0; o < svp::kOctaves; ++o) {
     const svp::OctavePlan& oc = plan->oct[o];
     OctaveState* st = states + o;
-    const hipStream_t s = as ? as->side[o] : caller;
+    const hipStream_t s = (as && o > 0) ? as->chain : caller;
     LevelSet L = make_levels(plan, ws, o);
     ssrlcv_sskeypoint* A = (ssrlcv_sskeypoint*)(ws + oc.off_kpA);
     ssrlcv_sskeypoint* B = (ssrlcv_sskeypoint*)(ws + oc.off_kpB);
@@ -858,13 +860,13 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
       swap();
     }
     if (cur != A) return SSRLCV_ERR_INVALID_ARG;  // cannot happen: nswaps accounts for every swap above
-    if (as) {
+    if (as && o == svp::kOctaves - 1) {  // `chain` is in order: its last event joins octaves 1-3
       SSRLCV_HIP_TRY(hipEventRecord(as->join[o], s));
       SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->join[o], 0));
     }
   }
   if (as) {  // the polar stream joins too (its tables are read by the descriptor kernels below even when stop < 6 ran none)
-    SSRLCV_HIP_TRY(hipEventRecord(as->join[svp::kOctaves], as->side[svp::kOctaves]));
+    SSRLCV_HIP_TRY(hipEventRecord(as->join[svp::kOctaves], as->table));
     SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->join[svp::kOctaves], 0));
   }
   uint32_t* featBase = (uint32_t*)(ws + plan->oct[0].off_featBase);

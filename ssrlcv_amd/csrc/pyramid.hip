@@ -12,6 +12,7 @@
 //   * both normalisations + the DoG subtraction are one streaming kernel reading 6 levels and writing 5 (float4
 //     lanes), which also reduces the DoG levels' min/max for findKeyPoints' second normalisation.
 #include <hip/hip_runtime.h>
+#include <map>
 #include <mutex>
 #include <float.h>
 #include <math.h>
@@ -720,7 +721,21 @@ PlanAsync* plan_async(const ssrlcv_sift_plan* plan) {
       bool ok = a != nullptr;
       auto mk = [&](hipEvent_t& e) { ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
       if (ok) {
-        for (hipStream_t& st : a->side) ok = ok && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+        // per-device side streams, created once and kept for the life of the process
+        static std::map<int, std::pair<hipStream_t, hipStream_t>> pool;
+        int dev = 0;
+        ok = hipGetDevice(&dev) == hipSuccess;
+        auto it = pool.find(dev);
+        if (ok && it == pool.end()) {
+          std::pair<hipStream_t, hipStream_t> pr{nullptr, nullptr};
+          ok = hipStreamCreateWithFlags(&pr.first, hipStreamNonBlocking) == hipSuccess &&
+               hipStreamCreateWithFlags(&pr.second, hipStreamNonBlocking) == hipSuccess;
+          if (ok) it = pool.emplace(dev, pr).first;
+        }
+        if (ok) {
+          a->chain = it->second.first;
+          a->table = it->second.second;
+        }
         mk(a->fork);
         for (hipEvent_t& e : a->join) mk(e);
         for (hipEvent_t& e : a->convDone) mk(e);
@@ -913,7 +928,6 @@ void ssrlcv_sift_plan_destroy(ssrlcv_sift_plan* plan) {
   if (!plan) return;
   if (plan->async) {
     svp::PlanAsync* a = plan->async;
-    for (hipStream_t st : a->side) (void)hipStreamDestroy(st);
     (void)hipEventDestroy(a->fork);
     for (hipEvent_t e : a->join) (void)hipEventDestroy(e);
     for (hipEvent_t e : a->convDone) (void)hipEventDestroy(e);
@@ -961,7 +975,7 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
   // side stream beside the convolutions of octave o+1, which only need level 3 of octave o.  Octaves alternate between
   // two sets of gaussian buffers so that octave o+1 never overwrites what DoG(o) is still reading.
   svp::PlanAsync* as = svp::plan_async(plan);
-  hipStream_t sd = as ? as->side[svp::kOctaves] : st;
+  hipStream_t sd = as ? as->table : st;
   hipLaunchKernelGGL(k_init_minmax, dim3(1), dim3(64), 0, st, mmAll, pairs);
   // S1+S2: u8 -> f32 + one 2x upsample (startingOctave = -1)
   float* in = (float*)(ws + plan->off_in0);

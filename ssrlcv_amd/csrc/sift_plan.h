@@ -54,11 +54,17 @@ struct OctavePlan {
 };
 
 // Side streams and events of one plan.  build_dog runs the HBM-bound DoG kernel of octave o beside the FMA-bound
-// convolutions of octave o+1; describe runs the four octaves' key-point chains (many tiny launches) and the polar
-// tables side by side.  Everything is forked from and joined back into the caller's stream, so the calls keep their
-// stream-ordered semantics.  One call per plan may be in flight at a time.
+// convolutions of octave o+1 (on `table`); describe runs octave 0's key-point chain on the caller's stream, the three
+// short chains of octaves 1-3 one after the other on `chain` and the polar tables on `table`.  Everything is forked
+// from and joined back into the caller's stream, so the calls keep their stream-ordered semantics.  The two side
+// streams belong to the device, not to the plan (every plan on a device shares them): with the caller's stream that
+// makes three queues, below the four hardware queues the runtime multiplexes streams onto - with one stream per octave
+// and plan the chains were measured waiting for each other behind a shared queue.  Starting octave 0's chain and the
+// polar tables earlier, beside the convolutions of octaves 1-3, was measured too: the convolutions lose as much as the
+// chain gains (every one of these kernels fills the chip on its own), so the order below is kept.
+// One call per plan may be in flight at a time.
 struct PlanAsync {
-  hipStream_t side[kOctaves + 1];
+  hipStream_t chain, table;
   hipEvent_t fork;
   hipEvent_t join[kOctaves + 1], convDone[kOctaves], dogDone[kOctaves], polarDone[kOctaves];
 };
