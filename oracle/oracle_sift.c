@@ -139,8 +139,51 @@ static void normalize_level(float* p, size_t n, float mn, float mx) {
   for (size_t i = 0; i < n; ++i) p[i] = (p[i] - mn) / (mx - mn);
 }
 
+/* S3: src/Image.cu:572-598 addBufferBorder(float).  The new buffer comes from Unity's nullptr constructor with state gpu,
+ * which fills it from a value-initialised array (include/Unity.cuh:763-790): the border is 0.0f. */
+static float* add_border(const float* in, uint32_t w, uint32_t h, int bx, int by) {
+  uint32_t nw = w + 2 * (uint32_t)bx, nh = h + 2 * (uint32_t)by;
+  float* out = (float*)calloc((size_t)nw * nh, sizeof(float));
+  for (uint32_t y = 0; y < h; ++y) memcpy(out + (size_t)(y + by) * nw + bx, in + (size_t)y * w, sizeof(float) * w);
+  return out;
+}
+/* S3: src/Image.cu:966-995 makeBinnable(float): pad so that both sides are multiples of 2^plannedDepth.  Takes
+ * ownership of `px`, updates the size, returns the (possibly new) image. */
+static float* make_binnable(float* px, uint32_t* w, uint32_t* h, int plannedDepth) {
+  int numResize = 1 << plannedDepth; /* (int)pow(2, plannedDepth) */
+  int off[2] = {(int)(*w % (uint32_t)numResize), (int)(*h % (uint32_t)numResize)};
+  if (!off[0] && !off[1]) return px;
+  int mustSizeUp = (*w % 2) || (*h % 2); /* never true from ScaleSpace (even sizes reach here), restated for fidelity */
+  if (mustSizeUp) {
+    float* up = upsample2x(px, *w, *h);
+    free(px);
+    px = up;
+    *w *= 2;
+    *h *= 2;
+    numResize *= 2;
+    off[0] = (int)(*w % (uint32_t)numResize);
+    off[1] = (int)(*h % (uint32_t)numResize);
+  }
+  int bx = off[0] ? (numResize - (int)(*w % (uint32_t)numResize)) / 2 : 0;
+  int by = off[1] ? (numResize - (int)(*h % (uint32_t)numResize)) / 2 : 0;
+  float* padded = add_border(px, *w, *h, bx, by);
+  free(px);
+  px = padded;
+  *w += 2 * (uint32_t)bx;
+  *h += 2 * (uint32_t)by;
+  if (mustSizeUp) {
+    float* b = bin2x(px, *w, *h);
+    free(px);
+    px = b;
+    *w /= 2;
+    *h /= 2;
+  }
+  return px;
+}
+
 oracle_sift* oracle_sift_create(const uint8_t* pixels, uint32_t width, uint32_t height) {
-  if (width % 8 || height % 8) return NULL; /* makeBinnable (S3) is a no-op only for multiples of 2^3 */
+  /* ScaleSpace::ScaleSpace "too small" test (src/FeatureFactory.cu:341-345): numResize = 2^(startingOctave + depth.x) */
+  if (width / 8 == 0 || height / 8 == 0) return NULL;
   oracle_sift* s = (oracle_sift*)calloc(1, sizeof *s);
   s->W = width;
   s->H = height;
@@ -148,10 +191,17 @@ oracle_sift* oracle_sift_create(const uint8_t* pixels, uint32_t width, uint32_t 
   size_t n = (size_t)width * height;
   float* flt = (float*)malloc(sizeof(float) * n);
   for (size_t i = 0; i < n; ++i) flt[i] = (float)pixels[i];
-  /* S2: startingOctave = -1 -> one 2x upsample, pixelWidth 0.5 (FeatureFactory.cu:368-376) */
-  float* cur = upsample2x(flt, width, height);
+  /* S3 + S2 (src/FeatureFactory.cu:364-376), startingOctave = -1, depth.x = 4: even sizes are padded to multiples of
+   * 2^3 before the one 2x upsample; sizes with an odd side are upsampled first and then padded to multiples of 2^5
+   * (makeBinnable(imageSize, pixels, depth.x - i) with i = -1). */
+  uint32_t w = width, h = height;
+  int canBinEarly = (w % 2 == 0) && (h % 2 == 0);
+  if (canBinEarly) flt = make_binnable(flt, &w, &h, -1 + NUM_OCT);
+  float* cur = upsample2x(flt, w, h);
   free(flt);
-  uint32_t w = width * 2, h = height * 2;
+  w *= 2;
+  h *= 2;
+  if (!canBinEarly) cur = make_binnable(cur, &w, &h, NUM_OCT + 1);
   float pixelWidth = 1.0f;
   pixelWidth /= 2.0f;
   /* FeatureFactory.cu:383-387 with SIFT_FeatureFactory.cu:63-64 constants */

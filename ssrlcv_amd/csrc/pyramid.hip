@@ -81,6 +81,16 @@ __global__ void k_init_minmax(float* mm, int pairs) {
 }
 
 // ---- S1 / S2 / S5 ------------------------------------------------------------------------------------------------
+// S3: addBufferBorder (src/Image.cu:572-598): the image inside a zero border of (bx, by) pixels; grid = padded size
+template <typename T>
+__global__ __launch_bounds__(256) void k_add_border(const T* __restrict__ in, uint32_t w, uint32_t h, T* __restrict__ out,
+                                                    uint32_t bx, uint32_t by) {
+  const uint32_t ow = w + 2 * bx, x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= ow) return;
+  const uint32_t sx = x - bx, sy = y - by;  // wraps to a huge value left of / above the image
+  out[(size_t)y * ow + x] = (sx < w && sy < h) ? in[(size_t)sy * w + sx] : (T)0;
+}
+
 __global__ __launch_bounds__(256) void k_u8_to_f32(const uint8_t* __restrict__ in, float* __restrict__ out, size_t n) {
   size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i + 3 < n) {
@@ -848,17 +858,39 @@ int ssrlcv_hip_dog_normalised_sub(const float* const levels_host[6], const float
 // ---- plan ------------------------------------------------------------------------------------------------------------
 int ssrlcv_sift_plan_create(uint32_t w, uint32_t h, const ssrlcv_sift_params* params, ssrlcv_sift_plan** out) {
   if (!out || !params || !w || !h) return SSRLCV_ERR_INVALID_ARG;
-  if (w % 8 || h % 8) return SSRLCV_ERR_UNSUPPORTED;  // makeBinnable would have to pad (src/Image.cu:966-995)
   if (params->maxOrientations == 0 || params->maxOrientations > (uint32_t)svp::kMaxOrient) return SSRLCV_ERR_UNSUPPORTED;
   // "image too small" check of ScaleSpace::ScaleSpace (src/FeatureFactory.cu:341-345): numResize = 2^(start+depth.x)
   if (w / 8 == 0 || h / 8 == 0) return SSRLCV_ERR_INVALID_ARG;
-  // the fused Gaussian kernel needs every octave >= 64 pixels on each side (the smallest octave is W/4 x H/4)
-  if (w < 256 || h < 256) return SSRLCV_ERR_UNSUPPORTED;
+  // S3, makeBinnable as ScaleSpace::ScaleSpace applies it (src/FeatureFactory.cu:364-376, src/Image.cu:966-995): even
+  // sizes are padded to multiples of 2^(startingOctave + depth.x) = 8 before the upsample, sizes with an odd side to
+  // multiples of 2^(depth.x + 1) = 32 after it; border = (numResize - size % numResize) / 2 on both sides, zero filled
+  int padMode = 0;
+  uint32_t padX = 0, padY = 0, ow = w * 2, oh = h * 2;
+  if (w % 2 == 0 && h % 2 == 0) {
+    if (w % 8 || h % 8) {
+      padMode = 1;
+      padX = w % 8 ? (8 - w % 8) / 2 : 0;
+      padY = h % 8 ? (8 - h % 8) / 2 : 0;
+      ow = (w + 2 * padX) * 2;
+      oh = (h + 2 * padY) * 2;
+    }
+  } else if (ow % 32 || oh % 32) {
+    padMode = 2;
+    padX = ow % 32 ? (32 - ow % 32) / 2 : 0;
+    padY = oh % 32 ? (32 - oh % 32) / 2 : 0;
+    ow += 2 * padX;
+    oh += 2 * padY;
+  }
+  // the fused Gaussian kernels need every octave >= 64 pixels on each side (the smallest octave is an eighth of octave 0)
+  if (ow < 512 || oh < 512) return SSRLCV_ERR_UNSUPPORTED;
   ssrlcv_sift_plan* p = new (std::nothrow) ssrlcv_sift_plan;
   if (!p) return SSRLCV_ERR_INVALID_ARG;
   memset(p, 0, sizeof *p);
   p->W = w;
   p->H = h;
+  p->padMode = padMode;
+  p->padX = padX;
+  p->padY = padY;
   p->params = *params;
   p->stopStage = 7;
   p->async = nullptr;
@@ -868,12 +900,12 @@ int ssrlcv_sift_plan_create(uint32_t w, uint32_t h, const ssrlcv_sift_params* pa
   float mulY = sqrtf(2.0f), mulX = 2;
   sigmas[0] = sqrtf(2.0f) / 2.0f;
   for (int i = 1; i < svp::kGauss; ++i) sigmas[i] = sigmas[i - 1] * mulY;
-  uint32_t ow = w * 2, oh = h * 2;
   float pixelWidth = 1.0f;
   pixelWidth /= 2.0f;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t r = off; off += align256(bytes); return r; };
   size_t P0 = (size_t)ow * oh;
+  p->off_pad = take(padMode == 1 ? (size_t)(w + 2 * padX) * (h + 2 * padY) : padMode == 2 ? (size_t)w * h * 16 : 0);
   p->off_in0 = take(P0 * 4);
   p->off_in1 = take(P0 / 4 * 4);
   p->off_in2 = take(P0 / 16 * 4);
@@ -979,7 +1011,21 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
   hipLaunchKernelGGL(k_init_minmax, dim3(1), dim3(64), 0, st, mmAll, pairs);
   // S1+S2: u8 -> f32 + one 2x upsample (startingOctave = -1)
   float* in = (float*)(ws + plan->off_in0);
-  int rc = ssrlcv_hip_upsample2x_u8(pixels, plan->W, plan->H, in, stream);
+  int rc;
+  if (plan->padMode == 1) {  // S3 before S2: zero border around the u8 input ((float)0 == 0.0f: the order of S1 and S3 is free)
+    const uint32_t pw = plan->W + 2 * plan->padX, ph = plan->H + 2 * plan->padY;
+    uint8_t* padded = (uint8_t*)(ws + plan->off_pad);
+    hipLaunchKernelGGL(k_add_border<uint8_t>, dim3((pw + 255) / 256, ph), dim3(256), 0, st, pixels, plan->W, plan->H, padded,
+                       plan->padX, plan->padY);
+    rc = ssrlcv_hip_upsample2x_u8(padded, pw, ph, in, stream);
+  } else if (plan->padMode == 2) {  // S2 first, then the border around the upsampled image
+    float* up = (float*)(ws + plan->off_pad);
+    rc = ssrlcv_hip_upsample2x_u8(pixels, plan->W, plan->H, up, stream);
+    hipLaunchKernelGGL(k_add_border<float>, dim3((plan->oct[0].w + 255) / 256, plan->oct[0].h), dim3(256), 0, st, up,
+                       2 * plan->W, 2 * plan->H, in, plan->padX, plan->padY);
+  } else {
+    rc = ssrlcv_hip_upsample2x_u8(pixels, plan->W, plan->H, in, stream);
+  }
   if (rc) return rc;
   float* nextIn[3] = {(float*)(ws + plan->off_in1), (float*)(ws + plan->off_in2), (float*)(ws + plan->off_in1)};
   for (int o = 0; o < svp::kOctaves; ++o) {

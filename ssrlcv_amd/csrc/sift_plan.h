@@ -73,6 +73,12 @@ struct PlanAsync {
 
 struct ssrlcv_sift_plan {
   uint32_t W, H;
+  // makeBinnable (src/Image.cu:966-995) as ScaleSpace::ScaleSpace calls it (src/FeatureFactory.cu:364-376):
+  // padMode 0 = sizes already binnable; 1 = even sizes, zero border of (padX, padY) pixels added to the input before the
+  // 2x upsample (multiples of 2^3); 2 = an odd side, border added to the upsampled image (multiples of 2^5)
+  int padMode;
+  uint32_t padX, padY;
+  size_t off_pad;      // mode 1: padded u8 input; mode 2: un-padded upsampled f32 image
   ssrlcv_sift_params params;
   svp::OctavePlan oct[svp::kOctaves];
   size_t off_in0, off_in1, off_in2;

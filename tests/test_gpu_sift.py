@@ -67,8 +67,10 @@ def test_separable_gaussian_bit_exact(capi, oracle_lib, w, h, sigma, pw):
     assert mm[0] == ref.min() and mm[1] == ref.max()
 
 
-@pytest.mark.parametrize("size", [(384, 256), (256, 256)])
+@pytest.mark.parametrize("size", [(384, 256), (256, 256), (262, 260), (300, 258), (257, 263), (261, 264)])
 def test_dog_pyramid_bit_exact(capi, oracle_lib, size):
+    """Sizes 3-6 go through makeBinnable (S3): even sizes padded to multiples of 8 before the upsample (one or both
+    sides), sizes with an odd side padded to multiples of 32 after it."""
     w, h = size
     img = H.synthetic_image(w, h, seed=2)
     osf = H.OracleSift(oracle_lib, img)
@@ -139,8 +141,11 @@ def test_keypoint_stages_match_oracle(capi, oracle_lib, image_small, stage):
     assert plan.count() == total
 
 
-def test_features_match_oracle(capi, oracle_lib, image_small):
-    img = image_small
+@pytest.mark.parametrize("size", [None, (262, 260), (257, 263)])
+def test_features_match_oracle(capi, oracle_lib, image_small, size):
+    """None = the 384 x 256 image; the other two sizes run with makeBinnable's zero border (even / odd branch):
+    locations are in the padded frame on both sides."""
+    img = image_small if size is None else H.synthetic_image(size[0], size[1], seed=5)
     h, w = img.shape
     of = H.oracle_sift(oracle_lib, img)
     plan = capi.SiftPlan(w, h)
