@@ -502,18 +502,28 @@ __global__ __launch_bounds__(256) void k_thetas(const OctaveState* st, const ssr
 __device__ __forceinline__ float uniform_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
-// 4 lane-private copies of the 128 bins (4 KiB per wave) and <= 64 VGPRs: 8 waves per SIMD.  Measured on MI355X
-// (1.6 M key points of a 4096^2 image): 8 copies / 4 waves 10.4 ms, 4 copies / 8 waves 9.7 ms, 2 copies / 8 waves 10.1 ms.
-constexpr int kDescCopies = 4;
+// LDS atomics are processed one 16-lane row at a time and lanes of a row that hit the same address serialise
+// (tools/lds_atomic_rate.hip, cycles per wave-instruction per SIMD: ds_add_u32 16.5 / ds_add_u64 24.5 conflict-free and
+// with duplicates only across rows; two lanes of a row per address 24 / 49; with 4 copies and 64-bit bins, the layout
+// this kernel had first, 49-57).  So the bins are 32-bit, in 8 lane-private copies (copy = lane & 7: at most two lanes
+// of a row share a copy, they collide only when their orientation bins coincide): 4 KiB per wave and <= 64 VGPRs, 8
+// waves per SIMD.  32-bit sums need a per-key-point fixed-point scale 2^k: a bin receives at most (2 binWidth + 2)^2
+// votes (lattice points of a rotated square) of at most sqrt(2), k is the largest power with bound * 2^k < 2^31.  At the
+// pipeline's windows (w >= 14) k <= 23: the truncation of a vote is below 2^-23 of a histogram whose norm is O(1),
+// i.e. 1e-3 of a descriptor LSB.  The normalisation that follows is scale invariant, so the sums are used as they are.
+#ifndef SSRLCV_DESC_COPIES
+#define SSRLCV_DESC_COPIES 8
+#endif
+constexpr int kDescCopies = SSRLCV_DESC_COPIES;
 __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, const ssrlcv_sskeypoint* kps, LevelSet L,
                                                      float pixelWidth, float lambda, const uint32_t* featBase, int octave,
                                                      ssrlcv_sift_feature* __restrict__ features, uint32_t maxFeatures) {
   // lane-private copies of the 128 bins (copy = lane & 3, bin-major / copy-minor) keep same-address conflicts low
-  __shared__ unsigned long long s_bins[4][128 * kDescCopies];
+  __shared__ unsigned s_bins[4][(1 + 128 + 2) * kDescCopies];  // one bin of padding in front, two behind (votes of 0)
   __shared__ __attribute__((aligned(8))) uint8_t s_bytes[4][128];
   const int n = st->hasExtrema ? st->n : 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned long long* bins = s_bins[wave];
+  unsigned* bins = s_bins[wave] + kDescCopies;
   const int copy = lane & (kDescCopies - 1);
   const float pi = SSRLCV_PI_F;
   const float rad45 = pi / 4.0f;
@@ -531,7 +541,7 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
     const float c = uniform_f(cv_), s = uniform_f(sv_);
     const float2* __restrict__ pl = polar + (size_t)(seg - 1) * L.h * L.w;
 #pragma unroll
-    for (int i = 0; i < 2 * kDescCopies; ++i) bins[i * 64 + lane] = 0ull;
+    for (int i = 0; i < 2 * kDescCopies; ++i) bins[i * 64 + lane] = 0u;
     // rotated cell centres (:511-512), identical expressions to the reference's per-sample recomputation: lane i
     // evaluates cell i & 15, the 16 {x, y} pairs are then broadcast into SGPR pairs
     f32x2 rc[16];
@@ -549,11 +559,15 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
     // exp(-(r^2) / (2 w^2)) is evaluated as exp2(r^2 * k2) with k2 = -log2(e) / (2 w^2): <= 3 ulp from expf of the quotient
     const float k2 = uniform_f(-1.4426950408889634f / (2.0f * windowWidth * windowWidth));
     const int S = 2 * (int)windowWidth + 1;
+    // fixed-point scale of the votes (see kDescCopies): sqrt(2) * (windowWidth + 2)^2 * 2^k < 2^31
+    int boundExp;
+    (void)frexpf(1.4143f * ((windowWidth + 2.0f) * (windowWidth + 2.0f)), &boundExp);
+    const float voteExp = uniform_f((float)(31 - boundExp));
     // sample index -> (row, col) with a multiply-high by a per-key-point magic constant; votes are exact integers,
     // so the visiting order does not matter.  The polar gather of the next batch is issued before the current one
     // is used.
     const unsigned total = (unsigned)(S * S);
-    const unsigned magic = (unsigned)((0x100000000ull + (unsigned long long)S - 1ull) / (unsigned long long)S);
+    const unsigned magic = 0xFFFFFFFFu / (unsigned)S + 1u;  // ceil(2^32 / S): S is odd and > 1
     auto sample = [&](unsigned sidx, float& cx, float& cy, bool& ok) {
       const unsigned r = __umulhi(sidx, magic);  // sidx / S, exact for sidx < 2^16
       const unsigned cc = sidx - r * (unsigned)S;
@@ -561,7 +575,7 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
       const float y = -windowWidth + (float)(int)r;
       cx = (x * c) + (y * s);
       cy = (-x * s) + (y * c);
-      ok = sidx < total && !(fabsf(cx) > windowWidth || fabsf(cy) > windowWidth);
+      ok = sidx < total && fmaxf(fabsf(cx), fabsf(cy)) <= windowWidth;  // :505, one compare
     };
     auto gather = [&](float cx, float cy) {
       // llroundf of the reference; in-range by checkKeyPoints (window + 1 pixel inside the level)
@@ -578,52 +592,49 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
       const float2 pg = npg;
       sample(base + 64 + (unsigned)lane, ncx, ncy, nok);
       if (nok) npg = gather(ncx, ncy);
-      // gaussian-weighted magnitude, pre-scaled by 2^31 for the fixed-point votes (a power of two: same mantissas)
-      const float mag31 = (pg.x * __builtin_amdgcn_exp2f(((cx * cx) + (cy * cy)) * k2)) * 2147483648.0f;
+      // gaussian-weighted magnitude with the fixed-point scale folded into the exponent
+      const float mag31 = pg.x * __builtin_amdgcn_exp2f(fmaf((cx * cx) + (cy * cy), k2, voteExp));
       const float ang = fmod_2pi_above(pg.y - theta + (2.0f * pi), 2.0f * pi);
-      // orientation bins: every k in 0..7 with |ang - k*rad45| < rad45 (:515-518), at most two.  Only k0-1..k0+1
-      // around k0 = trunc(ang/rad45) can pass (any other k is >= 1.99 rad45 away) and k0-1, k0+1 never both do, so
-      // the votes are {k0 if it passes} and {k0+1, else k0-1, if it passes}; the tests are the reference's.  A
-      // missing vote adds 0 to an in-range bin instead of branching.
-      const int k0 = (int)(ang * inv45);
-      const float f0 = (float)k0;
-      const float a0 = fabsf(ang - (f0 * rad45));
-      const float am = fabsf(ang - ((f0 - 1.0f) * rad45));
-      const float ap = fabsf(ang - ((f0 + 1.0f) * rad45));
-      const bool h0 = (unsigned)k0 < 8u && a0 < rad45;
-      const bool hm = (unsigned)(k0 - 1) < 8u && am < rad45;
-      const bool hp = (unsigned)(k0 + 1) < 8u && ap < rad45;
-      const float aB = hp ? ap : am;
-      f32x2 mab;  // orientation weights of the two votes
-      mab.x = h0 ? 1.0f - (a0 * inv45) : 0.0f;
-      mab.y = (hp || hm) ? 1.0f - (aB * inv45) : 0.0f;
-      unsigned long long* pa = bins + (k0 & 7) * kDescCopies + copy;
-      unsigned long long* pb = bins + ((hp ? k0 + 1 : k0 - 1) & 7) * kDescCopies + copy;
-      // cells whose rotated centre lies within binWidth of the sample on both axes (:513-514); the x and y halves
-      // of the test / weight arithmetic are packed (v_pk_add_f32 / v_pk_mul_f32: same IEEE operations)
-      // `ok` is folded into the lane's threshold and the two axis tests into one compare of max(|tx|, |ty|), so a
-      // cell costs {2 v_sub, v_max, v_cmp} + {s_and_saveexec, s_cbranch_execz, s_or}: on gfx950 a scalar instruction
-      // costs 2-3 cycles of the wave's issue, not much less than a vector one (tools/valu_rate.hip)
+      // orientation bins: every k in 0..7 with |ang - k*rad45| < rad45 votes 1 - |ang - k*rad45| / rad45 (:515-518);
+      // ang lies in (-pi, 2 pi) (fmodf keeps the sign) and there is no wrap-around.  With k0 = floor(ang / rad45) and
+      // u = (ang - k0*rad45) / rad45 these are bin k0 with 1 - u and bin k0 + 1 with u, each if it exists.  The
+      // reference's float tests can also admit a third bin, or reject one of the two, when a product rounds across an
+      // integer -- with a weight within an ulp of 0 either way; those cases are not replayed.  A missing vote adds 0 to
+      // a valid word (a neighbouring cell's bin or the padding in front of / behind the histogram) instead of branching.
+      int k0 = (int)floorf(ang * inv45);
+      const float u = fabsf(ang - ((float)k0 * rad45)) * inv45;
+      const float m0 = (unsigned)k0 < 8u ? (1.0f - u) * mag31 : 0.0f;
+      const float m1 = (unsigned)(k0 + 1) < 8u ? u * mag31 : 0.0f;
+      k0 = k0 < -1 ? -1 : k0;  // k0 in -4..8 -> -1..8
+      unsigned* pa = bins + k0 * kDescCopies + copy;
+      unsigned* pb = pa + kDescCopies;
+      // cells whose rotated centre lies within binWidth of the sample on both axes (:513-514).  `ok` is folded into
+      // the lane's threshold and the two axis tests into one compare of max(|tx|, |ty|), so a cell costs {2 v_sub,
+      // v_max, v_cmp} + {s_and_saveexec, s_cbranch_execz, s_or}: on gfx950 a scalar instruction costs 2-3 cycles of
+      // the wave's issue, not much less than a vector one (tools/valu_rate.hip).  A passing cell costs two fused
+      // 1 - t/binWidth, their product and one multiply per vote: (wxy * wk) * mag of the reference becomes
+      // wxy * (wk * mag), and 1 - t * (1/binWidth) has one rounding instead of two -- a few ulp on a vote, against a
+      // quantisation step of 2^-8 of the normalised histogram.
       const float bwl = ok ? binWidth : -1.0f;
 #pragma unroll
       for (int cell = 0; cell < 16; ++cell) {
         const float tx = fabsf(rc[cell].x - cx), ty = fabsf(rc[cell].y - cy);
         if (fmaxf(tx, ty) <= bwl) {
-          const float wxy = (1.0f - (tx * invBin)) * (1.0f - (ty * invBin));
-          atomicAdd(pa + cell * 8 * kDescCopies, (unsigned long long)(unsigned)((wxy * mab.x) * mag31));  // (wxy * wk) * mag
-          atomicAdd(pb + cell * 8 * kDescCopies, (unsigned long long)(unsigned)((wxy * mab.y) * mag31));
+          const float wxy = fmaf(-tx, invBin, 1.0f) * fmaf(-ty, invBin, 1.0f);
+          atomicAdd(pa + cell * 8 * kDescCopies, (unsigned)(wxy * m0));
+          atomicAdd(pb + cell * 8 * kDescCopies, (unsigned)(wxy * m1));
         }
       }
     }
     __builtin_amdgcn_wave_barrier();
     // normalise, clamp at 0.2, renormalise, quantise (:529-542); each lane owns bins lane and lane + 64
-    unsigned long long t0 = 0ull, t1 = 0ull;
+    unsigned t0 = 0u, t1 = 0u;
 #pragma unroll
     for (int cpy = 0; cpy < kDescCopies; ++cpy) {
       t0 += bins[lane * kDescCopies + cpy];
       t1 += bins[(lane + 64) * kDescCopies + cpy];
     }
-    float v0 = from_fixed31(t0), v1 = from_fixed31(t1);
+    float v0 = (float)t0, v1 = (float)t1;
     float sq = sqrtf(sv::wave_sum((v0 * v0) + (v1 * v1)));
     v0 = v0 / sq;
     v1 = v1 / sq;
