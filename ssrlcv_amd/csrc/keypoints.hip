@@ -376,13 +376,14 @@ template <int MAXO>
 __global__ __launch_bounds__(256) void k_thetas(const OctaveState* st, const ssrlcv_sskeypoint* kps, LevelSet L,
                                                 float pixelWidth, float lambda, float orientationThreshold,
                                                 float* __restrict__ thetas, uint32_t* __restrict__ thetaCnt) {
-  __shared__ unsigned long long s_hist[4][36 * 8];
+  __shared__ unsigned long long s_hist[4][36 * 16];  // 16 lane-private copies: no two lanes of a 16-lane row share a word
   const int n = st->hasExtrema ? st->n : 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned long long* hist = s_hist[wave];
-  const int copy = lane & 7;
+  const int copy = lane & 15;
   const float pi = SSRLCV_PI_F;
   const float rad10 = pi / 18.0f;
+  const float inv10 = 1.0f / rad10;
   const float2* __restrict__ polar = L.polar;  // key points live on levels 1..3, whose polar tables are always built
   for (int gi = blockIdx.x * 4 + wave; gi < n; gi += gridDim.x * 4) {
     const int seg = __builtin_amdgcn_readfirstlane(segment_of(st, gi));
@@ -396,8 +397,7 @@ __global__ __launch_bounds__(256) void k_thetas(const OctaveState* st, const ssr
     for (int i = 0; i < MAXO; ++i) outTheta[i] = -FLT_MAX;
     if (!(minx < 0.0f || miny < 0.0f || maxx >= (unsigned)(L.w - 1) || maxy >= (unsigned)(L.h - 1))) {
 #pragma unroll
-      for (int i = 0; i < 5; ++i)
-        if (i * 64 + lane < 36 * 8) hist[i * 64 + lane] = 0ull;
+      for (int i = 0; i < 9; ++i) hist[i * 64 + lane] = 0ull;
       __builtin_amdgcn_wave_barrier();
       const float2* __restrict__ pl = polar + (size_t)(seg - 1) * L.h * L.w;
       const float weight = 2.0f * lambda * lambda * kp.sigma * kp.sigma;
@@ -424,17 +424,23 @@ __global__ __launch_bounds__(256) void k_thetas(const OctaveState* st, const ssr
         if (base + 64 + (unsigned)lane < total) npg = polar_px(pl, L.w, round_pos(nx), round_pos(ny));
         const float tx = x - kx, ty = y - ky;
         const float angle = fmod_2pi_above(pg.y + (2.0f * pi), 2.0f * pi);
-        const int bin = (int)floorf(angle / rad10);
+        // bin = floor(angle / rad10) (:1041) without the 12-instruction IEEE division: angle * (1 / rad10) is within
+        // 1e-5 of the quotient (bins < 36), so its floor is the quotient's floor unless it lies within 1e-4 of an
+        // integer; only then (about one batch in a hundred) the wave takes the exact division.
+        const float q = angle * inv10;
+        float fbin = floorf(q);
+        if (__ballot(fabsf(q - rintf(q)) < 1.0e-4f) != 0ull) fbin = floorf(angle / rad10);
+        const int bin = (int)fbin;
         const float wgt = __builtin_amdgcn_exp2f(((tx * tx) + (ty * ty)) * k2);
         if (ok && bin >= 0 && bin < 36)
-          atomicAdd(&hist[bin * 8 + copy], (unsigned long long)(unsigned)((pg.x * wgt) * 2147483648.0f));
+          atomicAdd(&hist[bin * 16 + copy], (unsigned long long)(unsigned)((pg.x * wgt) * 2147483648.0f));
       }
       __builtin_amdgcn_wave_barrier();
       float hb = 0.0f;
       if (lane < 36) {
         unsigned long long t = 0ull;
 #pragma unroll
-        for (int cpy = 0; cpy < 8; ++cpy) t += hist[lane * 8 + cpy];
+        for (int cpy = 0; cpy < 16; ++cpy) t += hist[lane * 16 + cpy];
         hb = from_fixed31(t);
       }
       const float hprev = __shfl(hb, (lane + 35) % 36, 64);
