@@ -168,6 +168,7 @@ struct ConvArgs {
   float* minmax;  // nullable
   uint32_t w, h;
   uint32_t rowsPerBlock;
+  uint32_t x0base;  // first column of the launch's first strip (k_gauss_fused on the partial last strip)
   float wgt[33];  // taps are symmetric (w[k] == w[2R-k] bit for bit): only k = 0..R travel, in SGPRs
 };
 
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(kTX) void k_gauss_fused(ConvArgs a) {
   float* s_h = reinterpret_cast<float*>(&s_h4[0][0]);
 
   const int W = (int)a.w, H = (int)a.h;
-  const int x0 = blockIdx.x * kTX;
+  const int x0 = (int)a.x0base + blockIdx.x * kTX;
   const int y0 = blockIdx.y * (int)a.rowsPerBlock;
   int nrows = (int)a.rowsPerBlock;
   if (y0 + nrows > H) nrows = H - y0;
@@ -276,6 +277,124 @@ __global__ __launch_bounds__(kTX) void k_gauss_fused(ConvArgs a) {
         int j = s * kNR - 2 * R + i;
         if (j >= 0 && j < nrows && gx < W) {
           a.out[(size_t)(y0 + j) * W + gx] = vs[i];
+          mn = fminf(mn, vs[i]);
+          mx = fmaxf(mx, vs[i]);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * R; ++k) win[k] = win[k + kNR];
+  }
+  if (a.minmax) block_minmax_commit(mn, mx, a.minmax, s_h);
+}
+
+// The same kernel for strips that lie fully inside the image (x0 + 256 <= W, rows 16-byte aligned): the per-element
+// mirror / address arithmetic of the generic staging above was as many VALU instructions as the 16 (2R + 1) FMAs of a
+// step.  Here a wave stages two whole rows per step: the row index is wave-uniform (mirrored in SGPRs), every lane loads
+// one float4 of the strip's interior and lanes 0 .. 2 RP - 1 one halo float each (columns mirrored once, outside the
+// loop); stores go to a uniform row base.  Passes and summation order are identical, so are the results.
+template <int R>
+__global__ __launch_bounds__(kTX) void k_gauss_strip(ConvArgs a) {
+  constexpr int RP = (R + 3) / 4 * 4;
+  constexpr int SW = kTX + 2 * RP;
+  constexpr int WIN = 2 * R + kNR;
+  constexpr int HQ = (2 * RP + 8) / 4;
+  static_assert(kNR == 8 && kTX == 256, "two rows per wave and step");
+  __shared__ float4 s_in4[kNR][SW / 4];
+  __shared__ float4 s_h4[kNR][kTX / 4];
+  float* s_in = reinterpret_cast<float*>(&s_in4[0][0]);
+  float* s_h = reinterpret_cast<float*>(&s_h4[0][0]);
+
+  const int W = (int)a.w, H = (int)a.h;
+  const int x0 = blockIdx.x * kTX;  // host: x0 + kTX <= W
+  const int y0 = blockIdx.y * (int)a.rowsPerBlock;
+  int nrows = (int)a.rowsPerBlock;
+  if (y0 + nrows > H) nrows = H - y0;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hr = tid >> 5, hq = (tid & 31) * 2;  // horizontal-pass role: row hr, outputs 8*(tid&31) .. +7
+
+  // halo role: lane h < RP owns column x0 - RP + h, lane RP <= h < 2 RP column x0 + 256 + (h - RP)
+  const bool halo = lane < 2 * RP;
+  int hx = lane < RP ? x0 - RP + lane : x0 + kTX + (lane - RP);
+  hx = hx > W - 1 + R ? W - 1 + R : hx;
+  hx = hx < 0 ? -1 - hx : hx;              // sym_coord for -l <= i < 0
+  hx = hx > W - 1 ? 2 * W - 1 - hx : hx;   // sym_coord for l <= i < 2l
+  const int hl = lane < RP ? lane : kTX + lane;  // its column in the staged row: the right halo starts at RP + 256
+
+  float win[WIN];
+#pragma unroll
+  for (int k = 0; k < WIN; ++k) win[k] = 0.0f;
+  float mn = FLT_MAX, mx = -FLT_MAX;
+  const int steps = (nrows + 2 * R + kNR - 1) / kNR;
+  float4 preI0, preI1;  // next step's two rows of this wave (named scalars: an indexed pair went to scratch)
+  float preH0 = 0.0f, preH1 = 0.0f;
+  auto row_of = [&](int y) {  // wave-uniform mirrored row
+    y = y > H - 1 + R ? H - 1 + R : y;
+    y = y < 0 ? -1 - y : y;
+    y = y > H - 1 ? 2 * H - 1 - y : y;
+    return a.in + (size_t)y * W;
+  };
+  auto fetch = [&](int s) {
+    const int ybase = y0 - R + s * kNR + 2 * wave;
+    const float* r0 = row_of(ybase);
+    const float* r1 = row_of(ybase + 1);
+    preI0 = *reinterpret_cast<const float4*>(r0 + x0 + 4 * lane);
+    preI1 = *reinterpret_cast<const float4*>(r1 + x0 + 4 * lane);
+    if (halo) {
+      preH0 = r0[hx];
+      preH1 = r1[hx];
+    }
+  };
+  fetch(0);
+  const int gx = x0 + tid;
+  for (int s = 0; s < steps; ++s) {
+    s_in4[2 * wave][RP / 4 + lane] = preI0;
+    s_in4[2 * wave + 1][RP / 4 + lane] = preI1;
+    if (halo) {
+      s_in[(2 * wave) * SW + hl] = preH0;
+      s_in[(2 * wave + 1) * SW + hl] = preH1;
+    }
+    __syncthreads();
+    if (s + 1 < steps) fetch(s + 1);  // global loads stay in flight under the two passes below
+    {
+      float o[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = 0.0f;
+#pragma unroll
+      for (int q = 0; q < HQ; ++q) {
+        float4 v4 = s_in4[hr][hq + q];
+        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int k = 4 * q + j - (RP - R) - i;
+            if (k >= 0 && k <= 2 * R) o[i] = __builtin_fmaf(v[j], a.wgt[k <= R ? k : 2 * R - k], o[i]);
+          }
+        }
+      }
+      s_h4[hr][hq] = make_float4(o[0], o[1], o[2], o[3]);
+      s_h4[hr][hq + 1] = make_float4(o[4], o[5], o[6], o[7]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kNR; ++i) win[2 * R + i] = s_h[i * kTX + tid];
+    if (s * kNR + kNR - 1 >= 2 * R) {
+      float vs[kNR];
+#pragma unroll
+      for (int i = 0; i < kNR; ++i) vs[i] = 0.0f;
+#pragma unroll
+      for (int k = 0; k <= 2 * R; ++k) {
+#pragma unroll
+        for (int i = 0; i < kNR; ++i) vs[i] = __builtin_fmaf(win[i + k], a.wgt[k <= R ? k : 2 * R - k], vs[i]);
+      }
+      float* orow = a.out + (size_t)(y0 + s * kNR - 2 * R) * W + gx;
+#pragma unroll
+      for (int i = 0; i < kNR; ++i) {
+        const int j = s * kNR - 2 * R + i;  // uniform
+        if (j >= 0 && j < nrows) {
+          orow[(size_t)i * W] = vs[i];
           mn = fminf(mn, vs[i]);
           mx = fmaxf(mx, vs[i]);
         }
@@ -646,6 +765,7 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
   a.minmax = minmax;
   a.w = w;
   a.h = h;
+  a.x0base = 0;
   memset(a.wgt, 0, sizeof a.wgt);
   // pad the tap set symmetrically into the smallest templated radius: extra taps carry weight 0 and would change
   // the fmaf chain (0*x + s is exact, so the result is identical) -- only exact radii are dispatched below anyway.
@@ -662,21 +782,35 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
   rows = (rows + kNR - 1) / kNR * kNR;
   a.rowsPerBlock = rows;
   dim3 grid(bx, (h + rows - 1) / rows);
-  // Two bit-identical formulations.  Measured per 8192^2 level on MI355X (ms, taps 13/17/23/33/47/65): VALU marching
-  // kernel 0.148/0.156/0.251/0.239/0.370/0.382, f32-MFMA banded Toeplitz 0.172/0.159/0.186/0.209/0.237/0.269 -- the band
-  // wastes (16 + 2R - taps) / (16 + 2R) of the matrix pipe, more than half at R = 6.  Default: MFMA from 23 taps up.
-  // SSRLCV_GAUSS_VALU=1 / SSRLCV_GAUSS_MFMA=1 force one of them for every radius.
+  // Two bit-identical formulations.  Measured per 16384^2 level on MI355X (ms, taps 13/17/23/33/47/65): VALU marching
+  // kernel (row-staged strips) 0.464/0.517/0.690/0.654/1.120/1.102, f32-MFMA banded Toeplitz -/-/0.613/0.669/0.770/0.875
+  // -- the band wastes (16 + 2R - taps) / (16 + 2R) of the matrix pipe, more than half at R = 6, and the VALU kernel is
+  // within 12 % of copy speed there.  Default: MFMA from 23 taps up.  SSRLCV_GAUSS_VALU=1 / SSRLCV_GAUSS_MFMA=1 force
+  // one of them for every radius.
   static const bool forceValu = getenv("SSRLCV_GAUSS_VALU") != nullptr, forceMfma = getenv("SSRLCV_GAUSS_MFMA") != nullptr;
   const bool useMfma = forceMfma || (!forceValu && RT >= 11);
   if (!useMfma) {
+    // full strips with 16-byte aligned rows take the row-staged kernel, a partial last strip (or everything, when the
+    // rows are not aligned) the generic one
+    const bool aligned = (w & 3) == 0 && (reinterpret_cast<size_t>(in) & 15) == 0;
+    const uint32_t nFull = aligned ? w / kTX : 0;
+#define SSRLCV_LAUNCH_VALU(RR)                                                                              \
+  do {                                                                                                       \
+    if (nFull) hipLaunchKernelGGL(k_gauss_strip<RR>, dim3(nFull, grid.y), dim3(kTX), 0, st, a);              \
+    if (nFull < bx) {                                                                                        \
+      a.x0base = nFull * kTX;                                                                                \
+      hipLaunchKernelGGL(k_gauss_fused<RR>, dim3(bx - nFull, grid.y), dim3(kTX), 0, st, a);                  \
+    }                                                                                                        \
+  } while (0)
     switch (RT) {
-      case 6: hipLaunchKernelGGL(k_gauss_fused<6>, grid, dim3(kTX), 0, st, a); break;
-      case 8: hipLaunchKernelGGL(k_gauss_fused<8>, grid, dim3(kTX), 0, st, a); break;
-      case 11: hipLaunchKernelGGL(k_gauss_fused<11>, grid, dim3(kTX), 0, st, a); break;
-      case 16: hipLaunchKernelGGL(k_gauss_fused<16>, grid, dim3(kTX), 0, st, a); break;
-      case 23: hipLaunchKernelGGL(k_gauss_fused<23>, grid, dim3(kTX), 0, st, a); break;
-      default: hipLaunchKernelGGL(k_gauss_fused<32>, grid, dim3(kTX), 0, st, a); break;
+      case 6: SSRLCV_LAUNCH_VALU(6); break;
+      case 8: SSRLCV_LAUNCH_VALU(8); break;
+      case 11: SSRLCV_LAUNCH_VALU(11); break;
+      case 16: SSRLCV_LAUNCH_VALU(16); break;
+      case 23: SSRLCV_LAUNCH_VALU(23); break;
+      default: SSRLCV_LAUNCH_VALU(32); break;
     }
+#undef SSRLCV_LAUNCH_VALU
   } else {
     // one or two blocks are resident per CU (LDS): size the strips so that the launch is about one round of them;
     // 16-row steps, at least 4 steps of payload per 2R halo
