@@ -378,7 +378,8 @@ __global__ __launch_bounds__(256) void k_thetas(const OctaveState* st, const ssr
                                                 float* __restrict__ thetas, uint32_t* __restrict__ thetaCnt) {
   __shared__ unsigned long long s_hist[4][36 * 16];  // 16 lane-private copies: no two lanes of a 16-lane row share a word
   const int n = st->hasExtrema ? st->n : 0;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the wave index as a scalar: key-point index, list loads and per-key-point constants then live in SGPRs
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   unsigned long long* hist = s_hist[wave];
   const int copy = lane & 15;
   const float pi = SSRLCV_PI_F;
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(256) void k_thetas(const OctaveState* st, const ssr
       const float k2 = -1.4426950408889634f / weight;
       const int S = 2 * (int)windowWidth + 1;
       const unsigned total = (unsigned)(S * S);
-      const unsigned magic = (unsigned)((0x100000000ull + (unsigned long long)S - 1ull) / (unsigned long long)S);
+      const unsigned magic = 0xFFFFFFFFu / (unsigned)S + 1u;  // ceil(2^32 / S): S is odd and > 1
       auto sample = [&](unsigned sidx, float& x, float& y) {
         const unsigned r = __umulhi(sidx, magic);  // sidx / S, exact for sidx < 2^16
         const unsigned cc = sidx - r * (unsigned)S;
@@ -508,6 +509,44 @@ __global__ __launch_bounds__(256) void k_thetas(const OctaveState* st, const ssr
 __device__ __forceinline__ float uniform_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
+// Per-key-point constants of k_descriptors, computed one key point per LANE by a pre-pass: in the wave-per-key-point
+// kernel the same arithmetic (sincosf alone is ~100 instructions) ran once per WAVE, 64 lanes wide on a single value,
+// and was 9 % of its instructions.  The descriptor kernel fetches the 32-byte record with one scalar load.
+struct DescConst {
+  float c, s;           // cos / sin of -theta (:497-498)
+  float windowWidth;    // ceil(sigma * lambda / pixelWidth) (:487)
+  float invBin;         // 1 / binWidth, binWidth = windowWidth / 2
+  float k2;             // -log2(e) / (2 windowWidth^2): exp(-(r^2) / (2 w^2)) == exp2(r^2 * k2) to <= 3 ulp
+  float voteExp;        // fixed-point exponent of the votes (see kDescCopies)
+  uint32_t magic;       // ceil(2^32 / S), S = 2 windowWidth + 1: sample index -> row by a multiply-high
+  int32_t segment;      // blur segment of the key point = DoG level its window is sampled from
+};
+static_assert(sizeof(DescConst) == 32, "one s_load_dwordx8");
+__global__ __launch_bounds__(256) void k_desc_consts(const OctaveState* st, const ssrlcv_sskeypoint* kps, float pixelWidth,
+                                                     float lambda, DescConst* __restrict__ out) {
+  const int n = st->hasExtrema ? st->n : 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    DescConst d;
+    const float theta = kps[i].theta;
+    float sv, cv;
+    sincosf(-theta, &sv, &cv);
+    d.c = cv;
+    d.s = sv;
+    d.windowWidth = ceilf(kps[i].sigma * lambda / pixelWidth);
+    const float binWidth = d.windowWidth / 2.0f;
+    d.invBin = 1.0f / binWidth;  // hx / binWidth is evaluated as hx * (1/binWidth): <= 1 ulp off
+    d.k2 = -1.4426950408889634f / (2.0f * d.windowWidth * d.windowWidth);
+    // sqrt(2) * (windowWidth + 2)^2 * 2^k < 2^31
+    int boundExp;
+    (void)frexpf(1.4143f * ((d.windowWidth + 2.0f) * (d.windowWidth + 2.0f)), &boundExp);
+    d.voteExp = (float)(31 - boundExp);
+    const unsigned S = 2u * (unsigned)(int)d.windowWidth + 1u;
+    d.magic = 0xFFFFFFFFu / S + 1u;  // S is odd and > 1
+    d.segment = segment_of(st, i);
+    out[i] = d;
+  }
+}
+
 // LDS atomics are processed one 16-lane row at a time and lanes of a row that hit the same address serialise
 // (tools/lds_atomic_rate.hip, cycles per wave-instruction per SIMD: ds_add_u32 16.5 / ds_add_u64 24.5 conflict-free and
 // with duplicates only across rows; two lanes of a row per address 24 / 49; with 4 copies and 64-bit bins, the layout
@@ -522,13 +561,15 @@ __device__ __forceinline__ float uniform_f(float v) {
 #endif
 constexpr int kDescCopies = SSRLCV_DESC_COPIES;
 __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, const ssrlcv_sskeypoint* kps, LevelSet L,
-                                                     float pixelWidth, float lambda, const uint32_t* featBase, int octave,
+                                                     float pixelWidth, const DescConst* __restrict__ consts,
+                                                     const uint32_t* featBase, int octave,
                                                      ssrlcv_sift_feature* __restrict__ features, uint32_t maxFeatures) {
   // lane-private copies of the 128 bins (copy = lane & 3, bin-major / copy-minor) keep same-address conflicts low
   __shared__ unsigned s_bins[4][(1 + 128 + 2) * kDescCopies];  // one bin of padding in front, two behind (votes of 0)
   __shared__ __attribute__((aligned(8))) uint8_t s_bytes[4][128];
   const int n = st->hasExtrema ? st->n : 0;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the wave index as a scalar: key-point index, list loads and per-key-point constants then live in SGPRs
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   unsigned* bins = s_bins[wave] + kDescCopies;
   const int copy = lane & (kDescCopies - 1);
   const float pi = SSRLCV_PI_F;
@@ -536,15 +577,14 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
   const float inv45 = 1.0f / rad45;
   const float2* __restrict__ polar = L.polar;  // key points live on levels 1..3, whose polar tables are always built
   for (int gi = blockIdx.x * 4 + wave; gi < n; gi += gridDim.x * 4) {
-    const int seg = __builtin_amdgcn_readfirstlane(segment_of(st, gi));
+    const DescConst dc = consts[gi];  // gi is wave-uniform: scalar loads
     const ssrlcv_sskeypoint kp = kps[gi];
-    const float kx = uniform_f(kp.loc.x), ky = uniform_f(kp.loc.y);
-    const float theta = uniform_f(kp.theta);
-    const float windowWidth = uniform_f(ceilf(kp.sigma * lambda / pixelWidth));
-    const float binWidth = uniform_f(windowWidth / 2.0f);
-    float sv_, cv_;
-    sincosf(-theta, &sv_, &cv_);
-    const float c = uniform_f(cv_), s = uniform_f(sv_);
+    const int seg = dc.segment;
+    const float kx = kp.loc.x, ky = kp.loc.y;
+    const float theta = kp.theta;
+    const float windowWidth = dc.windowWidth;
+    const float binWidth = windowWidth / 2.0f;
+    const float c = dc.c, s = dc.s;
     const float2* __restrict__ pl = polar + (size_t)(seg - 1) * L.h * L.w;
 #pragma unroll
     for (int i = 0; i < 2 * kDescCopies; ++i) bins[i * 64 + lane] = 0u;
@@ -561,19 +601,13 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
         rc[cell].y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ry), cell));
       }
     }
-    const float invBin = uniform_f(1.0f / binWidth);  // hx / binWidth is evaluated as hx * (1/binWidth): <= 1 ulp off
-    // exp(-(r^2) / (2 w^2)) is evaluated as exp2(r^2 * k2) with k2 = -log2(e) / (2 w^2): <= 3 ulp from expf of the quotient
-    const float k2 = uniform_f(-1.4426950408889634f / (2.0f * windowWidth * windowWidth));
+    const float invBin = dc.invBin, k2 = dc.k2, voteExp = dc.voteExp;
     const int S = 2 * (int)windowWidth + 1;
-    // fixed-point scale of the votes (see kDescCopies): sqrt(2) * (windowWidth + 2)^2 * 2^k < 2^31
-    int boundExp;
-    (void)frexpf(1.4143f * ((windowWidth + 2.0f) * (windowWidth + 2.0f)), &boundExp);
-    const float voteExp = uniform_f((float)(31 - boundExp));
     // sample index -> (row, col) with a multiply-high by a per-key-point magic constant; votes are exact integers,
     // so the visiting order does not matter.  The polar gather of the next batch is issued before the current one
     // is used.
     const unsigned total = (unsigned)(S * S);
-    const unsigned magic = 0xFFFFFFFFu / (unsigned)S + 1u;  // ceil(2^32 / S): S is odd and > 1
+    const unsigned magic = dc.magic;
     auto sample = [&](unsigned sidx, float& cx, float& cy, bool& ok) {
       const unsigned r = __umulhi(sidx, magic);  // sidx / S, exact for sidx < 2^16
       const unsigned cc = sidx - r * (unsigned)S;
@@ -895,9 +929,13 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
     for (int o = 0; o < svp::kOctaves; ++o) {
       const svp::OctavePlan& oc = plan->oct[o];
       LevelSet L = make_levels(plan, ws, o);
+      DescConst* consts = (DescConst*)(ws + oc.off_descConst);
+      hipLaunchKernelGGL(k_desc_consts, dim3(list_blocks(oc.cap)), dim3(256), 0, caller, states + o,
+                         (const ssrlcv_sskeypoint*)(ws + oc.off_kpA), oc.pixelWidth, plan->params.descriptorContribWidth,
+                         consts);
       hipLaunchKernelGGL(k_descriptors, dim3(list_blocks(oc.cap) * 2), dim3(256), 0, caller, states + o,
-                         (const ssrlcv_sskeypoint*)(ws + oc.off_kpA), L, oc.pixelWidth,
-                         plan->params.descriptorContribWidth, featBase, o, features, plan->maxFeatures);
+                         (const ssrlcv_sskeypoint*)(ws + oc.off_kpA), L, oc.pixelWidth, (const DescConst*)consts, featBase, o,
+                         features, plan->maxFeatures);
     }
   }
   SSRLCV_LAUNCH_CHECK();

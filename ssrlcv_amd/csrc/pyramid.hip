@@ -1075,6 +1075,7 @@ int ssrlcv_sift_plan_create(uint32_t w, uint32_t h, const ssrlcv_sift_params* pa
                    (size_t)svp::kDog * 4 * (((size_t)cap * svp::kMaxOrient + 2047) / 2048) + 16;
     oc.off_part = take(words * 4);
     oc.off_featBase = take(256);
+    oc.off_descConst = take((size_t)cap * 32);
     maxFeat += cap;
     if (o + 1 < svp::kOctaves) {
       ow /= 2;

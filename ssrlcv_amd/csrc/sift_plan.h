@@ -51,6 +51,7 @@ struct OctavePlan {
   size_t off_thetaCnt;     // cap uint32 (number of orientations per key point)
   size_t off_part;         // partition workspace (uint32 words)
   size_t off_featBase;     // uint32: first feature index of this octave
+  size_t off_descConst;    // cap x 32 bytes: per-key-point constants of the descriptor kernel (k_desc_consts)
 };
 
 // Side streams and events of one plan.  build_dog runs the HBM-bound DoG kernel of octave o beside the FMA-bound
