@@ -30,8 +30,10 @@ struct LevelSet {  // one octave's raw DoG levels + their min/max
   int w, h;
 };
 
+// (v - min) / (max - min) of normalize (src/Image.cu:1560-1565); sv::div_by returns the IEEE quotient and the compiler
+// shares the divisor's reciprocal between the samples of one level
 __device__ __forceinline__ float norm_sample(const float* __restrict__ lvl, float mn, float mx, size_t a) {
-  return (lvl[a] - mn) / (mx - mn);
+  return sv::div_by(lvl[a] - mn, sv::make_divisor(mx - mn));
 }
 
 // ---- S8: extrema ---------------------------------------------------------------------------------------------------
@@ -316,7 +318,8 @@ __global__ __launch_bounds__(256) void k_refine(const OctaveState* st, ssrlcv_ss
   }
 }
 
-// calculatePixelGradients(float) (src/Image.cu:1583-1598) at one pixel of a normalised level
+// calculatePixelGradients(float) (src/Image.cu:1583-1598) at one pixel of a normalised level; the four normalising
+// divisions share their divisor (sv::div_by: the same correctly rounded quotients, 5 instructions instead of 11)
 __device__ __forceinline__ float2 pixel_gradient(const float* __restrict__ px, float mn, float mx, int W, int H, int x,
                                                  int y) {
   int xc0 = x + 1, xc1 = x - 1, yc0 = y + 1, yc1 = y - 1;
@@ -324,9 +327,10 @@ __device__ __forceinline__ float2 pixel_gradient(const float* __restrict__ px, f
   else if (xc0 == W) { xc0 -= 1; xc1 -= 1; }
   if (yc1 == -1) { yc0 += 1; yc1 += 1; }
   else if (yc0 == H) { yc0 -= 1; yc1 -= 1; }
+  const sv::Divisor range = sv::make_divisor(mx - mn);
   float2 g;
-  g.x = norm_sample(px, mn, mx, (size_t)y * W + xc0) - norm_sample(px, mn, mx, (size_t)y * W + xc1);
-  g.y = norm_sample(px, mn, mx, (size_t)yc0 * W + x) - norm_sample(px, mn, mx, (size_t)yc1 * W + x);
+  g.x = sv::div_by(px[(size_t)y * W + xc0] - mn, range) - sv::div_by(px[(size_t)y * W + xc1] - mn, range);
+  g.y = sv::div_by(px[(size_t)yc0 * W + x] - mn, range) - sv::div_by(px[(size_t)yc1 * W + x] - mn, range);
   return g;
 }
 

@@ -685,9 +685,10 @@ __global__ __launch_bounds__(256) void k_minmax(const float* __restrict__ in, si
   block_minmax_commit(mn, mx, minmax, s_red);
 }
 __global__ __launch_bounds__(256) void k_normalize(float* __restrict__ data, size_t n, const float* __restrict__ minmax) {
-  float mn = minmax[0], mx = minmax[1];
+  const float mn = minmax[0], mx = minmax[1];
+  const sv::Divisor range = sv::make_divisor(mx - mn);
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) data[i] = (data[i] - mn) / (mx - mn);
+  if (i < n) data[i] = sv::div_by(data[i] - mn, range);
 }
 
 // ---- S6 + S7: both normalisations + DoG, one streaming kernel --------------------------------------------------------

@@ -44,6 +44,24 @@ def test_image_ops_bit_exact(capi, oracle_lib):
     assert mm[0] == src.min() and mm[1] == src.max()
 
 
+def test_normalize_bit_exact(capi):
+    """normalize (src/Image.cu:1560-1565) = (x - min) / (max - min) with IEEE division: the kernels divide through
+    sv::div_by (shared refined reciprocal + the fma chain of the compiler's own expansion), which must return the
+    correctly rounded quotient numpy's float32 division returns -- on random data, on the end points, on values one
+    ulp from them and on level-like ranges (tiny and large spans)."""
+    import torch
+    rng = np.random.default_rng(7)
+    for lo, hi in [(-0.37, 0.81), (0.0, 255.0), (-3.1e-3, 2.7e-3), (1.0e-3, 1.0001e-3), (-7.5e4, 9.1e5)]:
+        x = rng.uniform(lo, hi, 1 << 20).astype(np.float32)
+        mn, mx = np.float32(x.min()), np.float32(x.max())
+        x[:4] = [mn, mx, np.nextafter(mn, mx, dtype=np.float32), np.nextafter(mx, mn, dtype=np.float32)]
+        ref = (x - mn) / (mx - mn)
+        d = capi.to_dev(x)
+        capi.normalize_(d, x.size, capi.to_dev(np.array([mn, mx], np.float32)))
+        got = d.cpu().numpy().view(np.float32).reshape(-1)[: x.size]
+        assert np.array_equal(got, ref), (lo, hi, int((got != ref).sum()))
+
+
 @pytest.mark.parametrize("w,h", [(512, 264), (64, 64), (1000, 72), (2048, 136), (250, 130), (1002, 96)])
 @pytest.mark.parametrize("sigma,pw", [(0.70710678, 0.5), (1.0, 0.5), (1.4142135, 0.5), (2.0, 0.5), (2.828427, 0.5),
                                       (4.0, 0.5), (1.3, 1.0)])
