@@ -700,9 +700,13 @@ struct DogArgs {
   size_t n;
 };
 __global__ __launch_bounds__(256) void k_dog(DogArgs a) {
-  float lmn[svp::kGauss], lmx[svp::kGauss];
+  float lmn[svp::kGauss];
+  sv::Divisor range[svp::kGauss];  // (v - min) / (max - min) as the IEEE quotient through a shared reciprocal (device_math.h)
 #pragma unroll
-  for (int b = 0; b < svp::kGauss; ++b) { lmn[b] = a.lvlMinMax[2 * b]; lmx[b] = a.lvlMinMax[2 * b + 1]; }
+  for (int b = 0; b < svp::kGauss; ++b) {
+    lmn[b] = a.lvlMinMax[2 * b];
+    range[b] = sv::make_divisor(a.lvlMinMax[2 * b + 1] - lmn[b]);
+  }
   float dmn[svp::kDog], dmx[svp::kDog];
 #pragma unroll
   for (int b = 0; b < svp::kDog; ++b) { dmn[b] = FLT_MAX; dmx[b] = -FLT_MAX; }
@@ -711,18 +715,18 @@ __global__ __launch_bounds__(256) void k_dog(DogArgs a) {
     typedef float f32x4nt __attribute__((ext_vector_type(4)));
     const f32x4nt p0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(a.lvl[0] + i));  // streamed once
     float4 prev = make_float4(p0.x, p0.y, p0.z, p0.w);
-    prev.x = (prev.x - lmn[0]) / (lmx[0] - lmn[0]);
-    prev.y = (prev.y - lmn[0]) / (lmx[0] - lmn[0]);
-    prev.z = (prev.z - lmn[0]) / (lmx[0] - lmn[0]);
-    prev.w = (prev.w - lmn[0]) / (lmx[0] - lmn[0]);
+    prev.x = sv::div_by(prev.x - lmn[0], range[0]);
+    prev.y = sv::div_by(prev.y - lmn[0], range[0]);
+    prev.z = sv::div_by(prev.z - lmn[0], range[0]);
+    prev.w = sv::div_by(prev.w - lmn[0], range[0]);
 #pragma unroll
     for (int b = 0; b < svp::kDog; ++b) {
       const f32x4nt c0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(a.lvl[b + 1] + i));
       float4 cur = make_float4(c0.x, c0.y, c0.z, c0.w);
-      cur.x = (cur.x - lmn[b + 1]) / (lmx[b + 1] - lmn[b + 1]);
-      cur.y = (cur.y - lmn[b + 1]) / (lmx[b + 1] - lmn[b + 1]);
-      cur.z = (cur.z - lmn[b + 1]) / (lmx[b + 1] - lmn[b + 1]);
-      cur.w = (cur.w - lmn[b + 1]) / (lmx[b + 1] - lmn[b + 1]);
+      cur.x = sv::div_by(cur.x - lmn[b + 1], range[b + 1]);
+      cur.y = sv::div_by(cur.y - lmn[b + 1], range[b + 1]);
+      cur.z = sv::div_by(cur.z - lmn[b + 1], range[b + 1]);
+      cur.w = sv::div_by(cur.w - lmn[b + 1], range[b + 1]);
       float4 d = make_float4(cur.x - prev.x, cur.y - prev.y, cur.z - prev.z, cur.w - prev.w);
       __builtin_nontemporal_store(f32x4nt{d.x, d.y, d.z, d.w}, reinterpret_cast<f32x4nt*>(a.dog[b] + i));
       dmn[b] = fminf(fminf(dmn[b], d.x), fminf(d.y, fminf(d.z, d.w)));
