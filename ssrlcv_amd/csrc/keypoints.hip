@@ -641,12 +641,13 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
       const float ang = fmod_2pi_above(pg.y - theta + (2.0f * pi), 2.0f * pi);
       // orientation bins: every k in 0..7 with |ang - k*rad45| < rad45 votes 1 - |ang - k*rad45| / rad45 (:515-518);
       // ang lies in (-pi, 2 pi) (fmodf keeps the sign) and there is no wrap-around.  With k0 = floor(ang / rad45) and
-      // u = (ang - k0*rad45) / rad45 these are bin k0 with 1 - u and bin k0 + 1 with u, each if it exists.  The
+      // u = fract(ang / rad45) these are bin k0 with 1 - u and bin k0 + 1 with u, each if it exists.  The
       // reference's float tests can also admit a third bin, or reject one of the two, when a product rounds across an
       // integer -- with a weight within an ulp of 0 either way; those cases are not replayed.  A missing vote adds 0 to
       // a valid word (a neighbouring cell's bin or the padding in front of / behind the histogram) instead of branching.
-      int k0 = (int)floorf(ang * inv45);
-      const float u = fabsf(ang - ((float)k0 * rad45)) * inv45;
+      const float t45 = ang * inv45;
+      int k0 = (int)floorf(t45);
+      const float u = __builtin_amdgcn_fractf(t45);  // (ang - k0*rad45) / rad45 to within an ulp of t45
       const float m0 = (unsigned)k0 < 8u ? (1.0f - u) * mag31 : 0.0f;
       const float m1 = (unsigned)(k0 + 1) < 8u ? u * mag31 : 0.0f;
       k0 = k0 < -1 ? -1 : k0;  // k0 in -4..8 -> -1..8
