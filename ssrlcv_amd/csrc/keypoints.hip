@@ -608,9 +608,18 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
     const float invBin = dc.invBin, k2 = dc.k2, voteExp = dc.voteExp;
     const int S = 2 * (int)windowWidth + 1;
     // sample index -> (row, col) with a multiply-high by a per-key-point magic constant; votes are exact integers,
-    // so the visiting order does not matter.  The polar gather of the next batch is issued before the current one
-    // is used.
+    // so the visiting order does not matter.  The polar gathers of the next batch are issued before the current
+    // one is used.
+    //
+    // Point symmetry: the window sample -p = (-x, -y) has the rotated coordinates -(cx, cy) exactly, and the cell centres
+    // are antisymmetric too (rc[15 - cell] == -rc[cell] bit for bit: hx, hy run over -0.75, -0.25, 0.25, 0.75 times
+    // windowWidth).  So the cell test of -p against cell 15 - h is the cell test of p against cell h -- the same
+    // |rc - c| on both axes -- and so are its two 1 - t/binWidth factors and the Gaussian of r^2.  A lane therefore
+    // carries the PAIR (p, -p): one set of coordinates, one exponential, one pass over the 16 cells; only the gathers
+    // and the orientation split are per sample.  Pairs are the sample indices 0 .. (S^2 - 1) / 2; the last one is the
+    // window centre, its own partner, which votes once.  382 -> ~255 VALU instructions per 128 samples.
     const unsigned total = (unsigned)(S * S);
+    const unsigned half = (total - 1u) >> 1;  // index of the centre sample (S is odd)
     const unsigned magic = dc.magic;
     auto sample = [&](unsigned sidx, float& cx, float& cy, bool& ok) {
       const unsigned r = __umulhi(sidx, magic);  // sidx / S, exact for sidx < 2^16
@@ -619,55 +628,67 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
       const float y = -windowWidth + (float)(int)r;
       cx = (x * c) + (y * s);
       cy = (-x * s) + (y * c);
-      ok = sidx < total && fmaxf(fabsf(cx), fabsf(cy)) <= windowWidth;  // :505, one compare
+      ok = sidx <= half && fmaxf(fabsf(cx), fabsf(cy)) <= windowWidth;  // :505, one compare; the same for -p
     };
-    auto gather = [&](float cx, float cy) {
-      // llroundf of the reference; in-range by checkKeyPoints (window + 1 pixel inside the level)
-      return polar_px(pl, L.w, round_pos(cx + kx), round_pos(cy + ky));
+    // llroundf of the reference; in-range by checkKeyPoints (window + 1 pixel inside the level).  The partner's
+    // coordinates are (-cx) + kx = kx - cx, the same rounded sum.
+    auto gather = [&](float px, float py) { return polar_px(pl, L.w, round_pos(px), round_pos(py)); };
+    // orientation bins: every k in 0..7 with |ang - k*rad45| < rad45 votes 1 - |ang - k*rad45| / rad45 (:515-518);
+    // ang lies in (-pi, 2 pi) (fmodf keeps the sign) and there is no wrap-around.  With k0 = floor(ang / rad45) and
+    // u = fract(ang / rad45) these are bin k0 with 1 - u and bin k0 + 1 with u, each if it exists.  The reference's
+    // float tests can also admit a third bin, or reject one of the two, when a product rounds across an integer --
+    // with a weight within an ulp of 0 either way; those cases are not replayed.  A missing vote adds 0 to a valid word
+    // (a neighbouring cell's bin or the padding in front of / behind the histogram) instead of branching.
+    auto split = [&](float2 pg, float mag, float& m0, float& m1, unsigned*& pa) {
+      const float ang = fmod_2pi_above(pg.y - theta + (2.0f * pi), 2.0f * pi);
+      const float t45 = ang * inv45;
+      int k0 = (int)floorf(t45);
+      const float u = __builtin_amdgcn_fractf(t45);  // (ang - k0*rad45) / rad45 to within an ulp of t45
+      m0 = (unsigned)k0 < 8u ? (1.0f - u) * mag : 0.0f;
+      m1 = (unsigned)(k0 + 1) < 8u ? u * mag : 0.0f;
+      k0 = k0 < -1 ? -1 : k0;  // k0 in -4..8 -> -1..8
+      pa = bins + k0 * kDescCopies + copy;  // bin k0 of cell 0; bin k0 + 1 is kDescCopies words further
     };
     float ncx, ncy;
     bool nok;
     sample((unsigned)lane, ncx, ncy, nok);
-    float2 npg = make_float2(0.0f, 0.0f);
-    if (nok) npg = gather(ncx, ncy);
-    for (unsigned base = 0; base < total; base += 64) {
+    float2 npgA = make_float2(0.0f, 0.0f), npgB = make_float2(0.0f, 0.0f);
+    if (nok) {
+      npgA = gather(ncx + kx, ncy + ky);
+      npgB = gather(kx - ncx, ky - ncy);
+    }
+    for (unsigned base = 0; base <= half; base += 64) {
       const float cx = ncx, cy = ncy;
       const bool ok = nok;
-      const float2 pg = npg;
+      const float2 pgA = npgA, pgB = npgB;
+      const bool paired = base + (unsigned)lane < half;  // the centre sample is its own partner
       sample(base + 64 + (unsigned)lane, ncx, ncy, nok);
-      if (nok) npg = gather(ncx, ncy);
-      // gaussian-weighted magnitude with the fixed-point scale folded into the exponent
-      const float mag31 = pg.x * __builtin_amdgcn_exp2f(fmaf((cx * cx) + (cy * cy), k2, voteExp));
-      const float ang = fmod_2pi_above(pg.y - theta + (2.0f * pi), 2.0f * pi);
-      // orientation bins: every k in 0..7 with |ang - k*rad45| < rad45 votes 1 - |ang - k*rad45| / rad45 (:515-518);
-      // ang lies in (-pi, 2 pi) (fmodf keeps the sign) and there is no wrap-around.  With k0 = floor(ang / rad45) and
-      // u = fract(ang / rad45) these are bin k0 with 1 - u and bin k0 + 1 with u, each if it exists.  The
-      // reference's float tests can also admit a third bin, or reject one of the two, when a product rounds across an
-      // integer -- with a weight within an ulp of 0 either way; those cases are not replayed.  A missing vote adds 0 to
-      // a valid word (a neighbouring cell's bin or the padding in front of / behind the histogram) instead of branching.
-      const float t45 = ang * inv45;
-      int k0 = (int)floorf(t45);
-      const float u = __builtin_amdgcn_fractf(t45);  // (ang - k0*rad45) / rad45 to within an ulp of t45
-      const float m0 = (unsigned)k0 < 8u ? (1.0f - u) * mag31 : 0.0f;
-      const float m1 = (unsigned)(k0 + 1) < 8u ? u * mag31 : 0.0f;
-      k0 = k0 < -1 ? -1 : k0;  // k0 in -4..8 -> -1..8
-      unsigned* pa = bins + k0 * kDescCopies + copy;
-      unsigned* pb = pa + kDescCopies;
+      if (nok) {
+        npgA = gather(ncx + kx, ncy + ky);
+        npgB = gather(kx - ncx, ky - ncy);
+      }
+      // gaussian weight (shared by the pair) with the fixed-point scale folded into the exponent
+      const float g = __builtin_amdgcn_exp2f(fmaf((cx * cx) + (cy * cy), k2, voteExp));
+      float a0, a1, b0, b1;
+      unsigned *pa, *pb;
+      split(pgA, pgA.x * g, a0, a1, pa);
+      split(pgB, paired ? pgB.x * g : 0.0f, b0, b1, pb);
       // cells whose rotated centre lies within binWidth of the sample on both axes (:513-514).  `ok` is folded into
       // the lane's threshold and the two axis tests into one compare of max(|tx|, |ty|), so a cell costs {2 v_sub,
-      // v_max, v_cmp} + {s_and_saveexec, s_cbranch_execz, s_or}: on gfx950 a scalar instruction costs 2-3 cycles of
-      // the wave's issue, not much less than a vector one (tools/valu_rate.hip).  A passing cell costs two fused
-      // 1 - t/binWidth, their product and one multiply per vote: (wxy * wk) * mag of the reference becomes
-      // wxy * (wk * mag), and 1 - t * (1/binWidth) has one rounding instead of two -- a few ulp on a vote, against a
-      // quantisation step of 2^-8 of the normalised histogram.
+      // v_max, v_cmp} + {s_and_saveexec, s_cbranch_execz, s_or}.  A passing cell costs two fused 1 - t/binWidth, their
+      // product and one multiply + conversion per vote: (wxy * wk) * mag of the reference becomes wxy * (wk * mag), and
+      // 1 - t * (1/binWidth) has one rounding instead of two -- a few ulp on a vote, against a quantisation step of
+      // 2^-8 of the normalised histogram.  p votes into cell h, -p with the same wxy into cell 15 - h.
       const float bwl = ok ? binWidth : -1.0f;
 #pragma unroll
       for (int cell = 0; cell < 16; ++cell) {
         const float tx = fabsf(rc[cell].x - cx), ty = fabsf(rc[cell].y - cy);
         if (fmaxf(tx, ty) <= bwl) {
           const float wxy = fmaf(-tx, invBin, 1.0f) * fmaf(-ty, invBin, 1.0f);
-          atomicAdd(pa + cell * 8 * kDescCopies, (unsigned)(wxy * m0));
-          atomicAdd(pb + cell * 8 * kDescCopies, (unsigned)(wxy * m1));
+          atomicAdd(pa + cell * 8 * kDescCopies, (unsigned)(wxy * a0));
+          atomicAdd(pa + cell * 8 * kDescCopies + kDescCopies, (unsigned)(wxy * a1));
+          atomicAdd(pb + (15 - cell) * 8 * kDescCopies, (unsigned)(wxy * b0));
+          atomicAdd(pb + (15 - cell) * 8 * kDescCopies + kDescCopies, (unsigned)(wxy * b1));
         }
       }
     }
