@@ -522,7 +522,7 @@ struct DescConst {
   float invBin;         // 1 / binWidth, binWidth = windowWidth / 2
   float k2;             // -log2(e) / (2 windowWidth^2): exp(-(r^2) / (2 w^2)) == exp2(r^2 * k2) to <= 3 ulp
   float voteExp;        // fixed-point exponent of the votes (see kDescCopies)
-  uint32_t magic;       // ceil(2^32 / S), S = 2 windowWidth + 1: sample index -> row by a multiply-high
+  uint32_t magic;       // ceil(2^32 / windowWidth): orbit index -> quadrant row by a multiply-high
   int32_t segment;      // blur segment of the key point = DoG level its window is sampled from
 };
 static_assert(sizeof(DescConst) == 32, "one s_load_dwordx8");
@@ -544,8 +544,8 @@ __global__ __launch_bounds__(256) void k_desc_consts(const OctaveState* st, cons
     int boundExp;
     (void)frexpf(1.4143f * ((d.windowWidth + 2.0f) * (d.windowWidth + 2.0f)), &boundExp);
     d.voteExp = (float)(31 - boundExp);
-    const unsigned S = 2u * (unsigned)(int)d.windowWidth + 1u;
-    d.magic = 0xFFFFFFFFu / S + 1u;  // S is odd and > 1
+    const unsigned wi = (unsigned)(int)d.windowWidth;
+    d.magic = wi > 1u ? 0xFFFFFFFFu / wi + 1u : 0u;  // ceil(2^32 / w) (2^32 / w when w is a power of two); w = 1 is special-cased
     d.segment = segment_of(st, i);
     out[i] = d;
   }
@@ -606,32 +606,34 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
       }
     }
     const float invBin = dc.invBin, k2 = dc.k2, voteExp = dc.voteExp;
-    const int S = 2 * (int)windowWidth + 1;
-    // sample index -> (row, col) with a multiply-high by a per-key-point magic constant; votes are exact integers,
-    // so the visiting order does not matter.  The polar gathers of the next batch are issued before the current
-    // one is used.
+    // Votes are exact integers, so the visiting order of the window samples does not matter.  The polar gathers of the
+    // next batch are issued before the current one is used.
     //
-    // Point symmetry: the window sample -p = (-x, -y) has the rotated coordinates -(cx, cy) exactly, and the cell centres
-    // are antisymmetric too (rc[15 - cell] == -rc[cell] bit for bit: hx, hy run over -0.75, -0.25, 0.25, 0.75 times
-    // windowWidth).  So the cell test of -p against cell 15 - h is the cell test of p against cell h -- the same
-    // |rc - c| on both axes -- and so are its two 1 - t/binWidth factors and the Gaussian of r^2.  A lane therefore
-    // carries the PAIR (p, -p): one set of coordinates, one exponential, one pass over the 16 cells; only the gathers
-    // and the orientation split are per sample.  Pairs are the sample indices 0 .. (S^2 - 1) / 2; the last one is the
-    // window centre, its own partner, which votes once.  382 -> ~255 VALU instructions per 128 samples.
-    const unsigned total = (unsigned)(S * S);
-    const unsigned half = (total - 1u) >> 1;  // index of the centre sample (S is odd)
-    const unsigned magic = dc.magic;
-    auto sample = [&](unsigned sidx, float& cx, float& cy, bool& ok) {
-      const unsigned r = __umulhi(sidx, magic);  // sidx / S, exact for sidx < 2^16
-      const unsigned cc = sidx - r * (unsigned)S;
-      const float x = -windowWidth + (float)(int)cc;  // integers: exact, equal to the reference's repeated += 1.0f
-      const float y = -windowWidth + (float)(int)r;
+    // Four-fold symmetry: a quarter turn maps the integer window onto itself, p = (x, y) -> (-y, x), and takes the
+    // rotated coordinates (cx, cy) to (-cy, cx) EXACTLY (the same two products, summed in the other order or negated);
+    // the 4 x 4 cell centres turn with it, rc[(3 - ny)*4 + nx] == (-rc[nx*4 + ny].y, rc[nx*4 + ny].x) bit for bit (hx, hy
+    // run over -0.75, -0.25, 0.25, 0.75 times windowWidth).  So the cell test of the turned sample against the turned
+    // cell is the test of p against the cell with |dx| and |dy| exchanged: the same pass / fail, the same product of the
+    // two 1 - t/binWidth factors, the same Gaussian of r^2.  A lane therefore carries the ORBIT {p, turned once, twice,
+    // three times}: one set of coordinates, one exponential, one pass over the 16 cells; only the gathers and the
+    // orientation split are per sample.  Orbits are numbered over the quadrant x = 1..w, y = 0..w (index = y*w + x - 1);
+    // one more index stands for the window centre, which is its own orbit.  764 -> ~390 VALU instructions per 256
+    // samples against one sample per lane.
+    const int Wi = (int)windowWidth;
+    const unsigned centreIdx = (unsigned)(Wi * (Wi + 1));
+    const unsigned magic = dc.magic;  // ceil(2^32 / w)
+    auto sample = [&](unsigned idx, float& cx, float& cy, bool& ok) {
+      const unsigned yq = Wi == 1 ? idx : __umulhi(idx, magic);  // idx / w, exact for idx < 2^16
+      const unsigned xq = idx - yq * (unsigned)Wi + 1u;
+      const bool centre = idx >= centreIdx;
+      const float x = centre ? 0.0f : (float)(int)xq;  // integers: exact, the values of the reference's repeated += 1.0f
+      const float y = centre ? 0.0f : (float)(int)yq;
       cx = (x * c) + (y * s);
       cy = (-x * s) + (y * c);
-      ok = sidx <= half && fmaxf(fabsf(cx), fabsf(cy)) <= windowWidth;  // :505, one compare; the same for -p
+      ok = idx <= centreIdx && fmaxf(fabsf(cx), fabsf(cy)) <= windowWidth;  // :505, one compare for the whole orbit
     };
-    // llroundf of the reference; in-range by checkKeyPoints (window + 1 pixel inside the level).  The partner's
-    // coordinates are (-cx) + kx = kx - cx, the same rounded sum.
+    // llroundf of the reference; in-range by checkKeyPoints (window + 1 pixel inside the level).  A turned sample's
+    // coordinate is e.g. (-cy) + kx = kx - cy, the same rounded sum.
     auto gather = [&](float px, float py) { return polar_px(pl, L.w, round_pos(px), round_pos(py)); };
     // orientation bins: every k in 0..7 with |ang - k*rad45| < rad45 votes 1 - |ang - k*rad45| / rad45 (:515-518);
     // ang lies in (-pi, 2 pi) (fmodf keeps the sign) and there is no wrap-around.  With k0 = floor(ang / rad45) and
@@ -652,43 +654,53 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
     float ncx, ncy;
     bool nok;
     sample((unsigned)lane, ncx, ncy, nok);
-    float2 npgA = make_float2(0.0f, 0.0f), npgB = make_float2(0.0f, 0.0f);
-    if (nok) {
-      npgA = gather(ncx + kx, ncy + ky);
-      npgB = gather(kx - ncx, ky - ncy);
-    }
-    for (unsigned base = 0; base <= half; base += 64) {
+    float2 npg[4] = {make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f)};
+    auto gather4 = [&]() {
+      npg[0] = gather(ncx + kx, ncy + ky);
+      npg[1] = gather(kx - ncy, ncx + ky);
+      npg[2] = gather(kx - ncx, ky - ncy);
+      npg[3] = gather(ncy + kx, ky - ncx);
+    };
+    if (nok) gather4();
+    for (unsigned base = 0; base <= centreIdx; base += 64) {
       const float cx = ncx, cy = ncy;
       const bool ok = nok;
-      const float2 pgA = npgA, pgB = npgB;
-      const bool paired = base + (unsigned)lane < half;  // the centre sample is its own partner
+      const float2 pg0 = npg[0], pg1 = npg[1], pg2 = npg[2], pg3 = npg[3];
+      const bool turned = base + (unsigned)lane < centreIdx;  // the centre sample is its own orbit
       sample(base + 64 + (unsigned)lane, ncx, ncy, nok);
-      if (nok) {
-        npgA = gather(ncx + kx, ncy + ky);
-        npgB = gather(kx - ncx, ky - ncy);
-      }
-      // gaussian weight (shared by the pair) with the fixed-point scale folded into the exponent
+      if (nok) gather4();
+      // gaussian weight (shared by the orbit) with the fixed-point scale folded into the exponent
       const float g = __builtin_amdgcn_exp2f(fmaf((cx * cx) + (cy * cy), k2, voteExp));
-      float a0, a1, b0, b1;
-      unsigned *pa, *pb;
-      split(pgA, pgA.x * g, a0, a1, pa);
-      split(pgB, paired ? pgB.x * g : 0.0f, b0, b1, pb);
+      const float gt = turned ? g : 0.0f;
+      float a0, a1, b0, b1, c0, c1, d0, d1;
+      unsigned *pa, *pb, *pc, *pd;
+      split(pg0, pg0.x * g, a0, a1, pa);
+      split(pg1, pg1.x * gt, b0, b1, pb);
+      split(pg2, pg2.x * gt, c0, c1, pc);
+      split(pg3, pg3.x * gt, d0, d1, pd);
       // cells whose rotated centre lies within binWidth of the sample on both axes (:513-514).  `ok` is folded into
       // the lane's threshold and the two axis tests into one compare of max(|tx|, |ty|), so a cell costs {2 v_sub,
       // v_max, v_cmp} + {s_and_saveexec, s_cbranch_execz, s_or}.  A passing cell costs two fused 1 - t/binWidth, their
       // product and one multiply + conversion per vote: (wxy * wk) * mag of the reference becomes wxy * (wk * mag), and
       // 1 - t * (1/binWidth) has one rounding instead of two -- a few ulp on a vote, against a quantisation step of
-      // 2^-8 of the normalised histogram.  p votes into cell h, -p with the same wxy into cell 15 - h.
+      // 2^-8 of the normalised histogram.  p votes into cell (nx, ny), its quarter turns with the same wxy into
+      // (3 - ny, nx), (3 - nx, 3 - ny) and (ny, 3 - nx).
       const float bwl = ok ? binWidth : -1.0f;
 #pragma unroll
       for (int cell = 0; cell < 16; ++cell) {
+        const int nx = cell >> 2, ny = cell & 3;
+        const int cellB = (3 - ny) * 4 + nx, cellC = 15 - cell, cellD = ny * 4 + (3 - nx);
         const float tx = fabsf(rc[cell].x - cx), ty = fabsf(rc[cell].y - cy);
         if (fmaxf(tx, ty) <= bwl) {
           const float wxy = fmaf(-tx, invBin, 1.0f) * fmaf(-ty, invBin, 1.0f);
           atomicAdd(pa + cell * 8 * kDescCopies, (unsigned)(wxy * a0));
           atomicAdd(pa + cell * 8 * kDescCopies + kDescCopies, (unsigned)(wxy * a1));
-          atomicAdd(pb + (15 - cell) * 8 * kDescCopies, (unsigned)(wxy * b0));
-          atomicAdd(pb + (15 - cell) * 8 * kDescCopies + kDescCopies, (unsigned)(wxy * b1));
+          atomicAdd(pb + cellB * 8 * kDescCopies, (unsigned)(wxy * b0));
+          atomicAdd(pb + cellB * 8 * kDescCopies + kDescCopies, (unsigned)(wxy * b1));
+          atomicAdd(pc + cellC * 8 * kDescCopies, (unsigned)(wxy * c0));
+          atomicAdd(pc + cellC * 8 * kDescCopies + kDescCopies, (unsigned)(wxy * c1));
+          atomicAdd(pd + cellD * 8 * kDescCopies, (unsigned)(wxy * d0));
+          atomicAdd(pd + cellD * 8 * kDescCopies + kDescCopies, (unsigned)(wxy * d1));
         }
       }
     }
