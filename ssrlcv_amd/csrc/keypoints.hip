@@ -847,7 +847,6 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
       const float* d2 = L.dog[2];
       const float* d3 = L.dog[3];
       ssrlcv_sskeypoint* first = (nswaps & 1) ? B : A;
-      auto keyfn = [=] __device__(uint32_t p) -> uint32_t { return (uint32_t)flags[p]; };
       auto emit = [=] __device__(uint32_t p, int b, uint32_t d) {
         if (d >= cap) return;
         ssrlcv_sskeypoint kp;  // fillExtrema (src/FeatureFactory.cu:883-890)
@@ -862,7 +861,7 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
         first[d] = kp;
       };
       uint32_t* totals = nullptr;
-      hipError_t e = svc::partition<3, 64>(P, keyfn, emit, words, &totals, s);
+      hipError_t e = svc::partition_flags<3>(P, flags, emit, words, &totals, s);
       if (e != hipSuccess) return (int)e;
       hipLaunchKernelGGL(k_book_extrema, dim3(1), dim3(1), 0, s, st, totals, cap);
     }
