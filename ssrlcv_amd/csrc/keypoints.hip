@@ -318,37 +318,62 @@ __global__ __launch_bounds__(256) void k_refine(const OctaveState* st, ssrlcv_ss
   }
 }
 
-// calculatePixelGradients(float) (src/Image.cu:1583-1598) at one pixel of a normalised level; the four normalising
-// divisions share their divisor (sv::div_by: the same correctly rounded quotients, 5 instructions instead of 11)
-__device__ __forceinline__ float2 pixel_gradient(const float* __restrict__ px, float mn, float mx, int W, int H, int x,
-                                                 int y) {
-  int xc0 = x + 1, xc1 = x - 1, yc0 = y + 1, yc1 = y - 1;
-  if (xc1 == -1) { xc0 += 1; xc1 += 1; }
-  else if (xc0 == W) { xc0 -= 1; xc1 -= 1; }
-  if (yc1 == -1) { yc0 += 1; yc1 += 1; }
-  else if (yc0 == H) { yc0 -= 1; yc1 -= 1; }
-  const sv::Divisor range = sv::make_divisor(mx - mn);
-  float2 g;
-  g.x = sv::div_by(px[(size_t)y * W + xc0] - mn, range) - sv::div_by(px[(size_t)y * W + xc1] - mn, range);
-  g.y = sv::div_by(px[(size_t)yc0 * W + x] - mn, range) - sv::div_by(px[(size_t)yc1 * W + x] - mn, range);
-  return g;
-}
-
 // Gradient magnitude / direction of every pixel of the normalised DoG levels 1..3, computed once per image: the
 // orientation and descriptor windows of neighbouring key points overlap ~10x, and 4 gathers + 4 divisions + sqrtf +
-// atan2f per sample was two thirds of their instruction count.  Same operations as the on-the-fly path, so values are
-// bit-identical.
+// atan2f per sample was two thirds of their instruction count.  The operations are those of normalize +
+// calculatePixelGradients, so values are bit-identical to the per-sample path; a block owns a 256 x 16 tile and every thread a column run of it, so a pixel is normalised once
+// (18 divisions per 16 pixels instead of 64: the kernel is VALU bound), vertical neighbours are the thread's own
+// registers, horizontal ones come through LDS, and the border rule of calculatePixelGradients (src/Image.cu:1583-1598:
+// a border pixel takes the stencil of its inner neighbour) is a choice of indices, not per-pixel address arithmetic.
+constexpr int kPolRows = 16;
 __global__ __launch_bounds__(256) void k_polar(LevelSet L, float2* __restrict__ out) {
-  int x = blockIdx.x * 256 + threadIdx.x;
-  int y = blockIdx.y;
-  int lvl = blockIdx.z + 1;
-  if (x >= L.w) return;
-  float mn = L.minmax[2 * lvl], mx = L.minmax[2 * lvl + 1];
-  float2 g = pixel_gradient(L.dog[lvl], mn, mx, L.w, L.h, x, y);
-  float2 r;
-  r.x = sqrtf((g.x * g.x) + (g.y * g.y));
-  r.y = atan2f(g.y, g.x);
-  out[((size_t)blockIdx.z * L.h + y) * L.w + x] = r;
+  __shared__ float s_n[kPolRows][256 + 2];  // column c of the tile at [.][c + 1]; [.][0] / [.][257] = columns x0 - 1 / x0 + 256
+  const int W = L.w, H = L.h;
+  const int x0 = blockIdx.x * 256, y0 = blockIdx.y * kPolRows, lvl = blockIdx.z + 1;
+  const int t = threadIdx.x, x = x0 + t;
+  const float* __restrict__ px = L.dog[lvl];
+  const float mn = L.minmax[2 * lvl];
+  const sv::Divisor range = sv::make_divisor(L.minmax[2 * lvl + 1] - mn);
+  // own column, rows y0 - 1 .. y0 + 16; rows / columns clamped into the image are loaded but never used (see below)
+  const int xc = x < W ? x : W - 1;
+  float v[kPolRows + 2];
+#pragma unroll
+  for (int j = 0; j < kPolRows + 2; ++j) {
+    int yy = y0 - 1 + j;
+    yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+    v[j] = sv::div_by(px[(size_t)yy * W + xc] - mn, range);
+  }
+#pragma unroll
+  for (int i = 0; i < kPolRows; ++i) s_n[i][t + 1] = v[i + 1];
+  if (t < 2 * kPolRows) {
+    const int i = t >> 1, side = t & 1;
+    int hx = side ? x0 + 256 : x0 - 1;
+    hx = hx < 0 ? 0 : (hx > W - 1 ? W - 1 : hx);
+    int yy = y0 + i;
+    yy = yy > H - 1 ? H - 1 : yy;
+    s_n[i][side ? 257 : 0] = sv::div_by(px[(size_t)yy * W + hx] - mn, range);
+  }
+  __syncthreads();
+  if (x >= W) return;
+  // LDS columns of the two horizontal taps: x - 1 / x + 1, at the image border x / x + 2 resp. x - 2 / x
+  const int cl = x == 0 ? 1 : (x == W - 1 ? t - 1 : t);
+  const int cr = x == 0 ? 3 : (x == W - 1 ? t + 1 : t + 2);
+  float2* __restrict__ o = out + ((size_t)blockIdx.z * H + y0) * W + x;
+#pragma unroll
+  for (int i = 0; i < kPolRows; ++i) {
+    const int y = y0 + i;
+    if (y >= H) break;
+    float2 g;
+    g.x = s_n[i][cr] - s_n[i][cl];
+    // rows y + 1 / y - 1 are v[i + 2] / v[i]; at the border rows y + 2 / y resp. y / y - 2
+    const float up = y == 0 ? v[i + 3 < kPolRows + 2 ? i + 3 : kPolRows + 1] : (y == H - 1 ? v[i + 1] : v[i + 2]);
+    const float dn = y == 0 ? v[i + 1] : (y == H - 1 ? v[i > 0 ? i - 1 : 0] : v[i]);
+    g.y = up - dn;
+    float2 r;
+    r.x = sqrtf((g.x * g.x) + (g.y * g.y));
+    r.y = atan2f(g.y, g.x);
+    o[(size_t)i * W] = r;
+  }
 }
 // Histogram votes in 2^-31 fixed point, accumulated with 64-bit integer LDS atomics: ds_add_f32 runs at about one lane
 // per clock on gfx950 (measured: 27 of 55 ms of the first version of k_descriptors), ds_add_u64 does not.  A vote is
@@ -815,7 +840,7 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
     if (stop >= 6) {
       for (int o = 0; o < svp::kOctaves; ++o) {
         const svp::OctavePlan& oc = plan->oct[o];
-        hipLaunchKernelGGL(k_polar, dim3((oc.w + 255) / 256, oc.h, 3), dim3(256), 0, as->table,
+        hipLaunchKernelGGL(k_polar, dim3((oc.w + 255) / 256, (oc.h + kPolRows - 1) / kPolRows, 3), dim3(256), 0, as->table,
                            make_levels(plan, ws, o), (float2*)(ws + oc.off_polar));
         SSRLCV_HIP_TRY(hipEventRecord(as->polarDone[o], as->table));
       }
@@ -915,7 +940,7 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
     }
     if (stop >= 6) {  // computeKeyPointOrientations (src/FeatureFactory.cu:540-632)
       if (as) SSRLCV_HIP_TRY(hipStreamWaitEvent(s, as->polarDone[o], 0));
-      else hipLaunchKernelGGL(k_polar, dim3((oc.w + 255) / 256, oc.h, 3), dim3(256), 0, s, L, (float2*)(ws + oc.off_polar));
+      else hipLaunchKernelGGL(k_polar, dim3((oc.w + 255) / 256, (oc.h + kPolRows - 1) / kPolRows, 3), dim3(256), 0, s, L, (float2*)(ws + oc.off_polar));
       float* thetas = (float*)(ws + oc.off_theta);
       uint32_t* thetaCnt = (uint32_t*)(ws + oc.off_thetaCnt);
       dim3 g(list_blocks(cap) * 2);
