@@ -72,6 +72,17 @@ def test_sift_plan_layout_is_host_only():
     # sum P = 5.3125 W H pixels; in0 + 6 gaussian + 5 DoG levels dominate
     assert 5.3125 * 1024 * 1024 * 4 * 5 < nbytes < 600e6
     lib.ssrlcv_sift_plan_destroy(plan)
-    # sizes that would need makeBinnable padding are refused, not silently mishandled
+    # sizes that need makeBinnable padding (S3) get the reference's border: 1001 x 1024 has an odd side, so the upsampled
+    # 2002 x 2048 image is padded to multiples of 32 (2016 x 2048) and the workspace grows with it
     assert lib.ssrlcv_sift_plan_create(ctypes.c_uint32(1001), ctypes.c_uint32(1024), ctypes.byref(p),
+                                       ctypes.byref(plan)) == 0
+    nb_odd = lib.ssrlcv_sift_plan_workspace_bytes(plan)
+    lib.ssrlcv_sift_plan_destroy(plan)
+    assert nbytes * 0.97 < nb_odd < nbytes * 1.03
+    # even sizes are padded to multiples of 8 before the upsample: 1002 -> 1008
+    assert lib.ssrlcv_sift_plan_create(ctypes.c_uint32(1002), ctypes.c_uint32(1024), ctypes.byref(p),
+                                       ctypes.byref(plan)) == 0
+    lib.ssrlcv_sift_plan_destroy(plan)
+    # images whose octave 0 is below 512 pixels on a side are refused (-4 = SSRLCV_ERR_UNSUPPORTED), not mishandled
+    assert lib.ssrlcv_sift_plan_create(ctypes.c_uint32(200), ctypes.c_uint32(1024), ctypes.byref(p),
                                        ctypes.byref(plan)) == -4
