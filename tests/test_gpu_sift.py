@@ -239,3 +239,34 @@ def test_nview_flow_single_rank_matches_3view_fixture(capi):
     if len(mm) == len(ref_mm) and np.array_equal(kp["loc"], ref_kp["loc"]):
         diff = pts - v["points0"]
         assert float(np.sqrt((diff.astype(np.float64) ** 2).sum(1).mean())) <= 2.5e-3
+
+
+@pytest.mark.parametrize("kind", ["const", "zeros", "rand", "checker", "onepixel"])
+def test_degenerate_images_match_oracle(capi, oracle_lib, kind):
+    """Edge inputs: a constant image (every normalisation is 0/0: no extrema, no features, no fault), an all-zero image
+    of a size makeBinnable pads, uniform noise on a padded size (feature-dense), a one-pixel checkerboard and a single
+    bright pixel.  Feature count, order and locations are the oracle's; orientations and descriptors within the usual
+    tolerance."""
+    img = {
+        "const": np.full((256, 256), 128, np.uint8),
+        "zeros": np.zeros((264, 300), np.uint8),
+        "rand": np.random.default_rng(1).integers(0, 256, (258, 262), dtype=np.uint8),
+        "checker": ((np.indices((256, 384)).sum(0) & 1) * 255).astype(np.uint8),
+        "onepixel": np.pad(np.full((1, 1), 255, np.uint8), ((128, 127), (200, 183))),
+    }[kind]
+    h, w = img.shape
+    plan = capi.SiftPlan(w, h)
+    plan.extract(capi.to_dev(img))
+    gf = plan.features_host(H.FEATURE)
+    of = H.oracle_sift(oracle_lib, img)
+    assert len(gf) == len(of), (kind, len(gf), len(of))
+    if len(gf):
+        assert np.array_equal(gf["loc"], of["loc"])
+        assert np.allclose(gf["sigma"], of["sigma"], rtol=3e-7, atol=0)
+    if len(gf) and kind != "onepixel":
+        # (the single pixel is mirror-symmetric: its orientation histograms hold exactly tied peaks, and which of two
+        # tied bins wins is decided by the last ulp of expf / atan2f -- ocml and glibc pick differently for some)
+        d = np.abs(gf["theta"] - of["theta"])
+        assert np.minimum(d, 2 * np.pi - d).max() <= 2e-4
+        diff = gf["values"].astype(np.int32) - of["values"].astype(np.int32)
+        assert ((diff ** 2).sum(1) <= 20).all()
