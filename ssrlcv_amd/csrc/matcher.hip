@@ -529,7 +529,7 @@ Layout make_layout(uint32_t nq, uint32_t nt) {
   L.off_pq = take((size_t)L.nq_pad * kKPad * 2);
   L.off_pt = take((size_t)L.nt_pad * kKPad * 2);
   L.off_nq = take((size_t)L.nq_pad * 4);
-  L.off_nt = take((size_t)L.nt_pad * 4);  // integer formulation only
+  L.off_nt = take((size_t)L.nt_pad * 8);  // integer formulation only: |t'|^2 [nt_pad], then -floor(|t'|^2 / 2) [nt_pad]
   L.off_lt = take((size_t)L.nt_pad * 8);
   L.off_geom = take((size_t)L.nq_pad * sizeof(Geom));
   L.off_key = take((size_t)L.nq_pad * 8);
