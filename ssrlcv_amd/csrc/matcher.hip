@@ -379,6 +379,10 @@ __global__ __launch_bounds__(256, SSRLCV_MATCH_WPS) void k_match(const _Float16*
       for (int s = 0; s < kKSteps; ++s) cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], bq[qt][s], cur, 0, 0, 0);
       epilogue(tt, qt - 1, prev);
     }
+    // the inline-asm v_min3 of the epilogue is invisible to the back end's MFMA hazard recogniser: give the last chain its
+    // wait states by hand (the earlier epilogues run behind the next tile's nine MFMAs)
+    asm volatile("s_nop 15");
+    asm volatile("s_nop 3");
     epilogue(tt, kQT - 1, ((kQT - 1) & 1) ? acc1 : acc0);
   };
   // Target tiles stream straight from L2 into registers (all blocks walk the same tiles at about the same time, so
@@ -414,6 +418,8 @@ __global__ __launch_bounds__(256, SSRLCV_MATCH_WPS) void k_match(const _Float16*
             floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int s2 = 0; s2 < kKSteps; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s2], bq[qt][s2], acc, 0, 0, 0);
+            asm volatile("s_nop 15");  // see process_tile: asm reads of fresh MFMA results
+            asm volatile("s_nop 3");
             epilogue(tt, qt, acc);
           }
         }
