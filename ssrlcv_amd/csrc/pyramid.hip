@@ -424,7 +424,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kMT = 16;            // rows per marching step of the MFMA kernel
 constexpr int kMfmaThreads = 512;  // 4 horizontal-pass waves + 4 vertical-pass waves
 
-template <int R>
+template <int R, int TW>
 struct MfmaCfg {
   static constexpr int K = 16 + 2 * R;            // Toeplitz depth
   static constexpr int KS = (K + 3) / 4;          // MFMA k-steps
@@ -432,24 +432,26 @@ struct MfmaCfg {
   static constexpr int RP = (R + 3) / 4 * 4;
   // staged row width: 256 + halo + padding for the KP - K overshoot, == 2 (mod 32) so that the A reads
   // (16 rows x 2 columns per 32-lane half) are bank-conflict free
-  static constexpr int SWmin = kTX + 2 * RP + (KP - K) + 4;
+  static constexpr int TPW = TW / 64;             // 16-column tiles per wave (4 waves of each role share the strip)
+  static constexpr int SWmin = TW + 2 * RP + (KP - K) + 4;
   static constexpr int SW = (SWmin + 29) / 32 * 32 + 2;
   // ring of H rows: the vertical pass of step it-1 reads rows 16(it-1)-2R .. 16 it - 1 while the horizontal pass of
   // step it writes rows 16 it .. 16 it + 15
   static constexpr int RINGROWS = (2 * R + 2 * kMT + kMT - 1) / kMT * kMT;
-  static constexpr int RSTR = kTX + 16;           // ring row stride (== 16 mod 32: B reads conflict free)
+  static constexpr int RSTR = TW + 16;            // ring row stride (== 16 mod 32: B reads conflict free)
   static constexpr int TOT = kMT * SW;
-  static constexpr int STG = (TOT + kTX - 1) / kTX;  // staged elements per horizontal-role thread
+  static constexpr int STG = (TOT + 255) / 256;   // staged elements per horizontal-role thread (256 of them)
   static constexpr size_t ldsBytes = sizeof(float) * ((size_t)2 * kMT * SW + (size_t)RINGROWS * RSTR);
 };
 
-template <int R>
+template <int R, int TW>
 __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma(ConvArgs a) {
-  using C = MfmaCfg<R>;
+  using C = MfmaCfg<R, TW>;
+  constexpr int TPW = C::TPW;
   extern __shared__ __attribute__((aligned(16))) float s_mem[];
   float* s_ring = s_mem + 2 * kMT * C::SW;     // [RINGROWS][RSTR]; the two row stages [kMT][SW] sit in front
   const int W = (int)a.w, H = (int)a.h;
-  const int x0 = blockIdx.x * kTX;
+  const int x0 = blockIdx.x * TW;
   const int y0 = blockIdx.y * (int)a.rowsPerBlock;
   int nrows = (int)a.rowsPerBlock;
   if (y0 + nrows > H) nrows = H - y0;
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma(ConvArgs a) {
   if (role == 0) {
 #pragma unroll
     for (int e = 0; e < C::STG; ++e) {
-      int idx = e * kTX + htid;
+      int idx = e * 256 + htid;
       idx = idx < C::TOT ? idx : C::TOT - 1;
       int r = idx / C::SW, c = idx - r * C::SW;
       int x = x0 - C::RP + c;
@@ -511,12 +513,12 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma(ConvArgs a) {
     float* s_in = s_mem + buf * kMT * C::SW;
 #pragma unroll
     for (int e = 0; e < C::STG; ++e)
-      if ((e + 1) * kTX <= C::TOT || e * kTX + htid < C::TOT) s_in[e * kTX + htid] = pre[e];
+      if ((e + 1) * 256 <= C::TOT || e * 256 + htid < C::TOT) s_in[e * 256 + htid] = pre[e];
   };
   float mn = FLT_MAX, mx = -FLT_MAX;
   // vertical role: the accumulators of the last vertical pass, stored one iteration later
   constexpr int kNoPending = -(1 << 30);
-  f32x4 pend[4];
+  f32x4 pend[TPW];
   int pendJ = kNoPending;
   // The vertical product is evaluated transposed, D^T[x][y] = sum_k H^T[x][k] * T[k][y] (same LDS reads, the ring rows
   // as the A operand): a lane then holds four consecutive x of output row jbase + li -- one 16-byte store per tile
@@ -527,8 +529,8 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma(ConvArgs a) {
     const int j = jbase + li;
     const bool rowOk = j >= 0 && j < nrows;
 #pragma unroll
-    for (int t4 = 0; t4 < 4; ++t4) {
-      const int gx = x0 + (w4 * 4 + t4) * 16 + lk * 4;
+    for (int t4 = 0; t4 < TPW; ++t4) {
+      const int gx = x0 + (w4 * TPW + t4) * 16 + lk * 4;
       float* o = a.out + ((long)(y0 + j) * W + gx);
       const f32x4 v = pend[t4];
       if (rowOk && vec4 && gx + 3 < W) {
@@ -556,33 +558,33 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma(ConvArgs a) {
       if (it < steps) {
         // ---- horizontal pass: H rows 16 it .. 16 it + 15 of this strip into the ring.  The wave's four column tiles
         // are four independent accumulation chains; the A operands of k-step ks+1 are read under the MFMAs of ks.
-        const float* arow = s_mem + (it & 1) * kMT * C::SW + li * C::SW + (w4 * 4) * 16 + (C::RP - R) + lk;
-        f32x4 acc[4];
+        const float* arow = s_mem + (it & 1) * kMT * C::SW + li * C::SW + (w4 * TPW) * 16 + (C::RP - R) + lk;
+        f32x4 acc[TPW];
 #pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) acc[t4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        float av[3][4];  // A operands are read two k-steps ahead of the MFMAs that use them
+        for (int t4 = 0; t4 < TPW; ++t4) acc[t4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        float av[3][TPW];  // A operands are read two k-steps ahead of the MFMAs that use them
 #pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) av[0][t4] = arow[t4 * 16];
+        for (int t4 = 0; t4 < TPW; ++t4) av[0][t4] = arow[t4 * 16];
         if (C::KS > 1) {
 #pragma unroll
-          for (int t4 = 0; t4 < 4; ++t4) av[1][t4] = arow[t4 * 16 + 4];
+          for (int t4 = 0; t4 < TPW; ++t4) av[1][t4] = arow[t4 * 16 + 4];
         }
 #pragma unroll
         for (int ks = 0; ks < C::KS; ++ks) {
           if (ks + 2 < C::KS) {
 #pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) av[(ks + 2) % 3][t4] = arow[t4 * 16 + 4 * (ks + 2)];
+            for (int t4 = 0; t4 < TPW; ++t4) av[(ks + 2) % 3][t4] = arow[t4 * 16 + 4 * (ks + 2)];
           }
           __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of this k-step's MFMAs
 #pragma unroll
-          for (int t4 = 0; t4 < 4; ++t4) acc[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks % 3][t4], tz[ks], acc[t4], 0, 0, 0);
+          for (int t4 = 0; t4 < TPW; ++t4) acc[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks % 3][t4], tz[ks], acc[t4], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
         // D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
         const int slot0 = (it * kMT) % C::RINGROWS;
 #pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) {
-          float* dst = s_ring + (size_t)(slot0 + lk * 4) * C::RSTR + (w4 * 4 + t4) * 16 + li;
+        for (int t4 = 0; t4 < TPW; ++t4) {
+          float* dst = s_ring + (size_t)(slot0 + lk * 4) * C::RSTR + (w4 * TPW + t4) * 16 + li;
           dst[0] = acc[t4][0];
           dst[C::RSTR] = acc[t4][1];
           dst[2 * C::RSTR] = acc[t4][2];
@@ -607,7 +609,7 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma(ConvArgs a) {
         // and stretched a k-step from 128 to 272 cycles (measured, vertical role alone).  One wrap at most
         // (K <= RINGROWS); padded k-steps re-read a valid row, their weight is 0.
         const int base = ((jbase % C::RINGROWS) + C::RINGROWS) % C::RINGROWS;  // wave-uniform
-        const float* colp = s_ring + (w4 * 4) * 16 + li;
+        const float* colp = s_ring + (w4 * TPW) * 16 + li;
         int boff[C::KS];
 #pragma unroll
         for (int ks = 0; ks < C::KS; ++ks) {
@@ -618,15 +620,15 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma(ConvArgs a) {
           boff[ks] = slot * C::RSTR;
         }
         __builtin_amdgcn_sched_barrier(0);
-        auto loadB = [&](int ks, float (&dst)[4]) {
+        auto loadB = [&](int ks, float (&dst)[TPW]) {
           const float* brow = colp + boff[ks];
 #pragma unroll
-          for (int t4 = 0; t4 < 4; ++t4) dst[t4] = brow[t4 * 16];
+          for (int t4 = 0; t4 < TPW; ++t4) dst[t4] = brow[t4 * 16];
         };
 #pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) pend[t4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int t4 = 0; t4 < TPW; ++t4) pend[t4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         // B operands are read two k-steps ahead of the MFMAs that use them
-        float bv[3][4];
+        float bv[3][TPW];
         loadB(0, bv[0]);
         if (C::KS > 1) loadB(1, bv[1]);
 #pragma unroll
@@ -634,7 +636,7 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma(ConvArgs a) {
           if (ks + 2 < C::KS) loadB(ks + 2, bv[(ks + 2) % 3]);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int t4 = 0; t4 < 4; ++t4) pend[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[ks % 3][t4], tz[ks], pend[t4], 0, 0, 0);
+          for (int t4 = 0; t4 < TPW; ++t4) pend[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[ks % 3][t4], tz[ks], pend[t4], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
         pendJ = jbase;
@@ -819,35 +821,44 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
   } else {
     // one or two blocks are resident per CU (LDS): size the strips so that the launch is about one round of them;
     // 16-row steps, at least 4 steps of payload per 2R halo
-#define SSRLCV_LAUNCH_MFMA(RR)                                                                                   \
-  do {                                                                                                            \
-    static int blocksPerCu = 0, cus = 0;                                                                          \
-    if (!blocksPerCu) {                                                                                           \
-      SSRLCV_HIP_TRY(hipFuncSetAttribute((const void*)k_gauss_mfma<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                         (int)MfmaCfg<RR>::ldsBytes));                                            \
-      int dev = 0, occ = 0;                                                                                       \
-      SSRLCV_HIP_TRY(hipGetDevice(&dev));                                                                         \
-      SSRLCV_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));                    \
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_gauss_mfma<RR>, kMfmaThreads,         \
-                                                       MfmaCfg<RR>::ldsBytes) != hipSuccess || occ < 1)           \
-        occ = 1;                                                                                                  \
-      blocksPerCu = occ;                                                                                          \
-    }                                                                                                             \
-    uint32_t by = ((uint32_t)(blocksPerCu * cus) + bx - 1) / bx;                                                  \
-    rows = (h + by - 1) / by;                                                                                     \
-    rows = rows < 64 ? 64 : rows;                                                                                 \
-    rows = (rows + kMT - 1) / kMT * kMT;                                                                          \
-    a.rowsPerBlock = rows;                                                                                        \
-    grid = dim3(bx, (h + rows - 1) / rows);                                                                       \
-    hipLaunchKernelGGL(k_gauss_mfma<RR>, grid, dim3(kMfmaThreads), MfmaCfg<RR>::ldsBytes, st, a);                 \
+#define SSRLCV_LAUNCH_MFMA(RR, TW)                                                                                \
+  do {                                                                                                              \
+    static int blocksPerCu = 0, cus = 0;                                                                            \
+    if (!blocksPerCu) {                                                                                             \
+      SSRLCV_HIP_TRY(hipFuncSetAttribute((const void*)k_gauss_mfma<RR, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         (int)MfmaCfg<RR, TW>::ldsBytes));                                          \
+      int dev = 0, occ = 0;                                                                                         \
+      SSRLCV_HIP_TRY(hipGetDevice(&dev));                                                                           \
+      SSRLCV_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));                      \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_gauss_mfma<RR, TW>, kMfmaThreads,       \
+                                                       MfmaCfg<RR, TW>::ldsBytes) != hipSuccess || occ < 1)         \
+        occ = 1;                                                                                                    \
+      blocksPerCu = occ;                                                                                            \
+    }                                                                                                               \
+    const uint32_t bxm = (w + (TW) - 1) / (TW);                                                                     \
+    uint32_t by = ((uint32_t)(blocksPerCu * cus) + bxm - 1) / bxm;                                                  \
+    rows = (h + by - 1) / by;                                                                                       \
+    rows = rows < 64 ? 64 : rows;                                                                                   \
+    rows = (rows + kMT - 1) / kMT * kMT;                                                                            \
+    a.rowsPerBlock = rows;                                                                                          \
+    grid = dim3(bxm, (h + rows - 1) / rows);                                                                        \
+    const size_t ldsB = MfmaCfg<RR, TW>::ldsBytes;                                                                  \
+    hipLaunchKernelGGL((k_gauss_mfma<RR, TW>), grid, dim3(kMfmaThreads), ldsB, st, a);                              \
   } while (0)
+    // 128-column strips let two blocks (8 waves each) share a CU's 160 KB of LDS (R <= 23).  Alone on the chip they are
+    // slower than the 256-column ones (more halo, two accumulation chains per wave instead of four: 0.632 / 0.834 / 0.801
+    // against 0.608 / 0.673 / 0.771 ms per 16384^2 level at 23 / 33 / 47 taps), but octaves >= 1 run beside the DoG kernel
+    // of the previous octave, whose resident blocks keep the big ones off the CUs: the narrow strips are used for the
+    // smaller levels (build_dog 2.57 -> 2.48 ms per 4096^2 image).  SSRLCV_GAUSS_WIDE=1 / SSRLCV_GAUSS_NARROW=1 force one.
+    static const bool forceWide = getenv("SSRLCV_GAUSS_WIDE") != nullptr, forceNarrow = getenv("SSRLCV_GAUSS_NARROW") != nullptr;
+    const bool wide = forceWide || (!forceNarrow && (size_t)w * h >= ((size_t)1 << 25));
     switch (RT) {
-      case 6: SSRLCV_LAUNCH_MFMA(6); break;
-      case 8: SSRLCV_LAUNCH_MFMA(8); break;
-      case 11: SSRLCV_LAUNCH_MFMA(11); break;
-      case 16: SSRLCV_LAUNCH_MFMA(16); break;
-      case 23: SSRLCV_LAUNCH_MFMA(23); break;
-      default: SSRLCV_LAUNCH_MFMA(32); break;
+      case 6: if (wide) SSRLCV_LAUNCH_MFMA(6, 256); else SSRLCV_LAUNCH_MFMA(6, 128); break;
+      case 8: if (wide) SSRLCV_LAUNCH_MFMA(8, 256); else SSRLCV_LAUNCH_MFMA(8, 128); break;
+      case 11: if (wide) SSRLCV_LAUNCH_MFMA(11, 256); else SSRLCV_LAUNCH_MFMA(11, 128); break;
+      case 16: if (wide) SSRLCV_LAUNCH_MFMA(16, 256); else SSRLCV_LAUNCH_MFMA(16, 128); break;
+      case 23: if (wide) SSRLCV_LAUNCH_MFMA(23, 256); else SSRLCV_LAUNCH_MFMA(23, 128); break;
+      default: SSRLCV_LAUNCH_MFMA(32, 256); break;
     }
 #undef SSRLCV_LAUNCH_MFMA
   }
