@@ -15,6 +15,22 @@ def capi():
     return c
 
 
+@pytest.fixture(scope="module")
+def dense2048(capi):
+    """The 2048^2 bench-generator image and the oracle's key points (after the window check) and features for it:
+    one oracle scale space serves both comparisons below."""
+    import bench
+    S = 2048
+    img = bench.synth_images(1, S, S, seed=5, device="cuda")[0]
+    osf = H.OracleSift(H.oracle(), img.cpu().numpy())
+    try:
+        okps, oidx = osf.keypoints(5)
+        of = osf.features()
+    finally:
+        osf.close()
+    return img, okps, oidx, of
+
+
 def test_sift_4096_is_deterministic_and_well_formed(capi):
     import torch
     import bench
@@ -88,23 +104,17 @@ def test_triangulation_round_trip_one_million_bundles(capi):
     assert abs(float(esum.item()) - float(err.astype(np.float64).sum())) <= 2e-3 * float(err.astype(np.float64).sum())
 
 
-def test_keypoint_lists_2048_dense_match_oracle_bit_for_bit(capi):
+def test_keypoint_lists_2048_dense_match_oracle_bit_for_bit(capi, dense2048):
     """A 2048^2 image of the bench generator (feature-dense noise, ~3e5 key points): every key point that survives
     extrema search -> noise -> refinement (+ sort, re-scan) -> noise -> edges -> window check has the oracle's octave,
     blur, location and intensity bit for bit, in the oracle's order, and extremaBlurIndices agree.  These stages are
     +-*/ only (the oracle finishes this size in ~10-20 s); sigma goes through powf and is held to 3e-7 relative."""
-    import bench
+    img, okps, oidx, _ = dense2048
     S = 2048
-    img = bench.synth_images(1, S, S, seed=5, device="cuda")[0]
     plan = capi.SiftPlan(S, S)
     plan.build_dog(img)
     plan.set_stop_stage(5)
     plan.describe()
-    osf = H.OracleSift(H.oracle(), img.cpu().numpy())
-    try:
-        okps, oidx = osf.keypoints(5)
-    finally:
-        osf.close()
     pos = 0
     for o in range(4):
         g, gidx, overflow = plan.keypoints(o, H.SSKEYPOINT)
@@ -121,20 +131,18 @@ def test_keypoint_lists_2048_dense_match_oracle_bit_for_bit(capi):
     assert pos == len(okps) and pos > 100000
 
 
-def test_features_2048_dense_against_oracle(capi):
+def test_features_2048_dense_against_oracle(capi, dense2048):
     """The same 2048^2 image through orientation and descriptors (404 745 features).  Feature count, order and every
     location are the oracle's bit for bit.  theta and the descriptor bytes pass through exp / atan2 / sincos of two
     different libms (ocml on the device, glibc in the oracle): measured on MI355X 4 features (1e-5) sit on a
     histogram near-tie and interpolate a different peak (theta off by up to 0.07 rad), 15 descriptors differ by a
     squared L2 above the reference's own tolerance of 20 (test/Pipeline.cu:33), 0.013 % of all bytes differ at all.
     The bounds below leave a factor ~5 over those counts."""
-    import bench
+    img, _, _, of = dense2048
     S = 2048
-    img = bench.synth_images(1, S, S, seed=5, device="cuda")[0]
     plan = capi.SiftPlan(S, S)
     plan.extract(img)
     gf = plan.features_host(H.FEATURE)
-    of = H.oracle_sift(H.oracle(), img.cpu().numpy())
     assert len(gf) == len(of) > 300000
     assert np.array_equal(gf["loc"], of["loc"])
     assert np.allclose(gf["sigma"], of["sigma"], rtol=3e-7, atol=0)
