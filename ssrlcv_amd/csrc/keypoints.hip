@@ -526,16 +526,16 @@ __global__ __launch_bounds__(256) void k_thetas(const OctaveState* st, const ssr
 
 // ---- S14: fillDescriptors(SSKeyPoint) (src/SIFT_FeatureFactory.cu:475-549) ------------------------------------------------
 // One WAVE per key point (the reference: a 4x4x8 block of which 16 threads sweep the window).  The samples of the
-// rotated (2w+1)^2 window are packed densely over the lanes, 64 per batch; each sample votes into the wave's 4x4x8 LDS
-// histogram (the reference also uses shared-memory atomics, :521).  This kernel is VALU-issue bound (about 1.6 M key
-// points x 10-40 batches per 4096^2 image), so the loop is written for instruction count:
-//   - everything that depends on the key point only (rotated cell centres, window constants) is wave-uniform and
-//     moved to SGPRs with v_readfirstlane, so the 16 cell tests are {v_sub, v_cmp} pairs on SGPR operands;
+// rotated (2w+1)^2 window vote into the wave's 4x4x8 LDS histogram (the reference also uses shared-memory atomics,
+// :521).  The kernel sits between VALU issue and the LDS atomic rate, so the loop is written for instruction count:
+//   - a lane carries the four-fold ORBIT of a window sample (see the loop): one coordinate set, one Gaussian and one
+//     pass over the 16 cells serve four samples;
+//   - everything that depends on the key point only comes from a lane-parallel pre-pass (k_desc_consts) or is
+//     wave-uniform in SGPRs (rotated cell centres), so a cell test is {2 v_sub, v_max, v_cmp} on SGPR operands;
 //   - the 16 cells are visited in a uniform, fully unrolled loop: a cell's vote code runs once under the lane mask of
-//     its passing samples (typically 8-10 of the 16 cells have any) instead of a per-lane loop over set bits, the
-//     coordinate differences of the test are reused for the weights and the LDS address is lane base + immediate;
-//   - votes are 2^-31 fixed point: one v_cvt_u32_f32 instead of an emulated f32->u64 conversion;
-//   - the x / y halves of the cell arithmetic and the two orientation votes use packed fp32 instructions.
+//     its passing orbits instead of a per-lane loop over set bits, the coordinate differences of the test are reused
+//     for the weights and the LDS address is lane base + immediate;
+//   - votes are fixed point in 32-bit bins with a per-key-point scale, 8 lane-private copies (see kDescCopies).
 __device__ __forceinline__ float uniform_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
                                                      float pixelWidth, const DescConst* __restrict__ consts,
                                                      const uint32_t* featBase, int octave,
                                                      ssrlcv_sift_feature* __restrict__ features, uint32_t maxFeatures) {
-  // lane-private copies of the 128 bins (copy = lane & 3, bin-major / copy-minor) keep same-address conflicts low
+  // lane-private copies of the 128 bins (copy = lane & 7, bin-major / copy-minor) keep same-address conflicts low
   __shared__ unsigned s_bins[4][(1 + 128 + 2) * kDescCopies];  // one bin of padding in front, two behind (votes of 0)
   __shared__ __attribute__((aligned(8))) uint8_t s_bytes[4][128];
   const int n = st->hasExtrema ? st->n : 0;
