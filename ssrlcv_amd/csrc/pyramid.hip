@@ -5,10 +5,11 @@
 //     are staged in LDS with their horizontal halo (coalesced, mirrored border), the horizontal pass runs from LDS
 //     with an 8-outputs-per-thread register block, the vertical pass keeps a sliding window of 2R+8 horizontally
 //     filtered rows IN REGISTERS (one column per thread), so every input pixel is fetched once per strip and every
-//     tap costs one v_fma_f32 whose weight operand is an SGPR (weights travel in the kernarg segment);
+//     tap costs one v_fma_f32 whose weight operand is an SGPR (weights travel in the kernarg segment); from 23 taps
+//     up the same two passes run as banded-Toeplitz products on the f32 matrix cores (k_gauss_mfma), bit-identical;
 //   * accumulation order is the reference's (k = -R..R, fmaf chain), so levels are bit-identical to the oracle;
 //   * the level's global min/max (normalizeImage finds it on the host after a D2H copy, src/Image.cu:631-649) is
-//     reduced in the epilogue of the same kernel: wave reduction + one integer atomic per wave;
+//     reduced in the epilogue of the same kernel: block reduction + one integer atomic pair per block;
 //   * both normalisations + the DoG subtraction are one streaming kernel reading 6 levels and writing 5 (float4
 //     lanes), which also reduces the DoG levels' min/max for findKeyPoints' second normalisation.
 #include <hip/hip_runtime.h>
