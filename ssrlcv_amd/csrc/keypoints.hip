@@ -715,6 +715,11 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
 #pragma unroll
       for (int cell = 0; cell < 16; ++cell) {
         const int nx = cell >> 2, ny = cell & 3;
+        // The orbit's first member lies in the quadrant x >= 1, y >= 0 (or is the centre).  A cell passes only if its
+        // centre is within sqrt(2) binWidth of the sample (the test is |R (h - p)|_inf <= binWidth), and the centres of
+        // column nx = 0 / row ny = 0 sit at -1.5 binWidth: at least 1.5 binWidth from every such sample.  Those seven
+        // cells can only be reached by the turned members, through the symmetry -- nine tests per orbit, not sixteen.
+        if (nx == 0 || ny == 0) continue;
         const int cellB = (3 - ny) * 4 + nx, cellC = 15 - cell, cellD = ny * 4 + (3 - nx);
         const float tx = fabsf(rc[cell].x - cx), ty = fabsf(rc[cell].y - cy);
         if (fmaxf(tx, ty) <= bwl) {
