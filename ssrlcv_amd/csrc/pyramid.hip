@@ -1010,6 +1010,13 @@ int ssrlcv_hip_dog_normalised_sub(const float* const levels_host[6], const float
 int ssrlcv_sift_plan_create(uint32_t w, uint32_t h, const ssrlcv_sift_params* params, ssrlcv_sift_plan** out) {
   if (!out || !params || !w || !h) return SSRLCV_ERR_INVALID_ARG;
   if (params->maxOrientations == 0 || params->maxOrientations > (uint32_t)svp::kMaxOrient) return SSRLCV_ERR_UNSUPPORTED;
+  // The sampling kernels index their windows with 16-bit multiply-high divisions: the descriptor window half-width
+  // ceil(lambda * sigma / pixelWidth) must stay below 256 and the orientation window 2 ceil(3 lambda_o sigma /
+  // pixelWidth) + 1 below 256.  sigma / pixelWidth of a refined key point is below 0.5 sqrt(2) * sqrt(2)^5 / 0.5 = 8,
+  // so the reference's 6.0 / 1.5 are far inside; absurd widths are refused instead of sampled wrongly.
+  if (!(params->descriptorContribWidth > 0.0f) || params->descriptorContribWidth > 30.0f ||
+      !(params->orientationContribWidth > 0.0f) || params->orientationContribWidth > 5.0f)
+    return SSRLCV_ERR_UNSUPPORTED;
   // "image too small" check of ScaleSpace::ScaleSpace (src/FeatureFactory.cu:341-345): numResize = 2^(start+depth.x)
   if (w / 8 == 0 || h / 8 == 0) return SSRLCV_ERR_INVALID_ARG;
   // S3, makeBinnable as ScaleSpace::ScaleSpace applies it (src/FeatureFactory.cu:364-376, src/Image.cu:966-995): even

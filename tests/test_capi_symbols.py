@@ -86,3 +86,7 @@ def test_sift_plan_layout_is_host_only():
     # images whose octave 0 is below 512 pixels on a side are refused (-4 = SSRLCV_ERR_UNSUPPORTED), not mishandled
     assert lib.ssrlcv_sift_plan_create(ctypes.c_uint32(200), ctypes.c_uint32(1024), ctypes.byref(p),
                                        ctypes.byref(plan)) == -4
+    # contribution widths whose sampling windows would outgrow the kernels' 16-bit window indexing are refused too
+    wide = SiftParams(2, 0.8, 1.5, 64.0, 0)
+    assert lib.ssrlcv_sift_plan_create(ctypes.c_uint32(1024), ctypes.c_uint32(1024), ctypes.byref(wide),
+                                       ctypes.byref(plan)) == -4
