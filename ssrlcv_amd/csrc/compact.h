@@ -51,17 +51,19 @@ __global__ __launch_bounds__(kThreads) void k_count(uint32_t n, uint32_t numRuns
 }
 
 // Exclusive scan over the NKEYS*numBlocks table (numBlocks = number of wave runs here) in key-major order; totals[k] = number of elements with key k,
-// totals[NKEYS] = grand total.  Single block of 1024 threads, each thread scanning 4 consecutive entries per round.
-template <int NKEYS>
-__global__ __launch_bounds__(1024) void k_scan(uint32_t numBlocks, uint32_t* __restrict__ counts,
-                                               uint32_t* __restrict__ totals) {
-  __shared__ uint32_t s_wave[16];
+// totals[NKEYS] = grand total.  Single block, each thread scanning 4 consecutive entries per round: 1024 threads for the
+// large pixel-domain tables, 256 for the list partitions -- a 16-wave block needs 16 free wave slots on ONE CU, and the
+// short chains of octaves 1-3 waited up to 0.96 ms for that beside the oversubscribed orientation kernel of octave 0.
+template <int NKEYS, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_scan(uint32_t numBlocks, uint32_t* __restrict__ counts,
+                                                  uint32_t* __restrict__ totals) {
+  __shared__ uint32_t s_wave[THREADS / 64];
   __shared__ uint32_t s_carry;
   __shared__ uint32_t s_keystart[NKEYS + 1];
   const uint32_t total_entries = NKEYS * numBlocks;
   if (threadIdx.x == 0) s_carry = 0;
   __syncthreads();
-  for (uint32_t start = 0; start < total_entries; start += 4096) {
+  for (uint32_t start = 0; start < total_entries; start += THREADS * 4) {
     uint32_t i0 = start + threadIdx.x * 4;
     uint32_t v[4];
 #pragma unroll
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(1024) void k_scan(uint32_t numBlocks, uint32_t* __r
       excl += v[j];
     }
     __syncthreads();
-    if (threadIdx.x == 1023) s_carry = excl;
+    if (threadIdx.x == THREADS - 1) s_carry = excl;
     __syncthreads();
   }
   if (threadIdx.x == 0) s_keystart[NKEYS] = s_carry;
@@ -140,7 +142,8 @@ inline hipError_t partition(uint32_t n, MaskFn maskfn, EmitFn emit, uint32_t* wo
   if (totals_out) *totals_out = totals;
   if (nb == 0) return hipMemsetAsync(totals, 0, sizeof(uint32_t) * (NKEYS + 1), stream);
   hipLaunchKernelGGL((k_count<NKEYS, PER_THREAD, MaskFn>), dim3(nb), dim3(kThreads), 0, stream, n, runs, maskfn, counts);
-  hipLaunchKernelGGL((k_scan<NKEYS>), dim3(1), dim3(1024), 0, stream, runs, counts, totals);
+  if ((size_t)NKEYS * runs > 16384) hipLaunchKernelGGL((k_scan<NKEYS, 1024>), dim3(1), dim3(1024), 0, stream, runs, counts, totals);
+  else hipLaunchKernelGGL((k_scan<NKEYS, 256>), dim3(1), dim3(256), 0, stream, runs, counts, totals);
   hipLaunchKernelGGL((k_scatter<NKEYS, PER_THREAD, MaskFn, EmitFn>), dim3(nb), dim3(kThreads), 0, stream, n, runs,
                      maskfn, emit, counts);
   return hipGetLastError();
@@ -247,7 +250,8 @@ inline hipError_t partition_flags(uint32_t n, const uint8_t* flags, EmitFn emit,
   if (totals_out) *totals_out = totals;
   if (nb == 0) return hipMemsetAsync(totals, 0, sizeof(uint32_t) * (NKEYS + 1), stream);
   hipLaunchKernelGGL((k_count_flags<NKEYS>), dim3(nb), dim3(kThreads), 0, stream, n, runs, flags, counts);
-  hipLaunchKernelGGL((k_scan<NKEYS>), dim3(1), dim3(1024), 0, stream, runs, counts, totals);
+  if ((size_t)NKEYS * runs > 16384) hipLaunchKernelGGL((k_scan<NKEYS, 1024>), dim3(1), dim3(1024), 0, stream, runs, counts, totals);
+  else hipLaunchKernelGGL((k_scan<NKEYS, 256>), dim3(1), dim3(256), 0, stream, runs, counts, totals);
   hipLaunchKernelGGL((k_scatter_flags<NKEYS, EmitFn>), dim3(nb), dim3(kThreads), 0, stream, n, runs, flags, emit, counts);
   return hipGetLastError();
 }
