@@ -178,6 +178,8 @@ void oracle_sift_octave_info(const oracle_sift* s, int octave, uint32_t* w, uint
 /* Blur::Blur tap generation (src/FeatureFactory.cu:15-18,29-33); returns odd tap count */
 int oracle_gauss_kernel(float sigma, float pixelWidth, float* weights);
 /* fillDescriptors(SSKeyPoint) for one keypoint on a (twice-normalised) DoG level */
+/* 0 (default): order-independent fixed-point bin sums + tree norms; 1: float raster-order sums (see oracle_sift.c) */
+void oracle_set_descriptor_sum_mode(int mode);
 void oracle_fill_descriptor(const float* level, uint32_t W, uint32_t H, float pixelWidth, float lambda,
                             const o_sskeypoint* kp, o_feature* feat);
 /* full keypoint + descriptor stage on an existing scale space; *out malloc'd (oracle_free) */
@@ -193,4 +195,7 @@ int oracle_sift_keypoints(oracle_sift* s, int stage, o_sskeypoint** out, int blu
 #ifdef __cplusplus
 }
 #endif
+/* element-wise evaluation of oracle_libm.h (fn: 0 expf(a), 1 atan2f(a,b), 2 sinf, 3 cosf, 4 tanf, 5 powf(a,b)) */
+void oracle_math_eval(int fn, const float* a, const float* b, float* out, size_t n);
+
 #endif

@@ -417,7 +417,7 @@ static void refine_one(const octave_t* oc, o_sskeypoint* pkp) {
       kp.discard = (lx <= 0 || ly <= 0 || lx >= W - 1 || ly >= H - 1);
       if (kp.discard) break;
       kp.intensity = PX(pm, ly, lx) - (0.5f * ((temp[0] * grad[0]) + (temp[1] * grad[1]) + (temp[2] * grad[2])));
-      kp.sigma = sigmaMin * powf(mult, ((float)kp.blur + offset[2]));
+      kp.sigma = sigmaMin * sv_powf(mult, ((float)kp.blur + offset[2]));
       if (fabsf(offset[2]) > 0.5) kp.blur += (offset[2] > 0) ? 1 : -1;
       break;
     } else if (attempt == 4) {
@@ -543,10 +543,10 @@ static void compute_thetas(const octave_t* oc, const float* level, const o_sskey
     for (float x = minx; x <= maxx; x += 1.0f) {
       o_float2 g = pixel_gradient(level, W, H, (int)llroundf(x), (int)llroundf(y));
       float tx = x - kx, ty = y - ky;
-      float angle = fmodf(atan2f(g.y, g.x) + (2.0f * pi), 2.0f * pi);
+      float angle = fmodf(sv_atan2f(g.y, g.x) + (2.0f * pi), 2.0f * pi);
       int bin = (int)floorf(angle / rad10);
       float mag = sqrtf((g.x * g.x) + (g.y * g.y));
-      float wgt = expf(-((tx * tx) + (ty * ty)) / weight);
+      float wgt = sv_expf(-((tx * tx) + (ty * ty)) / weight);
       if (bin >= 0 && bin < 36) hist[bin] = fmaf(mag, wgt, hist[bin]); /* bin 36 would be an OOB write upstream */
     }
   }
@@ -614,26 +614,73 @@ static void compute_orientations(octave_t* oc, float orientationThreshold, unsig
 }
 
 /* fillDescriptors(SSKeyPoint) (src/SIFT_FeatureFactory.cu:475-549) for one keypoint.
- * Bin accumulation order here: samples in raster order (the reference's shared-memory atomicAdd order is
- * non-deterministic); norm sums in CUDA linear thread order (x fastest, then y, then z). */
+ *
+ * Every vote `temp` is the reference's expression, operand for operand.  What the reference leaves UNDEFINED is the
+ * order of its sums: the 4x4x8 bins and both norms are accumulated with shared-memory float atomicAdd (:521,:533,:539)
+ * from 16 resp. 128 threads, so two runs of the reference itself differ in the last bits (its own two fixture runs
+ * differ by one descriptor byte).  A restatement has to pick an order; two are offered:
+ *   sum mode 0 (default): order-INDEPENDENT.  A vote enters its bin as the integer nearest to temp * 2^k (halves
+ *     round up; k chosen per key point so that no bin can reach 2^31: k = 22 at w = 12, 20 at w = 29); the integer
+ *     sum is exact, hence the same in any order -- the one definition a parallel implementation can reproduce bit
+ *     for bit.  (Rounding matters: with truncation every bin sits low by half a unit per vote, enough to move
+ *     descriptor bytes and to lose 2 of the 13 534 golden matches.)  The two norms are summed as a balanced binary
+ *     tree over the bins in [nx][ny][k] order (pairs 64 apart first, then 32, 16, ... 1).
+ *   sum mode 1: float sums, samples in raster order, norm in CUDA linear thread order (the round-1 oracle).
+ * tests/test_oracle_golden.py pins BOTH against the reference's golden match sets (13 534 / 21 177 exactly). */
+static int g_desc_sum_mode = 0;
+void oracle_set_descriptor_sum_mode(int mode) { g_desc_sum_mode = mode; }
+
+/* fixed-point exponent of sum mode 0: the largest k with sqrt(2) (w + 2)^2 2^k < 2^31 (a bin receives fewer than
+ * (2 binWidth + 2)^2 = (w + 2)^2 votes, each at most sqrt(2): gradient of a [0,1]-normalised level) */
+static int desc_vote_exponent(float windowWidth) {
+  int boundExp;
+  (void)frexpf(1.4143f * ((windowWidth + 2.0f) * (windowWidth + 2.0f)), &boundExp);
+  return 31 - boundExp;
+}
+
+/* nearest integer, halves up (exact: q - floorf(q) is exact in float) */
+static inline uint32_t vote_fixed(float q) {
+  float f = floorf(q);
+  return (uint32_t)f + ((q - f) >= 0.5f ? 1u : 0u);
+}
+
+/* sum of 128 squares as the balanced tree described above */
+static float tree_norm(const float* v /* [128], [nx][ny][k] order */) {
+  float p[64];
+  for (int i = 0; i < 64; ++i) p[i] = (v[i] * v[i]) + (v[i + 64] * v[i + 64]);
+  for (int o = 32; o > 0; o >>= 1)
+    for (int i = 0; i < o; ++i) p[i] = p[i] + p[i + o];
+  return p[0];
+}
+
 void oracle_fill_descriptor(const float* level, uint32_t W, uint32_t H, float pixelWidth, float lambda,
                             const o_sskeypoint* kp, o_feature* feat) {
   const float pi = O_PI_F;
   float bins[4][4][8];
+  uint32_t ibins[4][4][8];
   memset(bins, 0, sizeof bins);
+  memset(ibins, 0, sizeof ibins);
+  const int exact = g_desc_sum_mode == 0;
   float kx = kp->loc.x, ky = kp->loc.y;
   float windowWidth = ceilf(kp->sigma * lambda / pixelWidth);
   float theta = kp->theta;
   float binWidth = windowWidth / 2.0f;
   float rad45 = pi / 4.0f;
-  float c = cosf(-theta), s = sinf(-theta);
+  float c = sv_cosf(-theta), s = sv_sinf(-theta);
+  const float voteScale = ldexpf(1.0f, desc_vote_exponent(windowWidth));
   for (float y = -windowWidth; y <= windowWidth; y += 1.0f) {
     for (float x = -windowWidth; x <= windowWidth; x += 1.0f) {
       float cx = (x * c) + (y * s), cy = (-x * s) + (y * c);
       if (fabsf(cx) > windowWidth || fabsf(cy) > windowWidth) continue;
-      o_float2 g = pixel_gradient(level, (int)W, (int)H, (int)llroundf(cx + kx), (int)llroundf(cy + ky));
-      float mag = sqrtf((g.x * g.x) + (g.y * g.y)) * expf(-((cx * cx) + (cy * cy)) / (2.0f * windowWidth * windowWidth));
-      float ang = fmodf(atan2f(g.y, g.x) - theta + (2.0f * pi), 2.0f * pi);
+      /* the reference indexes its W*H gradient array with the FLAT index (:507); the window is the ceiling of the
+       * checked one, so a coordinate may reach -1, W or H: column -1 / W then reads the neighbouring row's gradient
+       * (as upstream); an index outside the array is an out-of-bounds read upstream (undefined) and is DEFINED here
+       * as a zero gradient, which votes nothing. */
+      long long flat = llroundf(cy + ky) * (long long)W + llroundf(cx + kx);
+      o_float2 g = {0.0f, 0.0f};
+      if (flat >= 0 && flat < (long long)W * H) g = pixel_gradient(level, (int)W, (int)H, (int)(flat % W), (int)(flat / W));
+      float mag = sqrtf((g.x * g.x) + (g.y * g.y)) * sv_expf(-((cx * cx) + (cy * cy)) / (2.0f * windowWidth * windowWidth));
+      float ang = fmodf(sv_atan2f(g.y, g.x) - theta + (2.0f * pi), 2.0f * pi);
       for (float nx = 0; nx < 4.0f; nx += 1.0f) {
         for (float ny = 0; ny < 4.0f; ny += 1.0f) {
           float hx = (nx * 0.5f - 0.75f) * windowWidth, hy = (ny * 0.5f - 0.75f) * windowWidth;
@@ -648,7 +695,8 @@ void oracle_fill_descriptor(const float* level, uint32_t W, uint32_t H, float pi
               if (angle < rad45) {
                 angle /= rad45;
                 float temp = (1.0f - hx) * (1.0f - hy) * (1.0f - angle) * mag;
-                bins[(int)nx][(int)ny][k] += temp;
+                if (exact) ibins[(int)nx][(int)ny][k] += vote_fixed(temp * voteScale);
+                else bins[(int)nx][(int)ny][k] += temp;
               }
             }
           }
@@ -656,10 +704,17 @@ void oracle_fill_descriptor(const float* level, uint32_t W, uint32_t H, float pi
       }
     }
   }
+  if (exact) { /* the normalisation below is scale invariant: the integer sums are used as they are */
+    for (int xx = 0; xx < 4; ++xx)
+      for (int yy = 0; yy < 4; ++yy)
+        for (int z = 0; z < 8; ++z) bins[xx][yy][z] = (float)ibins[xx][yy][z];
+  }
   float norm = 0.0f;
-  for (int z = 0; z < 8; ++z)
-    for (int yy = 0; yy < 4; ++yy)
-      for (int xx = 0; xx < 4; ++xx) norm += bins[xx][yy][z] * bins[xx][yy][z];
+  if (exact) norm = tree_norm(&bins[0][0][0]);
+  else
+    for (int z = 0; z < 8; ++z)
+      for (int yy = 0; yy < 4; ++yy)
+        for (int xx = 0; xx < 4; ++xx) norm += bins[xx][yy][z] * bins[xx][yy][z];
   float sq = sqrtf(norm);
   for (int xx = 0; xx < 4; ++xx)
     for (int yy = 0; yy < 4; ++yy)
@@ -668,9 +723,11 @@ void oracle_fill_descriptor(const float* level, uint32_t W, uint32_t H, float pi
         if (bins[xx][yy][z] > 0.2f) bins[xx][yy][z] = 0.2f;
       }
   norm = 0.0f;
-  for (int z = 0; z < 8; ++z)
-    for (int yy = 0; yy < 4; ++yy)
-      for (int xx = 0; xx < 4; ++xx) norm += bins[xx][yy][z] * bins[xx][yy][z];
+  if (exact) norm = tree_norm(&bins[0][0][0]);
+  else
+    for (int z = 0; z < 8; ++z)
+      for (int yy = 0; yy < 4; ++yy)
+        for (int xx = 0; xx < 4; ++xx) norm += bins[xx][yy][z] * bins[xx][yy][z];
   sq = sqrtf(norm);
   for (int xx = 0; xx < 4; ++xx)
     for (int yy = 0; yy < 4; ++yy)

@@ -248,6 +248,15 @@ def normalize_(img_d, n, mm_d):
     check(LIB.ssrlcv_hip_normalize(ptr(img_d), c_sz(n), ptr(mm_d), stream_ptr()))
 
 
+def math_eval(fn, a, b=None):
+    """Test hook: element-wise device elementary function (0 expf, 1 atan2f(a,b), 2 sinf, 3 cosf, 4 tanf, 5 powf(a,b))."""
+    a_d = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    b_d = None if b is None else torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32)).cuda()
+    out = torch.empty_like(a_d)
+    check(LIB.ssrlcv_hip_math_eval(c_int(fn), ptr(a_d), ptr(b_d), ptr(out), c_sz(a_d.numel()), stream_ptr()))
+    return out.cpu().numpy()
+
+
 # ------------------------------------------------------------------ SIFT pipeline
 class SiftPlan:
     """Owns an ssrlcv_sift_plan and (optionally) the workspace tensor for one W x H image slot."""

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void k_refine(const OctaveState* st, ssrlcv_ss
         kp.discard = (uint8_t)(lx <= 0 || ly <= 0 || lx >= W - 1 || ly >= H - 1);
         if (kp.discard) break;
         kp.intensity = PM(ly, lx) - (0.5f * ((temp[0] * grad[0]) + (temp[1] * grad[1]) + (temp[2] * grad[2])));
-        kp.sigma = sigmaMin * powf(mult, ((float)bl + offset[2]));
+        kp.sigma = sigmaMin * sv_powf(mult, ((float)bl + offset[2]));
         if (fabsf(offset[2]) > 0.5) bl += (offset[2] > 0) ? 1 : -1;
         break;
       } else if (attempt == 4) {
@@ -355,11 +355,16 @@ __global__ __launch_bounds__(256) void k_polar(LevelSet L, float2* __restrict__ 
     s_n[i][side ? 257 : 0] = sv::div_by(px[(size_t)yy * W + hx] - mn, range);
   }
   __syncthreads();
+  float2* __restrict__ lvlOut = out + (size_t)blockIdx.z * svp::polar_level_stride(W, H);
+  if (blockIdx.x == 0 && blockIdx.y == 0) {  // the zero entries around the table (see svp::polar_level_stride)
+    if (t == 0) lvlOut[0] = make_float2(0.0f, 0.0f);
+    for (int i = t; i < W + 1; i += 256) lvlOut[1 + (size_t)W * H + i] = make_float2(0.0f, 0.0f);
+  }
   if (x >= W) return;
   // LDS columns of the two horizontal taps: x - 1 / x + 1, at the image border x / x + 2 resp. x - 2 / x
   const int cl = x == 0 ? 1 : (x == W - 1 ? t - 1 : t);
   const int cr = x == 0 ? 3 : (x == W - 1 ? t + 1 : t + 2);
-  float2* __restrict__ o = out + ((size_t)blockIdx.z * H + y0) * W + x;
+  float2* __restrict__ o = lvlOut + 1 + (size_t)y0 * W + x;
 #pragma unroll
   for (int i = 0; i < kPolRows; ++i) {
     const int y = y0 + i;
@@ -372,130 +377,122 @@ __global__ __launch_bounds__(256) void k_polar(LevelSet L, float2* __restrict__ 
     g.y = up - dn;
     float2 r;
     r.x = sqrtf((g.x * g.x) + (g.y * g.y));
-    r.y = atan2f(g.y, g.x);
+    r.y = sv_atan2f(g.y, g.x);
     o[(size_t)i * W] = r;
   }
 }
-// Histogram votes in 2^-31 fixed point, accumulated with 64-bit integer LDS atomics: ds_add_f32 runs at about one lane
-// per clock on gfx950 (measured: 27 of 55 ms of the first version of k_descriptors), ds_add_u64 does not.  A vote is
-// weight * |grad| with weight <= 1 and |grad| <= sqrt(2) (components of a [0,1]-normalised level), so
-// vote * 2^31 < 2^32; a bin receives < 2^12 votes, so the 64-bit sum cannot overflow.  The integer sum is exact and
-// order independent, i.e. deterministic (the reference's shared float atomicAdd is not); the truncation error is
-// < 2^-31 per vote, far below the float rounding of the reference's own running sum.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// roundf / llroundf of a non-negative coordinate: floor + (fraction >= 0.5), 4 instructions instead of 8
-__device__ __forceinline__ int round_pos(float v) { return (int)v + (__builtin_amdgcn_fractf(v) >= 0.5f ? 1 : 0); }
-__device__ __forceinline__ float from_fixed31(unsigned long long t) { return (float)t * 4.656612873077393e-10f; }
+// roundf / llroundf of a non-negative coordinate: v_cvt_rpi_i32_f32 = floor(v + 0.5) evaluated exactly (see round_coord)
+__device__ __forceinline__ int round_pos(float v) {
+  int r;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
 
 // fmodf(v, p) for -p < v < 2p, exact: fmod is an exact operation and v - p is exact for p <= v < 2p (Sterbenz).  That
 // range is all the sampling kernels feed it: atan2 in [-pi, pi], theta in [0, 2 pi), plus 2 pi.
 __device__ __forceinline__ float fmod_2pi_above(float v, float p) { return v >= p ? v - p : v; }
-// pixel (x, y) of a polar table: the index fits 32 bits for any level up to 65536^2, which keeps the multiply 32-bit
+// pixel (x, y) of a polar table by its flat index y * W + x (-1 .. W*H + W: see svp::polar_level_stride; `pl` points at
+// flat index 0): the index fits 32 bits for any level up to 32768^2, which keeps the multiply 32-bit
 __device__ __forceinline__ float2 polar_px(const float2* __restrict__ pl, int W, int x, int y) {
-  return pl[(uint32_t)y * (uint32_t)W + (uint32_t)x];
+  return pl[y * W + x];
+}
+// llroundf of a window coordinate v > -1: v_cvt_rpi_i32_f32 is floor(v + 0.5) evaluated exactly (tools/f64_rate.hip:
+// equal to round-half-up for every float in (-1, 2^31)), which is llroundf except at v == -0.5 (half away from zero)
+__device__ __forceinline__ int round_coord(float v) {
+  int r;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+  return v == -0.5f ? -1 : r;
 }
 
 // ---- S13: computeThetas(SSKeyPoint) (src/FeatureFactory.cu:1004-1112) -----------------------------------------------------
-// One WAVE per key point (the reference: one thread).  The (2w+1)^2 window samples are packed densely over the lanes,
-// 64 per batch (sample index -> row, column by a multiply-high); the 36-bin histogram lives in LDS as 2^-31 fixed-point
-// integers (see k_descriptors).  Sample coordinates are minx + column: for coordinates below 2^23 that is the value the
-// reference's repeated `+= 1.0f` produces (an addition of 1 is exact except when it crosses a binade, where both round
-// the same exact sum).  Peak tests run one bin per lane; only the insertion of the (1-4) surviving peaks into the
-// best-N list is sequential, in ascending bin order like the reference.
+// The reference runs ONE THREAD per key point and accumulates its 36-bin histogram with a sequential float
+// multiply-add chain in raster order of the window (:1031-1047): that order is part of the result (float addition does
+// not associate), and the peak tests and the parabolic interpolation read the histogram's last bits.  So this kernel
+// keeps the reference's shape -- one lane per key point, the literal double loop with its float loop counters, one
+// fmaf per sample -- and spends its effort around it instead:
+//   - the histogram lives in LDS, one conflict-free column per lane (bin-major), not in scratch;
+//   - gradient magnitude / direction come from the per-pixel polar tables (k_polar) instead of 4 gathers + sqrtf +
+//     atan2f per sample;
+//   - one-wave blocks (9 KiB of LDS each): the windows of the key points of a wave differ in size and the wave runs as
+//     long as its largest, many small blocks let the dispatcher even that out;
+//   - the next sample's table entry is requested before the current one is processed.
+// The first version of this file ran one WAVE per key point with exact 64-bit fixed-point LDS atomics -- order
+// independent, but not the reference's sum: thetas agreed to ~1e-6 and a handful of peak decisions per million key
+// points flipped.
 template <int MAXO>
-__global__ __launch_bounds__(256) void k_thetas(const OctaveState* st, const ssrlcv_sskeypoint* kps, LevelSet L,
-                                                float pixelWidth, float lambda, float orientationThreshold,
-                                                float* __restrict__ thetas, uint32_t* __restrict__ thetaCnt) {
-  __shared__ unsigned long long s_hist[4][36 * 16];  // 16 lane-private copies: no two lanes of a 16-lane row share a word
+__global__ __launch_bounds__(64) void k_thetas(const OctaveState* st, const ssrlcv_sskeypoint* kps, LevelSet L,
+                                               float pixelWidth, float lambda, float orientationThreshold,
+                                               float* __restrict__ thetas, uint32_t* __restrict__ thetaCnt) {
+  __shared__ float s_hist[36][64];
   const int n = st->hasExtrema ? st->n : 0;
-  // the wave index as a scalar: key-point index, list loads and per-key-point constants then live in SGPRs
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  unsigned long long* hist = s_hist[wave];
-  const int copy = lane & 15;
+  const int gi = blockIdx.x * 64 + threadIdx.x;
+  if (blockIdx.x * 64 >= n) return;  // block-uniform
+  const int t = threadIdx.x;
+  const bool have = gi < n;
   const float pi = SSRLCV_PI_F;
   const float rad10 = pi / 18.0f;
-  const float inv10 = 1.0f / rad10;
-  const float2* __restrict__ polar = L.polar;  // key points live on levels 1..3, whose polar tables are always built
-  for (int gi = blockIdx.x * 4 + wave; gi < n; gi += gridDim.x * 4) {
-    const int seg = __builtin_amdgcn_readfirstlane(segment_of(st, gi));
-    const ssrlcv_sskeypoint kp = kps[gi];
-    const float kx = kp.loc.x, ky = kp.loc.y;
-    const float windowWidth = ceilf(kp.sigma * 3.0f * lambda / pixelWidth);
-    const float minx = kx - windowWidth, miny = ky - windowWidth, maxx = kx + windowWidth, maxy = ky + windowWidth;
-    uint32_t cnt = 0;
-    float outTheta[MAXO];
+  ssrlcv_sskeypoint kp;
+  kp.loc.x = kp.loc.y = 0.0f;
+  kp.sigma = 0.0f;
+  if (have) kp = kps[gi];
+  const int seg = have ? segment_of(st, gi) : 1;
+  const float kx = kp.loc.x, ky = kp.loc.y;
+  const float windowWidth = ceilf(kp.sigma * 3.0f * lambda / pixelWidth);
+  const float minx = kx - windowWidth, miny = ky - windowWidth, maxx = kx + windowWidth, maxy = ky + windowWidth;
+  bool active = have && !(minx < 0.0f || miny < 0.0f || maxx >= (unsigned)(L.w - 1) || maxy >= (unsigned)(L.h - 1));
+  const bool inside = active;
 #pragma unroll
-    for (int i = 0; i < MAXO; ++i) outTheta[i] = -FLT_MAX;
-    if (!(minx < 0.0f || miny < 0.0f || maxx >= (unsigned)(L.w - 1) || maxy >= (unsigned)(L.h - 1))) {
-#pragma unroll
-      for (int i = 0; i < 9; ++i) hist[i * 64 + lane] = 0ull;
-      __builtin_amdgcn_wave_barrier();
-      const float2* __restrict__ pl = polar + (size_t)(seg - 1) * L.h * L.w;
-      const float weight = 2.0f * lambda * lambda * kp.sigma * kp.sigma;
-      // exp(-(r^2) / weight) is evaluated as exp2(r^2 * k2), k2 = -log2(e) / weight: <= 3 ulp from expf of the quotient
-      const float k2 = -1.4426950408889634f / weight;
-      const int S = 2 * (int)windowWidth + 1;
-      const unsigned total = (unsigned)(S * S);
-      const unsigned magic = 0xFFFFFFFFu / (unsigned)S + 1u;  // ceil(2^32 / S): S is odd and > 1
-      auto sample = [&](unsigned sidx, float& x, float& y) {
-        const unsigned r = __umulhi(sidx, magic);  // sidx / S, exact for sidx < 2^16
-        const unsigned cc = sidx - r * (unsigned)S;
-        x = minx + (float)(int)cc;  // (int): one v_cvt_f32_i32; hipcc turns the unsigned mul-hi into a 64-bit conversion
-        y = miny + (float)(int)r;
-      };
-      float nx, ny;
-      sample((unsigned)lane, nx, ny);
-      float2 npg = make_float2(0.0f, 0.0f);
-      if ((unsigned)lane < total) npg = polar_px(pl, L.w, round_pos(nx), round_pos(ny));
-      for (unsigned base = 0; base < total; base += 64) {
-        const float x = nx, y = ny;
-        const float2 pg = npg;
-        const bool ok = base + (unsigned)lane < total;
-        sample(base + 64 + (unsigned)lane, nx, ny);
-        if (base + 64 + (unsigned)lane < total) npg = polar_px(pl, L.w, round_pos(nx), round_pos(ny));
-        const float tx = x - kx, ty = y - ky;
-        const float angle = fmod_2pi_above(pg.y + (2.0f * pi), 2.0f * pi);
-        // bin = floor(angle / rad10) (:1041) without the 12-instruction IEEE division: angle * (1 / rad10) is within
-        // 1e-5 of the quotient (bins < 36), so its floor is the quotient's floor unless it lies within 1e-4 of an
-        // integer; only then (about one batch in a hundred) the wave takes the exact division.
-        const float q = angle * inv10;
-        float fbin = floorf(q);
-        if (__ballot(fabsf(q - rintf(q)) < 1.0e-4f) != 0ull) fbin = floorf(angle / rad10);
-        const int bin = (int)fbin;
-        const float wgt = __builtin_amdgcn_exp2f(((tx * tx) + (ty * ty)) * k2);
-        if (ok && bin >= 0 && bin < 36)
-          atomicAdd(&hist[bin * 16 + copy], (unsigned long long)(unsigned)((pg.x * wgt) * 2147483648.0f));
+  for (int i = 0; i < 36; ++i) s_hist[i][t] = 0.0f;
+  const float2* __restrict__ pl = L.polar + (size_t)(seg - 1) * svp::polar_level_stride(L.w, L.h) + 1;
+  const float weight = 2.0f * lambda * lambda * kp.sigma * kp.sigma;
+  const int W = L.w;
+  float x = minx, y = miny;
+  float2 npg = make_float2(0.0f, 0.0f);
+  if (active) npg = polar_px(pl, W, round_pos(x), round_pos(y));
+  while (__any(active)) {
+    if (active) {
+      const float2 pg = npg;
+      const float cxs = x, cys = y;
+      // advance the reference's two float loop counters (`y <= maxy`, `x <= maxx`, += 1.0f)
+      x += 1.0f;
+      if (!(x <= maxx)) {
+        x = minx;
+        y += 1.0f;
+        if (!(y <= maxy)) active = false;
       }
-      __builtin_amdgcn_wave_barrier();
-      float hb = 0.0f;
-      if (lane < 36) {
-        unsigned long long t = 0ull;
+      if (active) npg = polar_px(pl, W, round_pos(x), round_pos(y));
+      const float tx = cxs - kx, ty = cys - ky;
+      const float angle = fmod_2pi_above(pg.y + (2.0f * pi), 2.0f * pi);
+      const int bin = (int)floorf(angle / rad10);
+      const float wgt = sv_expf(-((tx * tx) + (ty * ty)) / weight);
+      if (bin >= 0 && bin < 36) s_hist[bin][t] = fmaf(pg.x, wgt, s_hist[bin][t]);
+    }
+  }
+  uint32_t cnt = 0;
+  float outTheta[MAXO];
 #pragma unroll
-        for (int cpy = 0; cpy < 16; ++cpy) t += hist[lane * 16 + cpy];
-        hb = from_fixed31(t);
-      }
-      const float hprev = __shfl(hb, (lane + 35) % 36, 64);
-      const float hnext = __shfl(hb, (lane + 1) % 36, 64);
-      float maxHist = hb;
+  for (int i = 0; i < MAXO; ++i) outTheta[i] = -FLT_MAX;
+  if (inside) {
+    float maxHist = 0.0f;
+    for (int i = 0; i < 36; ++i) {
+      const float h = s_hist[i][t];
+      if (h > maxHist) maxHist = h;
+    }
+    maxHist *= orientationThreshold;
+    float bestMag[MAXO], bestTh[MAXO];
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) maxHist = fmaxf(maxHist, __shfl_xor(maxHist, o, 64));
-      maxHist = fmaxf(maxHist, 0.0f) * orientationThreshold;
-      // tests 1-5 of :1064-1068 (circular neighbours); test 6 (weakest kept peak) is order dependent, done below
-      const bool peak = lane < 36 && !(hb < maxHist || hb < hprev || hb < hnext);
-      float tth = (hprev - hnext) / (hprev - (2.0f * hb) + hnext);
-      tth *= (pi / 36.0f);
-      tth += (lane * rad10);
-      tth = fmodf(tth + (2.0f * pi), 2.0f * pi);
-      unsigned long long mask = __ballot(peak);
-      float bestMag[MAXO], bestTh[MAXO];
-#pragma unroll
-      for (int i = 0; i < MAXO; ++i) { bestMag[i] = 0.0f; bestTh[i] = 0.0f; }
-      while (mask) {
-        const int b = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        float tmag = __shfl(hb, b, 64);
-        float tt = __shfl(tth, b, 64);
-        if (tmag < bestMag[MAXO - 1]) continue;
+    for (int i = 0; i < MAXO; ++i) { bestMag[i] = 0.0f; bestTh[i] = 0.0f; }
+    float hprev = s_hist[35][t], hb = s_hist[0][t];
+    for (int b = 0; b < 36; ++b) {
+      const float hnext = s_hist[b == 35 ? 0 : b + 1][t];
+      // tests of :1064-1068 (circular neighbours) and the weakest kept peak
+      if (!(hb < maxHist || hb < hprev || hb < hnext || hb < bestMag[MAXO - 1])) {
+        float tmag = hb;
+        float tt = (hprev - hnext) / (hprev - (2.0f * hb) + hnext);
+        tt *= (pi / 36.0f);
+        tt += (b * rad10);
+        tt = fmodf(tt + (2.0f * pi), 2.0f * pi);
 #pragma unroll
         for (int i = 0; i < MAXO; ++i) {
           if (tmag > bestMag[i]) {
@@ -510,44 +507,50 @@ __global__ __launch_bounds__(256) void k_thetas(const OctaveState* st, const ssr
           }
         }
       }
-#pragma unroll
-      for (int i = 0; i < MAXO; ++i) {
-        if (bestMag[i] != 0.0f) { outTheta[i] = bestTh[i]; cnt = i + 1; }
-      }
-      __builtin_amdgcn_wave_barrier();
+      hprev = hb;
+      hb = hnext;
     }
-    if (lane == 0) {
 #pragma unroll
-      for (int i = 0; i < MAXO; ++i) thetas[(size_t)gi * svp::kMaxOrient + i] = outTheta[i];
-      thetaCnt[gi] = cnt;
+    for (int i = 0; i < MAXO; ++i) {
+      if (bestMag[i] != 0.0f) { outTheta[i] = bestTh[i]; cnt = i + 1; }
     }
+  }
+  if (have) {
+#pragma unroll
+    for (int i = 0; i < MAXO; ++i) thetas[(size_t)gi * svp::kMaxOrient + i] = outTheta[i];
+    thetaCnt[gi] = cnt;
   }
 }
 
 // ---- S14: fillDescriptors(SSKeyPoint) (src/SIFT_FeatureFactory.cu:475-549) ------------------------------------------------
 // One WAVE per key point (the reference: a 4x4x8 block of which 16 threads sweep the window).  The samples of the
 // rotated (2w+1)^2 window vote into the wave's 4x4x8 LDS histogram (the reference also uses shared-memory atomics,
-// :521).  The kernel sits between VALU issue and the LDS atomic rate, so the loop is written for instruction count:
+// :521).  Every vote is the reference's expression, operand for operand and rounding for rounding:
+//     temp = (1 - hx/binWidth) * (1 - hy/binWidth) * (1 - angle/rad45) * (|grad| * expf(-(r^2) / (2 w^2)))
+// with IEEE divisions and the shared expf / atan2f / sincos of sv_math.h.  What the reference leaves undefined is the
+// ORDER of its float atomicAdds; here (and in the oracle's sum mode 0, oracle/oracle_sift.c) a vote enters its bin as
+// the integer nearest to temp * 2^k (k per key point, see kDescCopies) and the integer sum is exact, so the result does
+// not depend on the order -- descriptors are deterministic and bit-identical to the oracle's.
+// The kernel sits between VALU issue and the LDS atomic rate, so the loop is written for instruction count:
 //   - a lane carries the four-fold ORBIT of a window sample (see the loop): one coordinate set, one Gaussian and one
 //     pass over the 16 cells serve four samples;
 //   - everything that depends on the key point only comes from a lane-parallel pre-pass (k_desc_consts) or is
 //     wave-uniform in SGPRs (rotated cell centres), so a cell test is {2 v_sub, v_max, v_cmp} on SGPR operands;
 //   - the 16 cells are visited in a uniform, fully unrolled loop: a cell's vote code runs once under the lane mask of
 //     its passing orbits instead of a per-lane loop over set bits, the coordinate differences of the test are reused
-//     for the weights and the LDS address is lane base + immediate;
-//   - votes are fixed point in 32-bit bins with a per-key-point scale, 8 lane-private copies (see kDescCopies).
+//     for the weights and the LDS address is lane base + immediate.
 __device__ __forceinline__ float uniform_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
 // Per-key-point constants of k_descriptors, computed one key point per LANE by a pre-pass: in the wave-per-key-point
-// kernel the same arithmetic (sincosf alone is ~100 instructions) ran once per WAVE, 64 lanes wide on a single value,
-// and was 9 % of its instructions.  The descriptor kernel fetches the 32-byte record with one scalar load.
+// kernel the same arithmetic (sine and cosine alone are ~100 instructions) ran once per WAVE, 64 lanes wide on a single
+// value.  The descriptor kernel fetches the 32-byte record with one scalar load.
 struct DescConst {
   float c, s;           // cos / sin of -theta (:497-498)
   float windowWidth;    // ceil(sigma * lambda / pixelWidth) (:487)
-  float invBin;         // 1 / binWidth, binWidth = windowWidth / 2
-  float k2;             // -log2(e) / (2 windowWidth^2): exp(-(r^2) / (2 w^2)) == exp2(r^2 * k2) to <= 3 ulp
-  float voteExp;        // fixed-point exponent of the votes (see kDescCopies)
+  float expDen;         // 2 windowWidth^2: the Gaussian is expf(-(r^2) / expDen) (:508)
+  float voteScale;      // 2^k: fixed-point scale of the votes (see kDescCopies)
+  float pad;
   uint32_t magic;       // ceil(2^32 / windowWidth): orbit index -> quadrant row by a multiply-high
   int32_t segment;      // blur segment of the key point = DoG level its window is sampled from
 };
@@ -558,23 +561,31 @@ __global__ __launch_bounds__(256) void k_desc_consts(const OctaveState* st, cons
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     DescConst d;
     const float theta = kps[i].theta;
-    float sv, cv;
-    sincosf(-theta, &sv, &cv);
-    d.c = cv;
-    d.s = sv;
+    d.c = sv_cosf(-theta);
+    d.s = sv_sinf(-theta);
     d.windowWidth = ceilf(kps[i].sigma * lambda / pixelWidth);
-    const float binWidth = d.windowWidth / 2.0f;
-    d.invBin = 1.0f / binWidth;  // hx / binWidth is evaluated as hx * (1/binWidth): <= 1 ulp off
-    d.k2 = -1.4426950408889634f / (2.0f * d.windowWidth * d.windowWidth);
+    d.expDen = 2.0f * d.windowWidth * d.windowWidth;
     // sqrt(2) * (windowWidth + 2)^2 * 2^k < 2^31
     int boundExp;
     (void)frexpf(1.4143f * ((d.windowWidth + 2.0f) * (d.windowWidth + 2.0f)), &boundExp);
-    d.voteExp = (float)(31 - boundExp);
+    d.voteScale = ldexpf(1.0f, 31 - boundExp);
+    d.pad = 0.0f;
     const unsigned wi = (unsigned)(int)d.windowWidth;
     d.magic = wi > 1u ? 0xFFFFFFFFu / wi + 1u : 0u;  // ceil(2^32 / w) (2^32 / w when w is a power of two); w = 1 is special-cased
     d.segment = segment_of(st, i);
     out[i] = d;
   }
+}
+
+// A vote enters its bin as the integer nearest to temp * 2^k, halves up: v_cvt_rpi_i32_f32 is floor(x + 0.5) evaluated
+// exactly (checked against floorf(x) + (x - floorf(x) >= 0.5f) for every float in [0, 2^31): tools/f64_rate.hip); the
+// oracle spells that out.  Plain truncation, which the first version used, biases every bin low by half a unit per
+// vote -- hundreds of units on bins that hold 1e5..1e6 of them, enough to move descriptor bytes and to lose 2 of the
+// reference's 13 534 golden matches.
+__device__ __forceinline__ unsigned vote_u32(float v) {
+  int r;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+  return (unsigned)r;
 }
 
 // LDS atomics are processed one 16-lane row at a time and lanes of a row that hit the same address serialise
@@ -583,9 +594,8 @@ __global__ __launch_bounds__(256) void k_desc_consts(const OctaveState* st, cons
 // this kernel had first, 49-57).  So the bins are 32-bit, in 8 lane-private copies (copy = lane & 7: at most two lanes
 // of a row share a copy, they collide only when their orientation bins coincide): 4 KiB per wave and <= 64 VGPRs, 8
 // waves per SIMD.  32-bit sums need a per-key-point fixed-point scale 2^k: a bin receives at most (2 binWidth + 2)^2
-// votes (lattice points of a rotated square) of at most sqrt(2), k is the largest power with bound * 2^k < 2^31.  At the
-// pipeline's windows (w >= 14) k <= 23: the truncation of a vote is below 2^-23 of a histogram whose norm is O(1),
-// i.e. 1e-3 of a descriptor LSB.  The normalisation that follows is scale invariant, so the sums are used as they are.
+// votes (lattice points of a rotated square) of at most sqrt(2), k is the largest power with bound * 2^k < 2^31
+// (k = 22 at w = 12, 20 at w = 29).  The normalisation that follows is scale invariant, so the sums are used as they are.
 #ifndef SSRLCV_DESC_COPIES
 #define SSRLCV_DESC_COPIES 8
 #endif
@@ -615,7 +625,7 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
     const float windowWidth = dc.windowWidth;
     const float binWidth = windowWidth / 2.0f;
     const float c = dc.c, s = dc.s;
-    const float2* __restrict__ pl = polar + (size_t)(seg - 1) * L.h * L.w;
+    const float2* __restrict__ pl = polar + (size_t)(seg - 1) * svp::polar_level_stride(L.w, L.h) + 1;
 #pragma unroll
     for (int i = 0; i < 2 * kDescCopies; ++i) bins[i * 64 + lane] = 0u;
     // rotated cell centres (:511-512), identical expressions to the reference's per-sample recomputation: lane i
@@ -631,7 +641,7 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
         rc[cell].y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ry), cell));
       }
     }
-    const float invBin = dc.invBin, k2 = dc.k2, voteExp = dc.voteExp;
+    const float expDen = dc.expDen, voteScale = dc.voteScale;
     // Votes are exact integers, so the visiting order of the window samples does not matter.  The polar gathers of the
     // next batch are issued before the current one is used.
     //
@@ -640,11 +650,10 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
     // the 4 x 4 cell centres turn with it, rc[(3 - ny)*4 + nx] == (-rc[nx*4 + ny].y, rc[nx*4 + ny].x) bit for bit (hx, hy
     // run over -0.75, -0.25, 0.25, 0.75 times windowWidth).  So the cell test of the turned sample against the turned
     // cell is the test of p against the cell with |dx| and |dy| exchanged: the same pass / fail, the same product of the
-    // two 1 - t/binWidth factors, the same Gaussian of r^2.  A lane therefore carries the ORBIT {p, turned once, twice,
-    // three times}: one set of coordinates, one exponential, one pass over the 16 cells; only the gathers and the
-    // orientation split are per sample.  Orbits are numbered over the quadrant x = 1..w, y = 0..w (index = y*w + x - 1);
-    // one more index stands for the window centre, which is its own orbit.  764 -> ~390 VALU instructions per 256
-    // samples against one sample per lane.
+    // two 1 - t/binWidth factors (a float product commutes), the same Gaussian of r^2 (so does a sum).  A lane therefore
+    // carries the ORBIT {p, turned once, twice, three times}: one set of coordinates, one exponential, one pass over
+    // the 16 cells; only the gathers and the orientation weights are per sample.  Orbits are numbered over the quadrant
+    // x = 1..w, y = 0..w (index = y*w + x - 1); one more index stands for the window centre, which is its own orbit.
     const int Wi = (int)windowWidth;
     const unsigned centreIdx = (unsigned)(Wi * (Wi + 1));
     const unsigned magic = dc.magic;  // ceil(2^32 / w)
@@ -658,22 +667,29 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
       cy = (-x * s) + (y * c);
       ok = idx <= centreIdx && fmaxf(fabsf(cx), fabsf(cy)) <= windowWidth;  // :505, one compare for the whole orbit
     };
-    // llroundf of the reference; in-range by checkKeyPoints (window + 1 pixel inside the level).  A turned sample's
-    // coordinate is e.g. (-cy) + kx = kx - cy, the same rounded sum.
-    auto gather = [&](float px, float py) { return polar_px(pl, L.w, round_pos(px), round_pos(py)); };
+    // llroundf of the reference and its flat index into the gradient array (:507).  checkKeyPoints keeps the window
+    // sigma * lambda / pixelWidth inside the level, but the loop runs over its ceiling, so a coordinate may reach -1,
+    // W or H: the padded table returns what the reference's array returns (the neighbouring row) or zero (outside).
+    // A turned sample's coordinate is e.g. (-cy) + kx = kx - cy, the same rounded sum.
+    auto gather = [&](float px, float py) { return polar_px(pl, L.w, round_coord(px), round_coord(py)); };
     // orientation bins: every k in 0..7 with |ang - k*rad45| < rad45 votes 1 - |ang - k*rad45| / rad45 (:515-518);
-    // ang lies in (-pi, 2 pi) (fmodf keeps the sign) and there is no wrap-around.  With k0 = floor(ang / rad45) and
-    // u = fract(ang / rad45) these are bin k0 with 1 - u and bin k0 + 1 with u, each if it exists.  The reference's
-    // float tests can also admit a third bin, or reject one of the two, when a product rounds across an integer --
-    // with a weight within an ulp of 0 either way; those cases are not replayed.  A missing vote adds 0 to a valid word
-    // (a neighbouring cell's bin or the padding in front of / behind the histogram) instead of branching.
-    auto split = [&](float2 pg, float mag, float& m0, float& m1, unsigned*& pa) {
-      const float ang = fmod_2pi_above(pg.y - theta + (2.0f * pi), 2.0f * pi);
+    // ang lies in (-pi, 2 pi) (fmodf keeps the sign) and there is no wrap-around.  With k0 = floor(ang / rad45) these
+    // are bins k0 and k0 + 1, each if it exists -- unless ang lies within rounding of a multiple of rad45, where the
+    // reference's float tests can admit a third bin or reject one of the two.  `odd` marks those samples (the estimate
+    // t45 is within 1e-4 of an integer; its own error is below 1e-6): they take no part in the fast path and are
+    // replayed literally afterwards.  The two weights are the reference's expressions: |ang - (float)k * rad45|, an
+    // IEEE division by rad45, 1 - quotient.  A missing vote adds 0 to a valid word (a neighbouring cell's bin or the
+    // padding in front of / behind the histogram) instead of branching.
+    auto split = [&](float2 pg, bool live, float& w0, float& w1, unsigned*& pa, float& ang, bool& odd) {
+      ang = fmod_2pi_above(pg.y - theta + (2.0f * pi), 2.0f * pi);
       const float t45 = ang * inv45;
-      int k0 = (int)floorf(t45);
-      const float u = __builtin_amdgcn_fractf(t45);  // (ang - k0*rad45) / rad45 to within an ulp of t45
-      m0 = (unsigned)k0 < 8u ? (1.0f - u) * mag : 0.0f;
-      m1 = (unsigned)(k0 + 1) < 8u ? u * mag : 0.0f;
+      const float fk = floorf(t45);
+      const float u = t45 - fk;  // exact (Sterbenz-like: fk <= t45 < fk + 1)
+      odd = live && !(u > 1.0e-4f && u < 0.9999f);
+      int k0 = (int)fk;
+      const float a0 = fabsf(ang - (fk * rad45)), a1 = fabsf(ang - ((fk + 1.0f) * rad45));
+      w0 = (live && !odd && (unsigned)k0 < 8u) ? 1.0f - (a0 / rad45) : 0.0f;
+      w1 = (live && !odd && (unsigned)(k0 + 1) < 8u) ? 1.0f - (a1 / rad45) : 0.0f;
       k0 = k0 < -1 ? -1 : k0;  // k0 in -4..8 -> -1..8
       pa = bins + k0 * kDescCopies + copy;  // bin k0 of cell 0; bin k0 + 1 is kDescCopies words further
     };
@@ -692,25 +708,23 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
       const float cx = ncx, cy = ncy;
       const bool ok = nok;
       const float2 pg0 = npg[0], pg1 = npg[1], pg2 = npg[2], pg3 = npg[3];
-      const bool turned = base + (unsigned)lane < centreIdx;  // the centre sample is its own orbit
+      const bool turned = ok && base + (unsigned)lane < centreIdx;  // the centre sample is its own orbit
       sample(base + 64 + (unsigned)lane, ncx, ncy, nok);
       if (nok) gather4();
-      // gaussian weight (shared by the orbit) with the fixed-point scale folded into the exponent
-      const float g = __builtin_amdgcn_exp2f(fmaf((cx * cx) + (cy * cy), k2, voteExp));
-      const float gt = turned ? g : 0.0f;
-      float a0, a1, b0, b1, c0, c1, d0, d1;
+      // gaussian weight (shared by the orbit), the fixed-point scale folded in (a power of two: exact)
+      const float g = sv_expf(-((cx * cx) + (cy * cy)) / expDen) * voteScale;
+      float a0, a1, b0, b1, c0, c1, d0, d1, angA, angB, angC, angD;
+      bool oddA, oddB, oddC, oddD;
       unsigned *pa, *pb, *pc, *pd;
-      split(pg0, pg0.x * g, a0, a1, pa);
-      split(pg1, pg1.x * gt, b0, b1, pb);
-      split(pg2, pg2.x * gt, c0, c1, pc);
-      split(pg3, pg3.x * gt, d0, d1, pd);
+      split(pg0, ok, a0, a1, pa, angA, oddA);
+      split(pg1, turned, b0, b1, pb, angB, oddB);
+      split(pg2, turned, c0, c1, pc, angC, oddC);
+      split(pg3, turned, d0, d1, pd, angD, oddD);
+      const float magA = pg0.x * g, magB = pg1.x * g, magC = pg2.x * g, magD = pg3.x * g;  // :508, times 2^k
       // cells whose rotated centre lies within binWidth of the sample on both axes (:513-514).  `ok` is folded into
       // the lane's threshold and the two axis tests into one compare of max(|tx|, |ty|), so a cell costs {2 v_sub,
-      // v_max, v_cmp} + {s_and_saveexec, s_cbranch_execz, s_or}.  A passing cell costs two fused 1 - t/binWidth, their
-      // product and one multiply + conversion per vote: (wxy * wk) * mag of the reference becomes wxy * (wk * mag), and
-      // 1 - t * (1/binWidth) has one rounding instead of two -- a few ulp on a vote, against a quantisation step of
-      // 2^-8 of the normalised histogram.  p votes into cell (nx, ny), its quarter turns with the same wxy into
-      // (3 - ny, nx), (3 - nx, 3 - ny) and (ny, 3 - nx).
+      // v_max, v_cmp} + {s_and_saveexec, s_cbranch_execz, s_or}.  p votes into cell (nx, ny), its quarter turns with
+      // the same (1 - hx)(1 - hy) into (3 - ny, nx), (3 - nx, 3 - ny) and (ny, 3 - nx).
       const float bwl = ok ? binWidth : -1.0f;
 #pragma unroll
       for (int cell = 0; cell < 16; ++cell) {
@@ -723,20 +737,54 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
         const int cellB = (3 - ny) * 4 + nx, cellC = 15 - cell, cellD = ny * 4 + (3 - nx);
         const float tx = fabsf(rc[cell].x - cx), ty = fabsf(rc[cell].y - cy);
         if (fmaxf(tx, ty) <= bwl) {
-          const float wxy = fmaf(-tx, invBin, 1.0f) * fmaf(-ty, invBin, 1.0f);
-          atomicAdd(pa + cell * 8 * kDescCopies, (unsigned)(wxy * a0));
-          atomicAdd(pa + cell * 8 * kDescCopies + kDescCopies, (unsigned)(wxy * a1));
-          atomicAdd(pb + cellB * 8 * kDescCopies, (unsigned)(wxy * b0));
-          atomicAdd(pb + cellB * 8 * kDescCopies + kDescCopies, (unsigned)(wxy * b1));
-          atomicAdd(pc + cellC * 8 * kDescCopies, (unsigned)(wxy * c0));
-          atomicAdd(pc + cellC * 8 * kDescCopies + kDescCopies, (unsigned)(wxy * c1));
-          atomicAdd(pd + cellD * 8 * kDescCopies, (unsigned)(wxy * d0));
-          atomicAdd(pd + cellD * 8 * kDescCopies + kDescCopies, (unsigned)(wxy * d1));
+          const float wxy = (1.0f - (tx / binWidth)) * (1.0f - (ty / binWidth));
+          atomicAdd(pa + cell * 8 * kDescCopies, vote_u32((wxy * a0) * magA));
+          atomicAdd(pa + cell * 8 * kDescCopies + kDescCopies, vote_u32((wxy * a1) * magA));
+          atomicAdd(pb + cellB * 8 * kDescCopies, vote_u32((wxy * b0) * magB));
+          atomicAdd(pb + cellB * 8 * kDescCopies + kDescCopies, vote_u32((wxy * b1) * magB));
+          atomicAdd(pc + cellC * 8 * kDescCopies, vote_u32((wxy * c0) * magC));
+          atomicAdd(pc + cellC * 8 * kDescCopies + kDescCopies, vote_u32((wxy * c1) * magC));
+          atomicAdd(pd + cellD * 8 * kDescCopies, vote_u32((wxy * d0) * magD));
+          atomicAdd(pd + cellD * 8 * kDescCopies + kDescCopies, vote_u32((wxy * d1) * magD));
+        }
+      }
+      // the literal replay (:509-524) of the samples whose direction sits on a bin boundary: about one in 10^4
+      if (__ballot(oddA || oddB || oddC || oddD) != 0ull) {
+#pragma unroll 1
+        for (int m = 0; m < 4; ++m) {
+          const bool odd = m == 0 ? oddA : m == 1 ? oddB : m == 2 ? oddC : oddD;
+          if (!odd) continue;
+          const float mcx = m == 0 ? cx : m == 1 ? -cy : m == 2 ? -cx : cy;
+          const float mcy = m == 0 ? cy : m == 1 ? cx : m == 2 ? -cy : -cx;
+          const float mang = m == 0 ? angA : m == 1 ? angB : m == 2 ? angC : angD;
+          const float mmag = m == 0 ? magA : m == 1 ? magB : m == 2 ? magC : magD;
+#pragma unroll 1
+          for (int cell = 0; cell < 16; ++cell) {
+            const int ci = lane & 15;
+            (void)ci;
+            const float hx0 = ((float)(cell >> 2) * 0.5f - 0.75f) * windowWidth, hy0 = ((float)(cell & 3) * 0.5f - 0.75f) * windowWidth;
+            const float rx = (hx0 * c) + (hy0 * s), ry = (-hx0 * s) + (hy0 * c);
+            float hx = fabsf(rx - mcx), hy = fabsf(ry - mcy);
+            if (hx <= binWidth && hy <= binWidth) {
+              hx = hx / binWidth;
+              hy = hy / binWidth;
+              for (int k = 0; k < 8; ++k) {
+                float angle = fabsf(mang - ((float)k * rad45));
+                if (angle < rad45) {
+                  angle /= rad45;
+                  const float temp = (1.0f - hx) * (1.0f - hy) * (1.0f - angle) * mmag;
+                  atomicAdd(bins + (cell * 8 + k) * kDescCopies + copy, vote_u32(temp));
+                }
+              }
+            }
+          }
         }
       }
     }
     __builtin_amdgcn_wave_barrier();
-    // normalise, clamp at 0.2, renormalise, quantise (:529-542); each lane owns bins lane and lane + 64
+    // normalise, clamp at 0.2, renormalise, quantise (:529-542); each lane owns bins lane and lane + 64.  The two norms
+    // are balanced-tree sums (the reference's are float atomicAdds in no defined order): pairs 64 apart, then the
+    // xor butterfly 32, 16, .. 1 -- the tree the oracle's sum mode 0 spells out.
     unsigned t0 = 0u, t1 = 0u;
 #pragma unroll
     for (int cpy = 0; cpy < kDescCopies; ++cpy) {
@@ -956,12 +1004,12 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
       else hipLaunchKernelGGL(k_polar, dim3((oc.w + 255) / 256, (oc.h + kPolRows - 1) / kPolRows, 3), dim3(256), 0, s, L, (float2*)(ws + oc.off_polar));
       float* thetas = (float*)(ws + oc.off_theta);
       uint32_t* thetaCnt = (uint32_t*)(ws + oc.off_thetaCnt);
-      dim3 g(list_blocks(cap) * kWaveKernelOversubscription);
+      dim3 g((cap + 63) / 64);  // one lane per key point, one-wave blocks; blocks past the list's end return at once
       switch (maxO) {
-        case 1: hipLaunchKernelGGL(k_thetas<1>, g, dim3(256), 0, s, st, cur, L, oc.pixelWidth, plan->params.orientationContribWidth, plan->params.orientationThreshold, thetas, thetaCnt); break;
-        case 2: hipLaunchKernelGGL(k_thetas<2>, g, dim3(256), 0, s, st, cur, L, oc.pixelWidth, plan->params.orientationContribWidth, plan->params.orientationThreshold, thetas, thetaCnt); break;
-        case 3: hipLaunchKernelGGL(k_thetas<3>, g, dim3(256), 0, s, st, cur, L, oc.pixelWidth, plan->params.orientationContribWidth, plan->params.orientationThreshold, thetas, thetaCnt); break;
-        default: hipLaunchKernelGGL(k_thetas<4>, g, dim3(256), 0, s, st, cur, L, oc.pixelWidth, plan->params.orientationContribWidth, plan->params.orientationThreshold, thetas, thetaCnt); break;
+        case 1: hipLaunchKernelGGL(k_thetas<1>, g, dim3(64), 0, s, st, cur, L, oc.pixelWidth, plan->params.orientationContribWidth, plan->params.orientationThreshold, thetas, thetaCnt); break;
+        case 2: hipLaunchKernelGGL(k_thetas<2>, g, dim3(64), 0, s, st, cur, L, oc.pixelWidth, plan->params.orientationContribWidth, plan->params.orientationThreshold, thetas, thetaCnt); break;
+        case 3: hipLaunchKernelGGL(k_thetas<3>, g, dim3(64), 0, s, st, cur, L, oc.pixelWidth, plan->params.orientationContribWidth, plan->params.orientationThreshold, thetas, thetaCnt); break;
+        default: hipLaunchKernelGGL(k_thetas<4>, g, dim3(64), 0, s, st, cur, L, oc.pixelWidth, plan->params.orientationContribWidth, plan->params.orientationThreshold, thetas, thetaCnt); break;
       }
       // thrust::remove of the -FLT_MAX / -1 slots + expandKeyPoints (:594-611): element space n x maxOrientations
       const OctaveState* cst = st;

@@ -16,7 +16,7 @@ constexpr int kBlock = 256;
 
 __device__ __forceinline__ ssrlcv_line make_line(const ssrlcv_camera& cam, ssrlcv_keypoint kp) {
   // src/PointCloudFactory.cu:4179-4195
-  float dpix_x = (cam.foc * tanf(cam.fov.x / 2.0f)) / (cam.size.x / 2.0f);
+  float dpix_x = (cam.foc * sv_tanf(cam.fov.x / 2.0f)) / (cam.size.x / 2.0f);
   float dpix_y = dpix_x;
   f3 v = mk3(dpix_x * ((kp.loc.x) - (cam.size.x / 2.0f)), dpix_y * ((kp.loc.y) - (cam.size.y / 2.0f)), cam.foc);
   v = rotate_point(v, cam.cam_rot);
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kBlock) void k_generate_pushbroom_bundles(const ssr
     float roll = (float)(pb.roll * (SSRLCV_PI_D / 180.0f));  // PI is a double macro upstream
     float radius = pb.axis_radius;
     float altitude = pb.altitude;
-    float t = tanf((float)(roll - (SSRLCV_PI_D / 2.0f)));
+    float t = sv_tanf((float)(roll - (SSRLCV_PI_D / 2.0f)));
     float a = 1.0f + (t * t);
     float bq = -2.0f * radius * t;
     float c = radius * radius - ((altitude + radius) * (altitude + radius));

@@ -1085,7 +1085,7 @@ int ssrlcv_sift_plan_create(uint32_t w, uint32_t h, const ssrlcv_sift_params* pa
     size_t P = (size_t)ow * oh;
     for (int b = 0; b < svp::kDog; ++b) oc.off_dog[b] = take(P * 4);
     oc.off_flags = take(P);
-    oc.off_polar = take(P * 3 * 8);
+    oc.off_polar = take(svp::polar_level_stride(oc.w, oc.h) * 3 * 8);
     uint32_t cap = params->maxKeyPointsPerOctave ? params->maxKeyPointsPerOctave : (uint32_t)(P / 16);
     if (cap < 4096) cap = 4096;
     oc.cap = cap;

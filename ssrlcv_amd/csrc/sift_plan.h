@@ -36,6 +36,14 @@ struct OctaveState {
   int pad[3];
 };
 
+// Polar tables (float2 {|grad|, atan2} per pixel of DoG levels 1..3): the descriptor kernel indexes them the way the
+// reference indexes its W*H gradient array, with the FLAT index round(y) * W + round(x) (src/SIFT_FeatureFactory.cu:507),
+// and a rotated window may reach one column left / right of the level (the flat index then lands in the neighbouring
+// row, as upstream) or one row below it and column -1 of row 0 (upstream: a read outside the array, undefined).  Each
+// level's table therefore carries one zero entry in front and W + 1 behind: an outside read returns a zero gradient,
+// which votes nothing -- the definition the oracle uses too.  Entry of flat index i of level l: l * stride + 1 + i.
+__host__ __device__ inline size_t polar_level_stride(uint32_t w, uint32_t h) { return (size_t)w * h + w + 2; }
+
 struct OctavePlan {
   uint32_t w, h;
   float pixelWidth;
@@ -45,7 +53,7 @@ struct OctavePlan {
   uint32_t cap;            // key-point list capacity
   size_t off_dog[kDog];
   size_t off_flags;
-  size_t off_polar;        // float2 {|grad|, atan2} of the twice-normalised DoG levels 1..3 (3 * P * 8 bytes)
+  size_t off_polar;        // float2 {|grad|, atan2} of the twice-normalised DoG levels 1..3 (3 * polar_level_stride * 8 bytes)
   size_t off_kpA, off_kpB; // SSKeyPoint ping-pong lists
   size_t off_theta;        // cap * kMaxOrient floats
   size_t off_thetaCnt;     // cap uint32 (number of orientations per key point)

@@ -22,3 +22,10 @@ def everest_oracle_features(oracle_lib):
     """Oracle SIFT features of the three 1024x1024 everest fixture images (computed once per session)."""
     import helpers
     return [helpers.oracle_sift(oracle_lib, p) for p in helpers.load_everest_pixels()]
+
+
+@pytest.fixture(scope="session")
+def capi():
+    """The ctypes plumbing over the C ABI; importing it loads libssrlcv_hip.so (no CPU fallback)."""
+    from ssrlcv_amd import capi
+    return capi

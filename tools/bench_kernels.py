@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+
 """Developer micro-benchmarks of individual C-ABI kernels (not part of the driver contract).
 usage: python tools/bench_kernels.py [--size 4096]"""
 import argparse

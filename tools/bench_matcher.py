@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+
 """Developer tool: stand-alone matcher timing (used under rocprofv3 for PMC passes)."""
 import os
 import sys

@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+
 """Developer tool: double-constrained (epipolar band) matching vs brute force on the same synthetic sets.
 usage: python tools/bench_matcher_band.py [N] [size]  -- N features per image, image edge `size` (fixture cameras are
 for 1024 px; locations are drawn uniformly in the image)"""

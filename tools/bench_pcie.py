@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+
 """Developer tool: the host <-> device transfers a Unity<T>-style caller pays around one image (pinned host memory):
 u8 pixels in, Feature<SIFT_Descriptor>[F] out.  usage: python tools/bench_pcie.py [size] [features]"""
 import sys

@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+
 """Developer timing of the SIFT stages on one synthetic image (not part of the driver contract).
 usage: [SSRLCV_HIP_LIB=variant.so] python tools/bench_sift_stages.py [--size 4096]
 Prints ms of ssrlcv_hip_sift_build_dog and of ssrlcv_hip_sift_describe stopped after each stage (differences = stage

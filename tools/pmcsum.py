@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+
 """Sum rocprofv3 --pmc counters of the longest dispatch of a kernel.  usage: pmcsum.py <kernel substring> <dir>..."""
 import csv, collections, sys, glob
 pat = sys.argv[1]

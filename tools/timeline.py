@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+
 """Kernel timeline of the last image of a `rocprofv3 --kernel-trace` run of bench.py (rocpd .db output): start, end,
 duration (us), stream and kernel name, so that overlaps and waits between streams can be read off.
 usage: timeline.py <results.db> [max_rows]"""
