@@ -198,4 +198,7 @@ int oracle_sift_keypoints(oracle_sift* s, int stage, o_sskeypoint** out, int blu
 /* element-wise evaluation of oracle_libm.h (fn: 0 expf(a), 1 atan2f(a,b), 2 sinf, 3 cosf, 4 tanf, 5 powf(a,b)) */
 void oracle_math_eval(int fn, const float* a, const float* b, float* out, size_t n);
 
+/* exhaustive check of the 3-operation exact division used by the HIP kernels (see oracle_pointcloud.c) */
+long oracle_check_exact_div3(float d);
+
 #endif

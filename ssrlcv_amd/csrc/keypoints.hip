@@ -409,64 +409,137 @@ __device__ __forceinline__ int round_coord(float v) {
 // The reference runs ONE THREAD per key point and accumulates its 36-bin histogram with a sequential float
 // multiply-add chain in raster order of the window (:1031-1047): that order is part of the result (float addition does
 // not associate), and the peak tests and the parabolic interpolation read the histogram's last bits.  So this kernel
-// keeps the reference's shape -- one lane per key point, the literal double loop with its float loop counters, one
-// fmaf per sample -- and spends its effort around it instead:
+// keeps the reference's shape -- one lane per key point, its two float loop counters, one fmaf per sample in raster
+// order -- and spends its effort around that chain:
 //   - the histogram lives in LDS, one conflict-free column per lane (bin-major), not in scratch;
 //   - gradient magnitude / direction come from the per-pixel polar tables (k_polar) instead of 4 gathers + sqrtf +
 //     atan2f per sample;
+//   - a lane fetches its window row in chunks of 8 consecutive table entries (four 16-byte buffer loads, the next chunk
+//     requested before the current one is processed): with one 8-byte gather per sample every lane pulled a whole
+//     128-byte line per sample through L2 (1024 lane streams per CU against 256 lines of L1: 82 GB per 4096^2 image);
+//   - the divisions are the IEEE quotients by way of sv::exact_div3 / exact_div5 (reciprocals hoisted), the Gaussian is
+//     the shared expf;
 //   - one-wave blocks (9 KiB of LDS each): the windows of the key points of a wave differ in size and the wave runs as
-//     long as its largest, many small blocks let the dispatcher even that out;
-//   - the next sample's table entry is requested before the current one is processed.
+//     long as its largest; many small blocks let the dispatcher even that out.
 // The first version of this file ran one WAVE per key point with exact 64-bit fixed-point LDS atomics -- order
 // independent, but not the reference's sum: thetas agreed to ~1e-6 and a handful of peak decisions per million key
 // points flipped.
+constexpr int kThetaChunk = 8;
 template <int MAXO>
 __global__ __launch_bounds__(64) void k_thetas(const OctaveState* st, const ssrlcv_sskeypoint* kps, LevelSet L,
                                                float pixelWidth, float lambda, float orientationThreshold,
                                                float* __restrict__ thetas, uint32_t* __restrict__ thetaCnt) {
   __shared__ float s_hist[36][64];
   const int n = st->hasExtrema ? st->n : 0;
-  const int gi = blockIdx.x * 64 + threadIdx.x;
-  if (blockIdx.x * 64 >= n) return;  // block-uniform
+  if ((int)(blockIdx.x * 64) >= n) return;  // block-uniform
   const int t = threadIdx.x;
+  const int gi = blockIdx.x * 64 + t;
   const bool have = gi < n;
   const float pi = SSRLCV_PI_F;
   const float rad10 = pi / 18.0f;
+  const float inv10 = 1.0f / rad10;
   ssrlcv_sskeypoint kp;
   kp.loc.x = kp.loc.y = 0.0f;
-  kp.sigma = 0.0f;
+  kp.sigma = 1.0f;
   if (have) kp = kps[gi];
-  const int seg = have ? segment_of(st, gi) : 1;
+  const int seg = have ? segment_of(st, gi) : -1;
   const float kx = kp.loc.x, ky = kp.loc.y;
   const float windowWidth = ceilf(kp.sigma * 3.0f * lambda / pixelWidth);
   const float minx = kx - windowWidth, miny = ky - windowWidth, maxx = kx + windowWidth, maxy = ky + windowWidth;
-  bool active = have && !(minx < 0.0f || miny < 0.0f || maxx >= (unsigned)(L.w - 1) || maxy >= (unsigned)(L.h - 1));
-  const bool inside = active;
+  const bool inside = have && !(minx < 0.0f || miny < 0.0f || maxx >= (unsigned)(L.w - 1) || maxy >= (unsigned)(L.h - 1));
 #pragma unroll
   for (int i = 0; i < 36; ++i) s_hist[i][t] = 0.0f;
-  const float2* __restrict__ pl = L.polar + (size_t)(seg - 1) * svp::polar_level_stride(L.w, L.h) + 1;
   const float weight = 2.0f * lambda * lambda * kp.sigma * kp.sigma;
+  const float rweight = 1.0f / weight;
   const int W = L.w;
-  float x = minx, y = miny;
-  float2 npg = make_float2(0.0f, 0.0f);
-  if (active) npg = polar_px(pl, W, round_pos(x), round_pos(y));
-  while (__any(active)) {
-    if (active) {
-      const float2 pg = npg;
-      const float cxs = x, cys = y;
-      // advance the reference's two float loop counters (`y <= maxy`, `x <= maxx`, += 1.0f)
-      x += 1.0f;
-      if (!(x <= maxx)) {
-        x = minx;
-        y += 1.0f;
-        if (!(y <= maxy)) active = false;
+  const size_t levelStride = svp::polar_level_stride(L.w, L.h);
+  // A wave's key points nearly always share a blur segment (the list is segment-ordered), i.e. a polar table; the few
+  // waves that straddle a boundary take one pass per segment so that the buffer descriptor stays wave-uniform.
+  unsigned long long todo = __ballot(inside);
+  while (todo) {
+    const int lead = __ffsll((long long)todo) - 1;
+    const int useg = __builtin_amdgcn_readlane(seg, lead);
+    bool active = inside && seg == useg;
+    todo &= ~__ballot(active);
+    // entry e of the table (flat index e - 1) is at byte 8 e; reads past the end return 0 (and belong to lanes whose
+    // samples are not used: a window row stays inside the level)
+    const float2* base = L.polar + (size_t)(useg - 1) * levelStride;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(uint32_t)(levelStride * 8), 0x00020000);  // < 4 GiB: checked by plan_create
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    float x = minx, y = miny;
+    // row state
+    float ty = y - ky;
+    float ty2 = ty * ty;
+    unsigned rowoff = (unsigned)round_pos(y) * (unsigned)W + 1u;
+    u32x4 nxt[kThetaChunk / 2];
+    auto fetch = [&](float fx, unsigned roff) {
+      const unsigned off = (roff + (unsigned)round_pos(fx)) * 8u;  // byte offset, below 2^32
+#pragma unroll
+      for (int j = 0; j < kThetaChunk / 2; ++j) nxt[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off + 16u * j), 0, 0);
+    };
+    if (active) fetch(x, rowoff);
+    while (__any(active)) {
+      u32x4 cur[kThetaChunk / 2];
+#pragma unroll
+      for (int j = 0; j < kThetaChunk / 2; ++j) cur[j] = nxt[j];
+      // the chunk's coordinates: the reference's `x += 1.0f`, kThetaChunk + 1 times
+      float xs[kThetaChunk + 1];
+      xs[0] = x;
+#pragma unroll
+      for (int i = 1; i <= kThetaChunk; ++i) xs[i] = xs[i - 1] + 1.0f;
+      const float cty2 = ty2;
+      const unsigned crow = rowoff;
+      const bool cact = active;
+      // Entry i of the chunk is the sample's pixel iff llroundf(xs[i]) == llroundf(xs[0]) + i.  In exact arithmetic it
+      // is; `+= 1.0f` rounds only when it crosses a binade, the perturbation then stays for the rest of the row, and
+      // from x >= 4 a chunk crosses at most one: checking the last entry covers them all.
+      const bool aligned = xs[0] >= 4.0f && round_pos(xs[kThetaChunk - 1]) == round_pos(xs[0]) + (kThetaChunk - 1);
+      // next chunk: same row while the reference's loop condition holds, else the next row
+      if (active) {
+        if (xs[kThetaChunk] <= maxx) {
+          x = xs[kThetaChunk];
+        } else {
+          x = minx;
+          y += 1.0f;
+          if (!(y <= maxy)) active = false;
+          ty = y - ky;
+          ty2 = ty * ty;
+          rowoff = (unsigned)round_pos(y) * (unsigned)W + 1u;
+        }
       }
-      if (active) npg = polar_px(pl, W, round_pos(x), round_pos(y));
-      const float tx = cxs - kx, ty = cys - ky;
-      const float angle = fmod_2pi_above(pg.y + (2.0f * pi), 2.0f * pi);
-      const int bin = (int)floorf(angle / rad10);
-      const float wgt = sv_expf(-((tx * tx) + (ty * ty)) / weight);
-      if (bin >= 0 && bin < 36) s_hist[bin][t] = fmaf(pg.x, wgt, s_hist[bin][t]);
+      if (active) fetch(x, rowoff);
+      auto vote = [&](float mag, float ang, float xi, bool valid) {
+        const float tx = xi - kx;
+        const float wgt = sv::expf_nonpos(sv::exact_div5(-((tx * tx) + cty2), weight, rweight));
+        const float angle = fmod_2pi_above(ang + (2.0f * pi), 2.0f * pi);
+        const int bin = (int)floorf(sv::exact_div3(angle, rad10, inv10));
+        if (valid && bin >= 0 && bin < 36) s_hist[bin][t] = fmaf(mag, wgt, s_hist[bin][t]);
+      };
+      const bool fast = cact && aligned;
+#pragma unroll
+      for (int i = 0; i < kThetaChunk; ++i)
+      {
+        // (element first, cast second: __builtin_bit_cast applied directly to a vector-element lvalue reads element 0)
+        const unsigned um = cur[i >> 1][(i & 1) * 2], ua = cur[i >> 1][(i & 1) * 2 + 1];
+        vote(__builtin_bit_cast(float, um), __builtin_bit_cast(float, ua), xs[i], fast && xs[i] <= maxx);
+      }
+      // rare (a chunk that crosses a binade with an unlucky fraction, or starts below x = 4): the lane's samples are
+      // gathered one by one.  After the fast path in program order, so that its loads do not sit between the prefetch
+      // and the fast path's wait; a lane takes exactly one of the two paths per chunk, so its raster order is kept.
+      if (__any(cact && !aligned)) {
+        if (cact && !aligned) {
+          const float2* lvl = L.polar + (size_t)(useg - 1) * levelStride;
+          float xi = xs[0];  // re-walked with += 1.0f: the same values as xs[]
+#pragma unroll 1
+          for (int i = 0; i < kThetaChunk; ++i) {
+            if (xi <= maxx) {
+              const float2 e = lvl[crow + (unsigned)round_pos(xi)];
+              vote(e.x, e.y, xi, true);
+            }
+            xi += 1.0f;
+          }
+        }
+      }
     }
   }
   uint32_t cnt = 0;
@@ -548,9 +621,9 @@ __device__ __forceinline__ float uniform_f(float v) {
 struct DescConst {
   float c, s;           // cos / sin of -theta (:497-498)
   float windowWidth;    // ceil(sigma * lambda / pixelWidth) (:487)
-  float expDen;         // 2 windowWidth^2: the Gaussian is expf(-(r^2) / expDen) (:508)
+  float invExpDen;      // 1 / (2 windowWidth^2), correctly rounded: the Gaussian is expf(-(r^2) / (2 w^2)) (:508)
   float voteScale;      // 2^k: fixed-point scale of the votes (see kDescCopies)
-  float pad;
+  float invBin;         // 1 / binWidth, correctly rounded (binWidth = windowWidth / 2)
   uint32_t magic;       // ceil(2^32 / windowWidth): orbit index -> quadrant row by a multiply-high
   int32_t segment;      // blur segment of the key point = DoG level its window is sampled from
 };
@@ -564,12 +637,12 @@ __global__ __launch_bounds__(256) void k_desc_consts(const OctaveState* st, cons
     d.c = sv_cosf(-theta);
     d.s = sv_sinf(-theta);
     d.windowWidth = ceilf(kps[i].sigma * lambda / pixelWidth);
-    d.expDen = 2.0f * d.windowWidth * d.windowWidth;
+    d.invExpDen = 1.0f / (2.0f * d.windowWidth * d.windowWidth);
     // sqrt(2) * (windowWidth + 2)^2 * 2^k < 2^31
     int boundExp;
     (void)frexpf(1.4143f * ((d.windowWidth + 2.0f) * (d.windowWidth + 2.0f)), &boundExp);
     d.voteScale = ldexpf(1.0f, 31 - boundExp);
-    d.pad = 0.0f;
+    d.invBin = 1.0f / (d.windowWidth / 2.0f);
     const unsigned wi = (unsigned)(int)d.windowWidth;
     d.magic = wi > 1u ? 0xFFFFFFFFu / wi + 1u : 0u;  // ceil(2^32 / w) (2^32 / w when w is a power of two); w = 1 is special-cased
     d.segment = segment_of(st, i);
@@ -641,7 +714,11 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
         rc[cell].y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ry), cell));
       }
     }
-    const float expDen = dc.expDen, voteScale = dc.voteScale;
+    // the reference's divisions by binWidth, 2 w^2 and rad45 as IEEE quotients from hoisted reciprocals (sv::exact_div3;
+    // windows wider than the 255 its exhaustive check covers take the plain division)
+    const float expDen = 2.0f * windowWidth * windowWidth, invExpDen = dc.invExpDen, invBin = dc.invBin;
+    const float voteScale = dc.voteScale;
+    const bool wideWindow = windowWidth > 255.0f;
     // Votes are exact integers, so the visiting order of the window samples does not matter.  The polar gathers of the
     // next batch are issued before the current one is used.
     //
@@ -688,8 +765,8 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
       odd = live && !(u > 1.0e-4f && u < 0.9999f);
       int k0 = (int)fk;
       const float a0 = fabsf(ang - (fk * rad45)), a1 = fabsf(ang - ((fk + 1.0f) * rad45));
-      w0 = (live && !odd && (unsigned)k0 < 8u) ? 1.0f - (a0 / rad45) : 0.0f;
-      w1 = (live && !odd && (unsigned)(k0 + 1) < 8u) ? 1.0f - (a1 / rad45) : 0.0f;
+      w0 = (live && !odd && (unsigned)k0 < 8u) ? 1.0f - sv::exact_div3(a0, rad45, inv45) : 0.0f;
+      w1 = (live && !odd && (unsigned)(k0 + 1) < 8u) ? 1.0f - sv::exact_div3(a1, rad45, inv45) : 0.0f;
       k0 = k0 < -1 ? -1 : k0;  // k0 in -4..8 -> -1..8
       pa = bins + k0 * kDescCopies + copy;  // bin k0 of cell 0; bin k0 + 1 is kDescCopies words further
     };
@@ -712,7 +789,8 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
       sample(base + 64 + (unsigned)lane, ncx, ncy, nok);
       if (nok) gather4();
       // gaussian weight (shared by the orbit), the fixed-point scale folded in (a power of two: exact)
-      const float g = sv_expf(-((cx * cx) + (cy * cy)) / expDen) * voteScale;
+      const float r2n = -((cx * cx) + (cy * cy));
+      const float g = sv::expf_nonpos(wideWindow ? r2n / expDen : sv::exact_div3(r2n, expDen, invExpDen)) * voteScale;
       float a0, a1, b0, b1, c0, c1, d0, d1, angA, angB, angC, angD;
       bool oddA, oddB, oddC, oddD;
       unsigned *pa, *pb, *pc, *pd;
@@ -737,7 +815,8 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
         const int cellB = (3 - ny) * 4 + nx, cellC = 15 - cell, cellD = ny * 4 + (3 - nx);
         const float tx = fabsf(rc[cell].x - cx), ty = fabsf(rc[cell].y - cy);
         if (fmaxf(tx, ty) <= bwl) {
-          const float wxy = (1.0f - (tx / binWidth)) * (1.0f - (ty / binWidth));
+          const float wxy = wideWindow ? (1.0f - (tx / binWidth)) * (1.0f - (ty / binWidth))
+                                       : (1.0f - sv::exact_div3(tx, binWidth, invBin)) * (1.0f - sv::exact_div3(ty, binWidth, invBin));
           atomicAdd(pa + cell * 8 * kDescCopies, vote_u32((wxy * a0) * magA));
           atomicAdd(pa + cell * 8 * kDescCopies + kDescCopies, vote_u32((wxy * a1) * magA));
           atomicAdd(pb + cellB * 8 * kDescCopies, vote_u32((wxy * b0) * magB));

@@ -1041,6 +1041,8 @@ int ssrlcv_sift_plan_create(uint32_t w, uint32_t h, const ssrlcv_sift_params* pa
   }
   // the fused Gaussian kernels need every octave >= 64 pixels on each side (the smallest octave is an eighth of octave 0)
   if (ow < 512 || oh < 512) return SSRLCV_ERR_UNSUPPORTED;
+  // one polar table (8 bytes per pixel of octave 0) is addressed with 32-bit byte offsets by the orientation kernel
+  if (svp::polar_level_stride(ow, oh) * 8 >= ((size_t)1 << 32)) return SSRLCV_ERR_UNSUPPORTED;
   ssrlcv_sift_plan* p = new (std::nothrow) ssrlcv_sift_plan;
   if (!p) return SSRLCV_ERR_INVALID_ARG;
   memset(p, 0, sizeof *p);

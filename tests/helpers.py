@@ -341,3 +341,19 @@ def synthetic_image(w, h, seed=0, blobs=None):
         sub = np.exp(-(((xx[ya:yb, xa:xb] - bx[i]) ** 2 + (yy[ya:yb, xa:xb] - by[i]) ** 2) / (2 * bs[i] ** 2)))
         img[ya:yb, xa:xb] += ba[i] * sub
     return np.clip(np.rint(img + 128.0), 0, 255).astype(np.uint8)
+
+
+def bits(a):
+    """float32 array -> its bit patterns (so that -0.0 / NaN payloads count, and == means bit-equal)."""
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def assert_features_equal(gf, of):
+    """Every field the reference writes is bit-equal (the 4 pad bytes after `parent` are never written upstream)."""
+    assert len(gf) == len(of), (len(gf), len(of))
+    assert np.array_equal(gf["parent"], of["parent"])
+    for name in ("loc", "sigma", "theta"):
+        ne = bits(gf[name]) != bits(of[name])
+        assert not ne.any(), (name, int(ne.sum()), len(gf))
+    nd = (gf["values"] != of["values"]).any(1)
+    assert not nd.any(), ("descriptor bytes", int(nd.sum()), len(gf))

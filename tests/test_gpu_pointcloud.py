@@ -33,8 +33,11 @@ def test_bundles_and_triangulation_match_oracle_and_fixture(capi, oracle_lib, vi
     assert np.array_equal(gb["numLines"], ob["numLines"]) and np.array_equal(gb["index"], ob["index"])
     assert (gb["invalid"] == 0).all()
     assert np.array_equal(gl["pnt"], ol["pnt"])
-    # direction vectors: device sinf/cosf/tanf (ocml) vs glibc differ by <= 2 ulp
-    assert np.abs(gl["vec"] - ol["vec"]).max() <= 3e-7
+    # direction vectors: tanf / sinf / cosf are the shared sv_math.h functions on both sides -> bit-equal
+    assert np.array_equal(H.bits(gl["vec"]), H.bits(ol["vec"]))
+    # ... and so the clouds are too (pure +-*/ and sqrt after that)
+    pts0_d, _, _ = capi.triangulate(l_d, b_d, n, nview=nview)
+    assert np.array_equal(pts0_d.cpu().numpy().reshape(-1, 3), H.oracle_triangulate(oracle_lib, nview, ob, ol)[0])
     pts_d, err_d, sum_d = capi.triangulate(l_d, b_d, n, nview=nview, want_errors=True)
     pts = pts_d.cpu().numpy().reshape(-1, 3)
     opts, oerr, osum = H.oracle_triangulate(oracle_lib, nview, ob, ol, want_errors=True)
@@ -126,6 +129,7 @@ def test_pushbroom_bundles_match_oracle(capi, oracle_lib):
     ol = np.zeros(nk, H.LINE)
     oracle_lib.oracle_generate_pushbroom_bundles(ctypes.c_uint32(nb), H.P(mm), H.P(kp), H.P(pb), H.P(ob), H.P(ol))
     gl = capi.to_host(l_d, H.LINE, nk)
-    assert np.abs(gl["vec"] - ol["vec"]).max() <= 1e-5
-    assert np.abs(gl["pnt"] - ol["pnt"]).max() <= 2e-2 * 1e-2 + 1e-3  # |pnt| ~ 6771 km: 1 ulp = 5e-4
+    # shared tanf / sinf / cosf: bit-equal (round 1: two libms, 1e-5 / 1e-3)
+    assert np.array_equal(H.bits(gl["vec"]), H.bits(ol["vec"]))
+    assert np.array_equal(H.bits(gl["pnt"]), H.bits(ol["pnt"]))
     assert np.array_equal(capi.to_host(b_d, H.BUNDLE, nb)["index"], mm["index"])
