@@ -508,12 +508,19 @@ __global__ __launch_bounds__(64) void k_thetas(const OctaveState* st, const ssrl
         }
       }
       if (active) fetch(x, rowoff);
+      // Branch-free: a sample that does not count (past the row's end, or bin 36 from an angle one ulp below 2 pi, which
+      // the reference's `bin < 36` guard drops... upstream it is an out-of-bounds write, see the oracle) adds
+      // fmaf(0, 0, h) = h to bin 0.  The bin's old value is requested before the Gaussian is evaluated, so the LDS
+      // round trip hides behind it.
       auto vote = [&](float mag, float ang, float xi, bool valid) {
-        const float tx = xi - kx;
-        const float wgt = sv::expf_nonpos(sv::exact_div5(-((tx * tx) + cty2), weight, rweight));
         const float angle = fmod_2pi_above(ang + (2.0f * pi), 2.0f * pi);
         const int bin = (int)floorf(sv::exact_div3(angle, rad10, inv10));
-        if (valid && bin >= 0 && bin < 36) s_hist[bin][t] = fmaf(mag, wgt, s_hist[bin][t]);
+        const bool counts = valid && (unsigned)bin < 36u;
+        float* slot = &s_hist[counts ? bin : 0][t];
+        const float h = *slot;
+        const float tx = xi - kx;
+        const float wgt = sv::expf_nonpos(sv::exact_div5(-((tx * tx) + cty2), weight, rweight));
+        *slot = fmaf(counts ? mag : 0.0f, counts ? wgt : 0.0f, h);
       };
       const bool fast = cact && aligned;
 #pragma unroll
@@ -673,7 +680,12 @@ __device__ __forceinline__ unsigned vote_u32(float v) {
 #define SSRLCV_DESC_COPIES 8
 #endif
 constexpr int kDescCopies = SSRLCV_DESC_COPIES;
-__global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, const ssrlcv_sskeypoint* kps, LevelSet L,
+#ifndef SSRLCV_DESC_VGPRS
+#define SSRLCV_DESC_VGPRS 64
+#endif
+// waves_per_eu(4, 8) + an explicit VGPR cap instead of __launch_bounds__(256, 8): the latter also caps the SGPRs at 80
+// (the budget of a 10-wave gfx9 part), and this kernel keeps the rotated cell centres and per-key-point constants there
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8), amdgpu_num_vgpr(SSRLCV_DESC_VGPRS), amdgpu_num_sgpr(102))) void k_descriptors(const OctaveState* st, const ssrlcv_sskeypoint* kps, LevelSet L,
                                                      float pixelWidth, const DescConst* __restrict__ consts,
                                                      const uint32_t* featBase, int octave,
                                                      ssrlcv_sift_feature* __restrict__ features, uint32_t maxFeatures) {
@@ -703,22 +715,23 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
     for (int i = 0; i < 2 * kDescCopies; ++i) bins[i * 64 + lane] = 0u;
     // rotated cell centres (:511-512), identical expressions to the reference's per-sample recomputation: lane i
     // evaluates cell i & 15, the 16 {x, y} pairs are then broadcast into SGPR pairs
-    f32x2 rc[16];
+    f32x2 rc[16];  // only the nine cells with nx, ny >= 1 are read (see the cell loop): 18 SGPRs
     {
       const int ci = lane & 15;
       const float hx = ((float)(ci >> 2) * 0.5f - 0.75f) * windowWidth, hy = ((float)(ci & 3) * 0.5f - 0.75f) * windowWidth;
       const float rx = (hx * c) + (hy * s), ry = (-hx * s) + (hy * c);
 #pragma unroll
       for (int cell = 0; cell < 16; ++cell) {
+        if ((cell >> 2) == 0 || (cell & 3) == 0) continue;
         rc[cell].x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rx), cell));
         rc[cell].y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ry), cell));
       }
     }
-    // the reference's divisions by binWidth, 2 w^2 and rad45 as IEEE quotients from hoisted reciprocals (sv::exact_div3;
-    // windows wider than the 255 its exhaustive check covers take the plain division)
+    // the reference's divisions by binWidth, 2 w^2 and rad45 as IEEE quotients from hoisted reciprocals (sv::exact_div3,
+    // checked exhaustively for every window width up to 255; the plan refuses wider windows: their orbit indices would
+    // not fit the 16-bit multiply-high below either)
     const float expDen = 2.0f * windowWidth * windowWidth, invExpDen = dc.invExpDen, invBin = dc.invBin;
     const float voteScale = dc.voteScale;
-    const bool wideWindow = windowWidth > 255.0f;
     // Votes are exact integers, so the visiting order of the window samples does not matter.  The polar gathers of the
     // next batch are issued before the current one is used.
     //
@@ -790,7 +803,7 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
       if (nok) gather4();
       // gaussian weight (shared by the orbit), the fixed-point scale folded in (a power of two: exact)
       const float r2n = -((cx * cx) + (cy * cy));
-      const float g = sv::expf_nonpos(wideWindow ? r2n / expDen : sv::exact_div3(r2n, expDen, invExpDen)) * voteScale;
+      const float g = sv::expf_nonpos(sv::exact_div3(r2n, expDen, invExpDen)) * voteScale;
       float a0, a1, b0, b1, c0, c1, d0, d1, angA, angB, angC, angD;
       bool oddA, oddB, oddC, oddD;
       unsigned *pa, *pb, *pc, *pd;
@@ -815,8 +828,7 @@ __global__ __launch_bounds__(256, 8) void k_descriptors(const OctaveState* st, c
         const int cellB = (3 - ny) * 4 + nx, cellC = 15 - cell, cellD = ny * 4 + (3 - nx);
         const float tx = fabsf(rc[cell].x - cx), ty = fabsf(rc[cell].y - cy);
         if (fmaxf(tx, ty) <= bwl) {
-          const float wxy = wideWindow ? (1.0f - (tx / binWidth)) * (1.0f - (ty / binWidth))
-                                       : (1.0f - sv::exact_div3(tx, binWidth, invBin)) * (1.0f - sv::exact_div3(ty, binWidth, invBin));
+          const float wxy = (1.0f - sv::exact_div3(tx, binWidth, invBin)) * (1.0f - sv::exact_div3(ty, binWidth, invBin));
           atomicAdd(pa + cell * 8 * kDescCopies, vote_u32((wxy * a0) * magA));
           atomicAdd(pa + cell * 8 * kDescCopies + kDescCopies, vote_u32((wxy * a1) * magA));
           atomicAdd(pb + cellB * 8 * kDescCopies, vote_u32((wxy * b0) * magB));
