@@ -1,23 +1,31 @@
-#!/usr/bin/env python3
 """bench.py -- SIFT extract (Mpix/s) + 128-D brute-force match (Mmatches/s) on MI355X.
 
 Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it
 under torch.distributed.run, one rank per GPU.  One STEP = one pass of the SIFT hot path
 (ssrlcv_hip_sift_extract: pyramid -> DoG -> extrema -> refinement -> orientation -> descriptors) over this rank's
-batch of synthetic u8 images already resident in HBM.  Ranks own different image pairs (weak scaling, no data-path
-collective inside the SIFT stage).  value = total input pixels of all ranks / max-over-ranks time.
+pair of synthetic u8 images already resident in HBM (BASELINE.json config[2]: 2-view 4096 x 4096).  Ranks own different
+image pairs (weak scaling, no data-path collective inside the SIFT stage).  value = total input pixels of all ranks /
+max-over-ranks time.  Inputs come from tools/scene.py (PCG32 terrain + texture rendered through
+Image::Camera, ~0.03 features per pixel like the reference's everest imagery).
 
 Besides the contract keys the JSON line carries
-  roofline      : the DoG-pyramid stage (ssrlcv_hip_sift_build_dog: 35 launches per image) against HBM, algorithmic
-                  bytes 362.25*W*H per image, duration from HIP events inside the timed steps;
-  matcher       : Mmatches/s of ssrlcv_hip_match_u8x128 (pairs compared / time) on Nq = Nt synthetic descriptors,
-                  with its own fp16-MFMA roofline (2*128*Nq*Nt flop);
-  cpu_baseline  : the CPU oracle (oracle/, a port restating the reference's kernels) timed on a bounded sample on
-                  rank 0's host cores.
+  roofline      : the DoG-pyramid stage (ssrlcv_hip_sift_build_dog) against HBM, algorithmic bytes 362.25*W*H per image
+                  (SURVEY.md section 8d), duration from HIP events around the stage inside the timed steps;
+  describe      : the key-point stage (ssrlcv_hip_sift_describe: extrema .. orientation .. descriptors), the larger
+                  share of a step: ms per image and ns per feature from events in the same steps, and its VALU-issue
+                  roofline from the committed PMC reduction (profiles/);
+  matcher       : Mmatches/s of ssrlcv_hip_match_u8x128 (pairs compared / time) on Nq = Nt synthetic descriptors, with
+                  its int8-MFMA roofline (2*128*Nq*Nt op), and the band-culled orbit mode;
+  nview         : BASELINE config[3] as one more measured step: V views sharded over the ranks, RCCL all-gather of the
+                  feature arrays and of the uint2_pair arrays, replicated merge, bundle-range N-view triangulation,
+                  all-gather of the cloud, BA error sweep with its all-reduce -- with the wall share of every stage;
+  cpu_baseline  : the CPU oracle (oracle/, a port restating the reference's kernels) on a bounded sample of the same
+                  generator's imagery, median of 3 runs after a warm-up, on rank 0's host cores.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,14 +34,17 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (~2.5 PF)
 MFMA_I8_PEAK_TOPS = 5000.0     # dense int8 MFMA peak: twice the bf16 rate per clock (MI355X_MICROARCH.md)
+VALU_PEAK_GINST = 1024 * 2.4 / 4.0  # wave-instructions per ns: 256 CUs x 4 SIMDs, one VALU issue per 4 clocks at 2.4 GHz
 
 
 def synth_images(n, w, h, seed, device):
-    """Multi-scale smooth noise quantised to u8 (mean 128) -- generated on the GPU with torch (plumbing only)."""
+    """Round-1 input (multi-scale noise, ~0.1 features per pixel: 3x denser than real imagery).  Kept for the dense
+    full-size parity tests; the benchmark itself renders tools/scene.py scenes."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(0x53524C43 + seed)
@@ -52,7 +63,7 @@ def synth_images(n, w, h, seed, device):
 
 
 def synth_descriptors(n, seed):
-    """uniform u8 vectors L2-normalised to ~255 like real SIFT descriptors, 25 % planted near-duplicates (+-3)."""
+    """uniform u8 vectors L2-normalised to ~255 like real SIFT descriptors."""
     import helpers as H
     rng = np.random.default_rng(seed)
     v = rng.integers(0, 256, (n, 128)).astype(np.float32)
@@ -64,11 +75,18 @@ def synth_descriptors(n, seed):
     return f
 
 
+def git_head():
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return None
+
+
 def bench_matcher(capi, torch, nq, nt, iters):
     q = synth_descriptors(nq, 1)
     t = synth_descriptors(nt, 2)
     rng = np.random.default_rng(3)
-    dup = rng.choice(nq, nq // 4, replace=False)
+    dup = rng.choice(nq, nq // 4, replace=False)   # 25 % planted near-duplicates (+-3)
     tgt = rng.choice(nt, nq // 4, replace=False)
     t["values"][tgt] = np.clip(q["values"][dup].astype(np.int32) + rng.integers(-3, 4, (len(dup), 128)), 0, 255)
     q_d, t_d = capi.to_dev(q), capi.to_dev(t)
@@ -85,28 +103,21 @@ def bench_matcher(capi, torch, nq, nt, iters):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     pairs = float(nq) * float(nt)
-    flops = 2.0 * 128.0 * pairs
-    tf = flops / (ms * 1e-3) / 1e12
+    tops = 2.0 * 128.0 * pairs / (ms * 1e-3) / 1e12
     return {"value": pairs / (ms * 1e-3) / 1e6, "unit": "Mmatches/s", "nq": nq, "nt": nt, "ms": ms,
-            "output_matches_per_s": nq / (ms * 1e-3),
-            "dtype": "f16" if os.environ.get("SSRLCV_MATCH_F16") else "int8",
-            "roofline": ({"bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                          "frac": tf / MFMA_F16_PEAK_TFLOPS, "traffic": None,
-                          "kernel": "k_match (v_mfma_f32_32x32x16_f16), whole ssrlcv_hip_match_u8x128 call"}
-                         if os.environ.get("SSRLCV_MATCH_F16") else
-                         {"bound": "mfma", "achieved": tf, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
-                          "frac": tf / MFMA_I8_PEAK_TOPS, "traffic": None,
-                          "frac_of_fp16_peak": tf / MFMA_F16_PEAK_TFLOPS,
-                          "kernel": "k_match_i8 (v_mfma_i32_32x32x32_i8, exact), whole ssrlcv_hip_match_u8x128 call; "
-                                    "ops = 2*128*Nq*Nt, priced against the int8 dense peak (2x the fp16 peak the "
-                                    "north star names: frac_of_fp16_peak is the same rate against that)"})}
+            "output_matches_per_s": nq / (ms * 1e-3), "dtype": "int8",
+            "roofline": {"bound": "mfma", "achieved": tops, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
+                         "frac": tops / MFMA_I8_PEAK_TOPS, "traffic": None,
+                         "frac_of_fp16_peak": tops / MFMA_F16_PEAK_TFLOPS,
+                         "kernel": "k_match_i8 (v_mfma_i32_32x32x32_i8, exact), whole ssrlcv_hip_match_u8x128 call; "
+                                   "ops = 2*128*Nq*Nt, priced against the int8 dense peak (2x the fp16 peak the "
+                                   "north star names: frac_of_fp16_peak is the same rate against that)"}}
 
 
 def bench_matcher_epipolar(capi, torch, n, size, iters):
-    """The orbit mode of doFeatureMatching (matchFeaturesDoubleConstrained, epsilon 25 px, delta 5 km) on the same kind
-    of synthetic sets, features spread uniformly over a size x size image seen by the fixture's camera pair rescaled
-    to that size.  Reported as effective pair comparisons per second (Nq*Nt / time): the band-culled path skips most
-    of them without computing a distance."""
+    """The orbit mode of doFeatureMatching (matchFeaturesDoubleConstrained, epsilon 25 px, delta 5 km), features spread
+    uniformly over a size x size image seen by the fixture's camera pair rescaled to that size.  Reported as effective
+    pair comparisons per second (Nq*Nt / time): the band-culled path skips most of them without computing a distance."""
     import helpers as H
     q, t = synth_descriptors(n, 1), synth_descriptors(n, 2)
     rng = np.random.default_rng(5)
@@ -133,48 +144,71 @@ def bench_matcher_epipolar(capi, torch, n, size, iters):
             "mode": "double-constrained, epsilon 25 px, delta 5 km, %dx%d images" % (size, size)}
 
 
-def cpu_baseline(size):
-    """Oracle (CPU port of the reference kernels) SIFT on ONE size x size image: bounded sample of the workload."""
+def cpu_baseline(size, runs=3):
+    """Oracle (CPU port of the reference kernels) SIFT on ONE size x size view of the benchmark's own generator: a bounded
+    sample of the workload.  One warm-up run, then the median of `runs`."""
+    import torch
     import helpers as H
+    import scene
     lib = H.oracle()
-    img = H.synthetic_image(size, size, seed=21)
-    t0 = time.time()
+    imgs, _, _, _ = scene.pinhole_views(1, size, device=torch.device("cuda"))
+    img = imgs[0].cpu().numpy()
     f = H.oracle_sift(lib, img)
-    dt = time.time() - t0
+    times = []
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        f = H.oracle_sift(lib, img)
+        times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
     return {"value": size * size / dt / 1e6, "unit": "Mpix/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "oracle_sift_generate on one %dx%d synthetic image (%d features, %.1f s, OpenMP on all host "
-                      "cores); the reference itself has no CPU compute path" % (size, size, len(f), dt)}
+            "sample": "oracle_sift_generate on one %dx%d view of the benchmark's scene generator (%d features; median of %d "
+                      "runs after a warm-up: %s s; OpenMP on all host cores); the reference itself has no CPU compute path"
+                      % (size, size, len(f), runs, ", ".join("%.2f" % t for t in times))}
 
 
-def bench_nview(args, torch, dist, capi, world, rank, dev):
-    """config[3]: V views, image/pair sharding over the ranks with the two RCCL exchanges (ssrlcv_amd/pipeline.py)."""
+def describe_roofline(ms_per_image, features, size):
+    """VALU-issue roofline of the key-point stage from the committed PMC reduction of its kernels (instruction counts per
+    feature do not depend on the run; the time does)."""
+    path = os.path.join(ROOT, "profiles", "r02_describe_pmc.json")
+    out = {"ms_per_image": ms_per_image, "features_per_image": features,
+           "ns_per_feature": ms_per_image * 1e6 / max(features, 1),
+           "kernels": "k_extrema_flags, partitions, k_refine, k_flag_*, k_polar, k_thetas, k_desc_consts, k_descriptors "
+                      "(ssrlcv_hip_sift_describe); events bracket the call on the launching stream"}
+    if os.path.exists(path):
+        pmc = json.load(open(path))
+        per_feature = pmc.get("valu_wave_instructions_per_feature")
+        if per_feature:
+            ginst = per_feature * features / (ms_per_image * 1e6)  # wave-instructions per ns
+            out.update({"bound": "valu", "achieved": ginst, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+                        "frac": ginst / VALU_PEAK_GINST, "traffic": pmc.get("hbm_bytes_per_image"),
+                        "algorithmic_bytes_per_image": pmc.get("algorithmic_bytes_per_image"),
+                        "pmc_source": "profiles/r02_describe_pmc.json @ %s" % pmc.get("commit")})
+    return out
+
+
+def run_nview(args, torch, dist, capi, world, rank, dev, views, size, steps, warmup):
+    """config[3]: V views, image/pair sharding over the ranks with the RCCL exchanges (ssrlcv_amd/pipeline.py)."""
     import helpers as H
-    from ssrlcv_amd import pipeline, dist as sd
-    V, S = args.views, args.size
-    base = synth_images(1, S + 64, S + 64, seed=99, device=dev)[0]
-    # every view sees the same scene shifted by a few pixels, so descriptors do match across views
-    imgs = [base[8 * v: 8 * v + S, 5 * v: 5 * v + S].contiguous() for v in range(V)]
-    cams = np.zeros(V, H.CAMERA)
-    cams["foc"], cams["fov"], cams["size"] = 0.859311, 0.0418879, S
-    cams["dpix"] = 0.859311 * np.tan(0.0418879 / 2) / (S / 2)
-    cams["cam_rot"] = [2.0567966, 0.02217786, -0.04195467]
-    for v in range(V):
-        cams["cam_pos"][v] = [-35.0 * v, 1.3 * v, 0.7 * v]
-    plans = {v: capi.SiftPlan(S, S) for v in range(V) if sd.image_owner(v, world) == rank}
+    import scene
+    from ssrlcv_amd import pipeline
+    imgs, cams, _, _ = scene.pinhole_views(views, size, device=dev)
+    seed, _ = H.load_seed_features()
+    ws = pipeline.Workspace()
 
     def step():
-        return pipeline.reconstruct(imgs, cams, mode=0, plans=plans)
+        return pipeline.reconstruct(imgs, cams, seed_features=seed, mode=1, ws=ws, ba=True)
 
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
+    ws.times.clear()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         res = step()
     barrier()
     dt = time.perf_counter() - t0
@@ -182,19 +216,16 @@ def bench_nview(args, torch, dist, capi, world, rank, dev):
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    if rank == 0:
-        print(json.dumps({
-            "metric": "Mpix/s N-view reconstruction (SIFT + exhaustive match + merge + N-view triangulate)",
-            "value": V * S * S * args.steps / dt / 1e6, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%d-view %dx%d, image/pair shard over %d GPU(s), all-gather of features and "
-                                   "uint2_pair arrays, replicated merge" % (V, S, S, world),
-                       "multi_matches": int(len(res["matches"])), "points": int(res["points"].shape[0]),
-                       "features_per_image": [int(f.numel() // 152) for f in res["features"]]}}))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    return {"metric": "Mpix/s N-view reconstruction (SIFT + exhaustive orbit match + merge + N-view triangulate + BA sweep)",
+            "value": views * size * size * steps / dt / 1e6, "unit": "Mpix/s", "n_gpus": world, "steps": steps,
+            "ms_per_step": dt / steps * 1e3, "scaling": "strong",
+            "workload": "%d-view %dx%d scene, image/pair shard over %d GPU(s): all-gather of features, all-gather of "
+                        "uint2_pair arrays, replicated host merge, bundle-range triangulation + all-gather of the cloud, "
+                        "612-point BA error sweep + all-reduce" % (views, size, size, world),
+            "stage_ms_per_step_rank0": {k: v / steps * 1e3 for k, v in ws.times.items()},
+            "multi_matches": int(len(res["matches"])), "points": int(res["points"].shape[0]),
+            "ba_bundles": int(res.get("ba_bundles", 0)),
+            "features_per_image": [int(f.numel() // 152) for f in res["features"]]}
 
 
 def main():
@@ -209,11 +240,12 @@ def main():
     ap.add_argument("--cpu-size", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matcher", action="store_true")
-    ap.add_argument("--workload", choices=["pair", "nview"], default="pair",
-                    help="pair: SIFT on this rank's image pair (default, weak scaling).  nview: BASELINE config[3] -- "
-                         "--views images sharded over the ranks, RCCL all-gather of features and of the per-pair "
-                         "uint2_pair arrays, replicated merge, bundle-range N-view triangulation (strong scaling)")
-    ap.add_argument("--views", type=int, default=4)
+    ap.add_argument("--no-nview", action="store_true")
+    ap.add_argument("--nview-views", type=int, default=4)
+    ap.add_argument("--nview-size", type=int, default=2048,
+                    help="edge of the N-view leg's images (config[3] is 4096; the default keeps the whole run within minutes)")
+    ap.add_argument("--nview-steps", type=int, default=2)
+    ap.add_argument("--noise-input", action="store_true", help="round-1 input: multi-scale noise instead of the scene generator")
     args = ap.parse_args()
 
     import torch
@@ -229,12 +261,16 @@ def main():
         dist = None
         torch.cuda.set_device(0)
     from ssrlcv_amd import capi  # raises if the HIP library is missing: no CPU fallback
+    import scene
 
     W = H_ = args.size
     dev = torch.device("cuda", torch.cuda.current_device())
-    if args.workload == "nview":
-        return bench_nview(args, torch, dist, capi, world, rank, dev)
-    imgs = synth_images(args.images, W, H_, seed=rank, device=dev)
+    if args.noise_input:
+        imgs = synth_images(args.images, W, H_, seed=rank, device=dev)
+        workload = "multi-scale noise"
+    else:
+        imgs, _, _, _ = scene.pinhole_views(args.images, W, device=dev, seed=scene.SEED + 7919 * rank)
+        workload = "tools/scene.py pinhole views (PCG32 terrain + texture through Image::Camera)"
     plans = [capi.SiftPlan(W, H_) for _ in range(args.images)]
 
     def barrier():
@@ -251,12 +287,13 @@ def main():
             if ev is not None:
                 ev[i][1].record()
             p.describe()
+            if ev is not None:
+                ev[i][2].record()
 
     for _ in range(args.warmup):
         step()
     barrier()
-    events = [[[torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)] for _ in plans]
-              for _ in range(args.steps)]
+    events = [[[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in plans] for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(events[k])
@@ -266,17 +303,20 @@ def main():
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    nfeat = [p.count() for p in plans]
-    overflow = 0
+    nfeat = [p.count() for p in plans]  # raises if a key-point list overflowed its capacity (truncated result)
     pyr_ms = float(np.mean([e[0].elapsed_time(e[1]) for st in events for e in st]))
+    desc_ms = float(np.mean([e[1].elapsed_time(e[2]) for st in events for e in st]))
+    del plans
 
+    line = None
     if rank == 0:
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pyramid_traffic.json")
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r02_pyramid_traffic.json")
         if W == 4096 and H_ == 4096 and os.path.exists(tpath):
-            # HBM bytes of the pyramid stage per image from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
-            # same command (collected off-line: counters cannot be read from inside the timed run)
-            traffic = json.load(open(tpath))["pyramid_stage_bytes_per_image"]
+            # HBM bytes of the pyramid stage per image from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the stage
+            # benchmark (collected off-line: counters cannot be read from inside the timed run)
+            tj = json.load(open(tpath))
+            traffic, traffic_src = tj["pyramid_stage_bytes_per_image"], "profiles/r02_pyramid_traffic.json @ %s" % tj.get("commit")
         pixels_per_step = world * args.images * W * H_
         value = pixels_per_step * args.steps / dt / 1e6
         b_pyr = 362.25 * W * H_  # bytes per image
@@ -285,21 +325,28 @@ def main():
             "metric": "Mpix/s SIFT extract (+ Mmatches/s 128-D brute-force, see `matcher`)",
             "value": value, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "2-view %dx%d synthetic pair per GPU: SIFT_FeatureFactory::generateFeatures "
-                                   "(sparse DoG path) on each image, pixels resident in HBM" % (W, H_),
+            "dtype": "f32", "data": "synthetic", "commit": git_head(),
+            "config": {"workload": "2-view %dx%d pair per GPU (%s): SIFT_FeatureFactory::generateFeatures (sparse DoG "
+                                   "path) on each image, pixels resident in HBM" % (W, H_, workload),
                        "images_per_gpu": args.images, "features_per_image": nfeat, "parallelism": "image-pair shard"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "DoG pyramid stage = ssrlcv_hip_sift_build_dog (upsample, 24 gaussian levels: "
-                                   "k_gauss_fused up to 17 taps / k_gauss_mfma from 23 taps, 3 bin, 4 k_dog launches per "
-                                   "image; DoG(o) overlaps conv(o+1) on a side stream); algorithmic bytes 362.25*W*H "
-                                   "per image; events bracket the stage on the launching stream",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "DoG pyramid stage = ssrlcv_hip_sift_build_dog (u8 upsample, 24 gaussian levels, 3 bin, "
+                                   "4 DoG launches per image); algorithmic bytes 362.25*W*H per image; events bracket the "
+                                   "stage on the launching stream",
                          "ms_per_image": pyr_ms},
+            "describe": describe_roofline(desc_ms, int(np.mean(nfeat)), W),
         }
         if not args.no_matcher:
             line["matcher"] = bench_matcher(capi, torch, args.match_n, args.match_n, args.match_iters)
             line["matcher_epipolar"] = bench_matcher_epipolar(capi, torch, args.match_n, W, args.match_iters)
+    del imgs
+    torch.cuda.empty_cache()
+    if not args.no_nview:
+        nv = run_nview(args, torch, dist, capi, world, rank, dev, args.nview_views, args.nview_size, args.nview_steps, 1)
+        if rank == 0:
+            line["nview"] = nv
+    if rank == 0:
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_size)
         print(json.dumps(line))

@@ -839,3 +839,21 @@ void oracle_conv_separable(const float* in, uint32_t w, uint32_t h, int taps, co
   memcpy(out, r, sizeof(float) * (size_t)w * h);
   free(r);
 }
+
+/* generateBW (src/Image.cu:1277-1296) with bwaToBW / rgbToBW / rgbaToBW / rgbaToRGB (:1253-1275): the operands are
+ * unsigned chars promoted to int, the result is narrowed to unsigned char */
+void oracle_convert_to_bw(const uint8_t* color, uint32_t colorDepth, uint8_t* bw, size_t numPixels) {
+  for (size_t i = 0; i < numPixels; ++i) {
+    const uint8_t* p = color + i * colorDepth;
+    if (colorDepth == 2) {
+      bw[i] = (uint8_t)((1 - p[1]) * p[0] + p[1] * p[0]);
+    } else if (colorDepth == 3) {
+      bw[i] = (uint8_t)((p[0] / 4) + (p[1] / 2) + (p[2] / 4));
+    } else {
+      uint8_t r = (uint8_t)((1 - p[3]) * p[0] + p[3] * p[0]);
+      uint8_t g = (uint8_t)((1 - p[3]) * p[1] + p[3] * p[1]);
+      uint8_t b = (uint8_t)((1 - p[3]) * p[2] + p[3] * p[2]);
+      bw[i] = (uint8_t)((r / 4) + (g / 2) + (b / 4));
+    }
+  }
+}

@@ -39,11 +39,11 @@ EXPORTED = [
     "ssrlcv_hip_pose_lm_terms", "ssrlcv_hip_pose_cost",
     "ssrlcv_projection_matrix_host", "ssrlcv_hip_match_workspace_bytes", "ssrlcv_hip_seed_distances_u8x128",
     "ssrlcv_hip_match_u8x128", "ssrlcv_hip_compact_matches", "ssrlcv_merge_matches_host", "ssrlcv_host_free",
-    "ssrlcv_hip_u8_to_f32", "ssrlcv_hip_upsample2x", "ssrlcv_hip_upsample2x_u8", "ssrlcv_hip_bin2x",
+    "ssrlcv_hip_convert_to_bw", "ssrlcv_hip_u8_to_f32", "ssrlcv_hip_upsample2x", "ssrlcv_hip_upsample2x_u8", "ssrlcv_hip_bin2x",
     "ssrlcv_gauss_kernel_host", "ssrlcv_hip_gauss_sep_conv", "ssrlcv_hip_minmax", "ssrlcv_hip_normalize",
     "ssrlcv_hip_dog_normalised_sub",
     "ssrlcv_sift_plan_create", "ssrlcv_sift_plan_destroy", "ssrlcv_sift_plan_workspace_bytes",
     "ssrlcv_sift_plan_max_features", "ssrlcv_hip_sift_build_dog", "ssrlcv_hip_sift_describe",
     "ssrlcv_hip_sift_extract", "ssrlcv_sift_plan_level", "ssrlcv_sift_plan_keypoints",
-    "ssrlcv_sift_plan_set_stop_stage", "ssrlcv_hip_math_eval",
+    "ssrlcv_sift_plan_set_stop_stage", "ssrlcv_hip_math_eval", "ssrlcv_sift_plan_overflow",
 ]

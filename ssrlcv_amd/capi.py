@@ -204,6 +204,12 @@ def gauss_kernel(sigma, pixel_width):
     return taps, w[:max(taps, 0)].copy()
 
 
+def convert_to_bw(color_d, depth, n):
+    out = torch.empty(n, dtype=torch.uint8, device="cuda")
+    check(LIB.ssrlcv_hip_convert_to_bw(ptr(color_d), c_u32(depth), ptr(out), c_sz(n), stream_ptr()))
+    return out
+
+
 def upsample2x_u8(img_d, w, h):
     out = torch.empty(4 * w * h, dtype=torch.float32, device="cuda")
     check(LIB.ssrlcv_hip_upsample2x_u8(ptr(img_d), c_u32(w), c_u32(h), ptr(out), stream_ptr()))
@@ -294,8 +300,19 @@ class SiftPlan:
                                           ptr(self.num_features), stream_ptr()))
 
     def count(self):
-        torch.cuda.current_stream().synchronize()
+        """Feature count of the last extract; raises when a key-point list outgrew its capacity (the list was truncated:
+        not the reference's result -- re-run with a larger max_keypoints_per_octave)."""
+        mask = c_u32(0)
+        rc = LIB.ssrlcv_sift_plan_overflow(self.handle, ptr(self.workspace), ctypes.byref(mask), stream_ptr())
+        if mask.value:
+            raise SsrlcvError("key-point capacity exceeded in octaves %s" % [o for o in range(4) if mask.value >> o & 1])
+        check(rc)
         return int(self.num_features.item())
+
+    def overflow_mask(self):
+        mask = c_u32(0)
+        LIB.ssrlcv_sift_plan_overflow(self.handle, ptr(self.workspace), ctypes.byref(mask), stream_ptr())
+        return mask.value
 
     def level(self, kind, octave, blur):
         """-> (numpy level copy, (min, max)); kind 0 = raw DoG, 1 = gaussian (last octave built)."""

@@ -42,7 +42,11 @@ int ssrlcv_merge_matches_host(uint32_t numImages, const uint32_t* numFeatures, u
     const ssrlcv_uint2_pair* p = pairs;
     for (uint32_t k = 0; k < numPairs; ++k)
       for (uint32_t m = 0; m < pairCounts[k]; ++m, ++p) {
-        if (p->a.x >= V - 1 || p->a.y >= numFeatures[p->a.x]) return SSRLCV_ERR_INVALID_ARG;
+        // a names a list owner (images 0..V-2), b a feature of a later image: anything else (an un-compacted
+        // "invalid" a == b entry of the matcher, an index past a feature array) would index the lists out of bounds
+        if (p->a.x >= V - 1 || p->a.y >= numFeatures[p->a.x] || p->b.x >= V || p->b.y >= numFeatures[p->b.x] ||
+            p->b.x <= p->a.x)
+          return SSRLCV_ERR_INVALID_ARG;
         ++start[base[p->a.x] + p->a.y + 1];
         ++total;
       }

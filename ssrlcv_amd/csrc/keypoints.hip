@@ -101,7 +101,14 @@ __global__ void k_state_reset(OctaveState* st) {
 // after searchForExtrema (src/FeatureFactory.cu:98-151): totals = counts for b = 1,2,3
 __global__ void k_book_extrema(OctaveState* st, const uint32_t* totals, uint32_t cap) {
   uint32_t c1 = totals[0], c2 = totals[1], total = totals[3];
-  if (total > cap) { st->overflow = 1; total = 0; c1 = c2 = 0; }
+  // the list is grouped by blur (1, 2, 3) and the scatter drops everything past `cap`: on overflow the list is
+  // truncated there (the flag is reported by ssrlcv_sift_plan_overflow; the reference's lists are unbounded)
+  if (total > cap) {
+    st->overflow = 1;
+    total = cap;
+    c1 = c1 < cap ? c1 : cap;
+    c2 = c2 < cap - c1 ? c2 : cap - c1;
+  }
   st->idx[0] = 0;
   st->idx[1] = 0;
   st->idx[2] = (int)c1;
@@ -143,10 +150,10 @@ __global__ void k_book_orient(OctaveState* st, const uint32_t* totals, uint32_t 
   if (!st->hasExtrema) return;
   int total = 0;
   for (int b = 0; b < svp::kDog; ++b) {
-    st->idx[b] = total;
+    st->idx[b] = total < (int)cap ? total : (int)cap;
     total += (int)totals[b];
   }
-  if ((uint32_t)total > cap) { st->overflow = 1; total = 0; }
+  if ((uint32_t)total > cap) { st->overflow = 1; total = (int)cap; }  // truncated: the scatter drops what lies past cap
   st->n = total;
   if (total == 0) st->hasExtrema = 0;
 }
@@ -967,6 +974,20 @@ int ssrlcv_sift_plan_keypoints(const ssrlcv_sift_plan* plan, void* workspace, in
   if (list) *list = (ssrlcv_sskeypoint*)(ws + plan->oct[octave].off_kpA);
   if (blurIndices_dev) *blurIndices_dev = (int*)(ws + plan->off_state + sizeof(OctaveState) * octave);
   return SSRLCV_OK;
+}
+
+int ssrlcv_sift_plan_overflow(const ssrlcv_sift_plan* plan, const void* workspace, uint32_t* octaveMask,
+                              ssrlcv_stream_t stream) {
+  if (!plan || !workspace || !octaveMask) return SSRLCV_ERR_INVALID_ARG;
+  OctaveState st[svp::kOctaves];
+  SSRLCV_HIP_TRY(hipMemcpyAsync(st, (const char*)workspace + plan->off_state, sizeof st, hipMemcpyDeviceToHost,
+                                (hipStream_t)stream));
+  SSRLCV_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  uint32_t m = 0;
+  for (int o = 0; o < svp::kOctaves; ++o)
+    if (st[o].overflow) m |= 1u << o;
+  *octaveMask = m;
+  return m ? SSRLCV_ERR_CAPACITY : SSRLCV_OK;
 }
 
 int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrlcv_sift_feature* features,

@@ -76,6 +76,16 @@ __device__ __forceinline__ void block_minmax_commit(float mn, float mx, float* m
   }
 }
 
+// generateBW (src/Image.cu:1277-1296) with bwaToBW / rgbToBW / rgbaToBW (:1253-1261): integer arithmetic on promoted
+// bytes.  (1 - a) * x + a * x is x for every alpha, so 2 channels keep the grey value, 4 channels drop alpha and go
+// through the RGB rule r/4 + g/2 + b/4 (each quotient truncated, sum <= 253).
+__global__ __launch_bounds__(256) void k_to_bw(const uint8_t* __restrict__ in, int depth, uint8_t* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* p = in + i * (size_t)depth;
+  out[i] = depth == 2 ? p[0] : (uint8_t)((p[0] / 4) + (p[1] / 2) + (p[2] / 4));
+}
+
 __global__ void k_init_minmax(float* mm, int pairs) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < pairs) { mm[2 * i] = FLT_MAX; mm[2 * i + 1] = -FLT_MAX; }
@@ -928,6 +938,16 @@ int ssrlcv_gauss_kernel_host(float sigma, float pixelWidth, float* weights) {
     weights[i] = expf(-((x * x) / 2.0f / sigma / sigma)) / sqrtf((float)(2.0f * SSRLCV_PI_D)) / sigma;
   }
   return ksize;
+}
+
+int ssrlcv_hip_convert_to_bw(const uint8_t* colorPixels, uint32_t colorDepth, uint8_t* bw, size_t numPixels,
+                             ssrlcv_stream_t stream) {
+  if (!colorPixels || !bw || colorDepth < 2 || colorDepth > 4) return SSRLCV_ERR_INVALID_ARG;
+  if (numPixels == 0) return SSRLCV_OK;
+  hipLaunchKernelGGL(k_to_bw, dim3((unsigned)((numPixels + 255) / 256)), dim3(256), 0, (hipStream_t)stream, colorPixels,
+                     (int)colorDepth, bw, numPixels);
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
 }
 
 int ssrlcv_hip_u8_to_f32(const uint8_t* pixels, float* out, size_t n, ssrlcv_stream_t stream) {

@@ -9,8 +9,9 @@ collectives are the two exchanges the flow really has:
               (MatchFactory::generateMatchesExhaustive, src/MatchFactory.cu:943-1020), which then runs replicated and
               deterministic on every rank (ssrlcv_merge_matches_host).
 
-Arrays have different lengths per rank, so each exchange is a count all-gather followed by one padded all-gather
-(payloads are tens of MB at most: latency-, not bandwidth-bound on 7 x 153 GB/s xGMI links).
+Arrays have different lengths per rank, so each exchange is one small size collective (with a single device-to-host
+copy of the size vector) followed by one all-gather into a flat buffer padded to the largest rank (payloads are tens
+to hundreds of MB: the feature exchange of eight 4096^2 views moves 8 x 240 MB, ~10 ms on 7 x 153 GB/s xGMI links).
 
 This module holds only the sharding / exchange logic; compute calls go through ssrlcv_amd.capi (HIP C ABI).
 """
@@ -41,21 +42,46 @@ def bundle_range(num_bundles, world, rank):
     return lo, min(lo + per, num_bundles)
 
 
+def _comm_device(tensor_device, group=None):
+    """Collectives run on the tensors' own device under RCCL; gloo (CPU tests, and the 2-ranks-on-one-GPU test) stages
+    CUDA tensors through the host."""
+    return torch.device("cpu") if dist.get_backend(group) == "gloo" else tensor_device
+
+
+def all_reduce_sum(t, group=None):
+    """In-place sum all-reduce that also works for CUDA tensors under gloo."""
+    cd = _comm_device(t.device, group)
+    if cd == t.device:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    else:
+        h = t.to(cd)
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    return t
+
+
 def all_gather_bytes(local, group=None):
     """All-gather of variable-length uint8 tensors.  `local` is a 1-D uint8 tensor on the backend's device (CUDA for
-    nccl, CPU for gloo).  Returns a list with one tensor per rank."""
+    nccl, CPU for gloo).  Returns a list with one tensor per rank.  One count all-gather (a single D2H copy of the
+    world-sized count vector) and one payload all-gather into a flat buffer padded to the largest rank."""
     world = dist.get_world_size(group)
-    dev = local.device
+    home = local.device
+    dev = _comm_device(home, group)
+    local = local.to(dev)
     n = torch.tensor([local.numel()], dtype=torch.int64, device=dev)
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
-    counts = [int(c.item()) for c in counts]
+    counts_t = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts_t, n, group=group)
+    counts = counts_t.tolist()
     mx = max(max(counts), 1)
-    padded = torch.zeros(mx, dtype=torch.uint8, device=dev)
-    padded[: local.numel()] = local
-    out = [torch.empty(mx, dtype=torch.uint8, device=dev) for _ in range(world)]
-    dist.all_gather(out, padded, group=group)
-    return [o[:c] for o, c in zip(out, counts)]
+    if local.numel() == mx:
+        padded = local
+    else:
+        padded = torch.zeros(mx, dtype=torch.uint8, device=dev)
+        padded[: local.numel()] = local
+    flat = torch.empty(world * mx, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(flat, padded, group=group)
+    flat = flat.to(home)
+    return [flat[r * mx: r * mx + c] for r, c in enumerate(counts)]
 
 
 def exchange_keyed(local_items, num_keys, owner_fn, group=None):
@@ -71,19 +97,31 @@ def exchange_keyed(local_items, num_keys, owner_fn, group=None):
         break
     if dev is None:
         dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    sizes = torch.tensor([local_items[k].numel() for k in mine], dtype=torch.int64, device=dev)
-    size_bytes = sizes.view(torch.uint8) if len(mine) else torch.zeros(0, dtype=torch.uint8, device=dev)
-    all_sizes = all_gather_bytes(size_bytes.contiguous(), group)
-    payload = torch.cat([local_items[k].reshape(-1) for k in mine]) if mine else torch.zeros(0, dtype=torch.uint8, device=dev)
-    all_payload = all_gather_bytes(payload.contiguous(), group)
+    home = dev
+    dev = _comm_device(home, group)
+    # sizes of every key in one all-reduce (each rank fills in the keys it owns): one collective + one D2H copy
+    sizes = torch.zeros(num_keys, dtype=torch.int64, device=dev)
+    for k in mine:
+        sizes[k] = local_items[k].numel()
+    dist.all_reduce(sizes, op=dist.ReduceOp.SUM, group=group)
+    sizes = sizes.tolist()
+    per_rank = [sum(sizes[k] for k in range(num_keys) if owner_fn(k, world) == r) for r in range(world)]
+    mx = max(max(per_rank), 1)
+    payload = torch.zeros(mx, dtype=torch.uint8, device=dev)
+    off = 0
+    for k in mine:
+        payload[off: off + sizes[k]] = local_items[k].reshape(-1).to(dev)
+        off += sizes[k]
+    flat = torch.empty(world * mx, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(flat, payload, group=group)
+    flat = flat.to(home)
     out = [None] * num_keys
     for r in range(world):
-        keys_r = [k for k in range(num_keys) if owner_fn(k, world) == r]
-        sz = all_sizes[r].view(torch.int64).tolist() if keys_r else []
-        off = 0
-        for k, s in zip(keys_r, sz):
-            out[k] = all_payload[r][off: off + s]
-            off += s
+        off = r * mx
+        for k in range(num_keys):
+            if owner_fn(k, world) == r:
+                out[k] = flat[off: off + sizes[k]]
+                off += sizes[k]
     return out
 
 

@@ -102,6 +102,26 @@ class Image {
   }
 };
 
+// convertToBW (src/Image.cu:665-690): pixels end up single-channel, in their origin memory state
+inline void convertToBW(ptr::value<Unity<unsigned char>> pixels, unsigned int colorDepth) {
+  if (colorDepth == 1) {
+    logger.warn << "Pixels are already bw";
+    return;
+  }
+  if (colorDepth < 2 || colorDepth > 4) {
+    logger.err.printf("ERROR colorDepth of %u is not supported", colorDepth);  // generateBW's default branch traps
+    std::exit(-1);
+  }
+  MemoryState origin = pixels->getMemoryState();
+  if (origin != gpu) pixels->setMemoryState(gpu);
+  unsigned long numPixels = pixels->size() / colorDepth;
+  ptr::device<unsigned char> bwPixels_device((long)numPixels);
+  HipSafeCall(ssrlcv_hip_convert_to_bw(pixels->device.get(), colorDepth, bwPixels_device.get(), numPixels, nullptr));
+  HipCheckError();
+  pixels->setData(bwPixels_device, numPixels, gpu);
+  if (origin != gpu) pixels->setMemoryState(origin);
+}
+
 static_assert(sizeof(Image::Camera) == sizeof(ssrlcv_camera), "Image::Camera must be 80 B");
 static_assert(sizeof(Image::PushbroomCamera) == sizeof(ssrlcv_pushbroom), "Image::PushbroomCamera must be 72 B");
 static_assert(sizeof(Image) == 240, "Image layout drifted from the reference's .cpimg dump");

@@ -1,0 +1,252 @@
+"""BASELINE.json configs [3] and [4] on one GPU, plus the pieces around them that only run with a device:
+
+  config[3]  4-view 4096 x 4096: N-view flow (ssrlcv_amd.pipeline at world size 1) on tools/scene.py views -- determinism,
+             every pair's uint2_pair list equal to the stand-alone matcher call, BA error sweep against the triangulator's
+             own error sum, cloud against the generator's ground truth; and the same flow (1024^2 fixtures) in TWO
+             processes on the one GPU over gloo, equal to the single-process result;
+  config[4]  8192 x 8192: SIFT properties at that size, and a pushbroom flow (generatePushbroomBundle -> N-view
+             triangulate) against the pushbroom generator's ground truth;
+  fp16 matcher (SSRLCV_MATCH_F16=1, the formulation the north star names) in a subprocess against the oracle;
+  colour input (convertToBW) and the key-point capacity flag.
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def _ground_truth_error(rig, scene_obj, mm, kp, pts):
+    """|triangulated point - generator's ground truth at the bundle's first key point|, km."""
+    first = kp[mm["index"]]
+    err = np.zeros(len(mm))
+    for v in np.unique(first["parentId"]):
+        sel = np.nonzero(first["parentId"] == v)[0]
+        xs = torch.from_numpy(first["loc"][sel, 0].copy()).to(scene_obj.device)
+        ys = torch.from_numpy(first["loc"][sel, 1].copy()).to(scene_obj.device)
+        gt, _, _ = rig.ground_points(scene_obj, int(v), xs, ys)
+        err[sel] = np.linalg.norm(pts[sel] - gt.cpu().numpy(), axis=1)
+    return err
+
+
+def test_config3_four_view_4096_flow(capi):
+    import scene
+    from ssrlcv_amd import pipeline, dist as sd
+    S, V = 4096, 4
+    imgs, cams, rig, sc = scene.pinhole_views(V, S)
+    seed, _ = H.load_seed_features()
+    ws = pipeline.Workspace()
+    res = pipeline.reconstruct(imgs, cams, seed_features=seed, mode=1, ws=ws, ba=True)
+    nfeat = [f.numel() // 152 for f in res["features"]]
+    assert all(2e5 < n < 2e6 for n in nfeat), nfeat       # ~0.03 features per pixel, like the everest fixtures
+    mm, kp, pts = res["matches"], res["keypoints"], res["points"].cpu().numpy()
+    assert len(mm) > 50000 and pts.shape == (len(mm), 3) and np.isfinite(pts).all()
+    assert set(np.unique(mm["numKeyPoints"])) <= {2, 3, 4} and (mm["numKeyPoints"] > 2).sum() > 1000
+    # determinism: a second pass through the same workspace reproduces every array
+    res2 = pipeline.reconstruct(imgs, cams, seed_features=seed, mode=1, ws=ws, ba=True)
+    assert all(torch.equal(a, b) for a, b in zip(res["features"], res2["features"]))
+    assert all(torch.equal(a, b) for a, b in zip(res["pairs"], res2["pairs"]))
+    assert np.array_equal(mm, res2["matches"]) and np.array_equal(kp, res2["keypoints"])
+    assert np.array_equal(pts, res2["points"].cpu().numpy())
+    # every pair's list equals the stand-alone 2-view matcher call on the same features
+    seed_d = capi.to_dev(seed)
+    for p, (qi, ti) in enumerate(sd.pair_list(V)):
+        fq, ft = res["features"][qi], res["features"][ti]
+        nq, nt = nfeat[qi], nfeat[ti]
+        sdist = capi.seed_distances(fq, nq, seed_d, len(seed))
+        params = capi.make_match_params(1, qi, ti, 25.0, 5.0, 0.6, 200.0 * 200.0, cams[qi:qi + 1],
+                                        capi.projection_matrix(cams[ti:ti + 1]))
+        out = capi.match(fq, nq, ft, nt, params, capi.OUT_UINT2_PAIR, seed_d=sdist)
+        n = capi.compact_matches(capi.OUT_UINT2_PAIR, out, nq, capi.match_workspace(nq, nt))
+        assert torch.equal(out[: n * 16], res["pairs"][p]), (p, n, res["pairs"][p].numel() // 16)
+    # BA error sweep on pair (0, 1): 612 sums; every gradient-stencil point (h = 1e-5) sits within a few per cent of the
+    # unperturbed value, which is the triangulator's own sum of squared gaps over the same bundles
+    sums = res["ba_sums"].cpu().numpy()
+    assert sums.shape == (612,) and np.isfinite(sums).all() and res["ba_bundles"] > 10000
+    two = np.nonzero(mm["numKeyPoints"] == 2)[0]
+    two = two[(kp["parentId"][mm["index"][two]] == 0) & (kp["parentId"][mm["index"][two] + 1] == 1)]
+    sub_mm = np.zeros(len(two), H.MULTIMATCH)
+    sub_mm["numKeyPoints"], sub_mm["index"] = 2, 2 * np.arange(len(two))
+    sub_kp = np.zeros(2 * len(two), H.KEYPOINT)
+    sub_kp["parentId"][1::2] = 1
+    sub_kp["loc"][0::2], sub_kp["loc"][1::2] = kp["loc"][mm["index"][two]], kp["loc"][mm["index"][two] + 1]
+    b_d, l_d = capi.generate_bundles(capi.to_dev(sub_mm), capi.to_dev(sub_kp), len(two), capi.to_dev(cams[:2].copy()), 2, len(sub_kp))
+    _, err_d, _ = capi.triangulate(l_d, b_d, len(two), want_errors=True)
+    ref = float(err_d.double().sum().item())
+    centre = sums[24 + 2]   # the unperturbed point of the first diagonal stencil
+    assert abs(centre - ref) <= 2e-3 * ref, (centre, ref)
+    assert np.abs(sums[:24] - centre).max() <= 0.2 * centre
+    # the cloud against the generator's ground truth: GSD 4.1 m, baselines 35..140 km at 400 km range
+    err = _ground_truth_error(rig, sc, mm, kp, pts)
+    print("config[3]: %d features/image, %d multi-matches, cloud error vs ground truth: median %.4f km, 90 %% %.4f km" %
+          (int(np.mean(nfeat)), len(mm), np.median(err), np.percentile(err, 90)))
+    assert np.median(err) < 0.03 and np.percentile(err, 90) < 0.15
+
+
+def _gloo_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)   # both ranks on the one GPU
+        from ssrlcv_amd import capi, pipeline
+        pix = [capi.to_dev(p).view(1024, 1024) for p in H.load_everest_pixels()]
+        seed, _ = H.load_seed_features()
+        v = H.load_view("Pipeline3View")
+        res = pipeline.reconstruct(pix, v["cameras"], seed_features=seed, ba=True)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), mm=res["matches"], kp=res["keypoints"],
+                 pts=res["points"].cpu().numpy(), ba=res["ba_sums"].cpu().numpy())
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_equal_single_process(capi, tmp_path):
+    """The sharded flow with world size 2 (both ranks on device 0, gloo collectives staged through the host) against
+    world size 1 and the reference's 3-view fixture: same MatchSet on both ranks, same cloud; BA sums to float
+    accumulation accuracy (the all-reduce adds two partial sums)."""
+    import socket
+    import torch.multiprocessing as mp
+    from ssrlcv_amd import pipeline
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    pix = [capi.to_dev(p).view(1024, 1024) for p in H.load_everest_pixels()]
+    seed, _ = H.load_seed_features()
+    v = H.load_view("Pipeline3View")
+    one = pipeline.reconstruct(pix, v["cameras"], seed_features=seed, ba=True)
+    for r in (r0, r1):
+        assert np.array_equal(r["mm"], one["matches"]) and np.array_equal(r["kp"], one["keypoints"])
+        assert np.array_equal(r["pts"], one["points"].cpu().numpy())
+        assert np.allclose(r["ba"], one["ba_sums"].cpu().numpy(), rtol=1e-4)
+    assert len(r0["mm"]) == 21177 and np.array_equal(r0["kp"]["loc"], v["kp0"]["loc"])
+
+
+def test_config4_sift_8192_properties(capi):
+    import scene
+    S = 8192
+    rig = scene.PushbroomRig(2, S)
+    sc = scene.Scene(S, rig.gsd_x, anisotropy=rig.gsd_y / rig.gsd_x)
+    img = rig.render(sc, 0)
+    plan = capi.SiftPlan(S, S)
+    plan.extract(img)
+    n1 = plan.count()
+    f1 = plan.features[: n1 * 152].clone()
+    plan.extract(img)
+    assert plan.count() == n1 and torch.equal(f1, plan.features[: n1 * 152])
+    f = capi.to_host(f1, H.FEATURE, n1)
+    assert 5e5 < n1 < 8e6, n1
+    assert (f["parent"] == -1).all() and (f["sigma"] > 0).all()
+    assert (f["theta"] >= 0).all() and (f["theta"] < 2 * np.pi + 1e-6).all()
+    assert (f["loc"] >= 0).all() and (f["loc"] < S).all()
+    norms = np.sqrt((f["values"].astype(np.float64) ** 2).sum(1))
+    assert np.percentile(norms, 0.1) > 245 and norms.max() < 265
+    # octave-major, blur-major, raster order inside a blur (refinement moves a key point by a few pixels at most): y falls
+    # back to the top of the image only at the <= 11 segment boundaries
+    dy = np.diff(f["loc"][:, 1])
+    assert (dy < -100.0).sum() <= 11
+
+
+def test_config4_pushbroom_flow_against_ground_truth(capi):
+    """Three pushbroom strips (2048^2 here: the flow, not the size, is what this covers) through SIFT, brute-force
+    matching with the seed ratio test, the host merge, generatePushbroomBundle and N-view triangulation; the cloud
+    against the pushbroom generator's ground truth."""
+    import scene
+    from ssrlcv_amd import pipeline
+    S, V = 2048, 3
+    imgs, pbs, rig, sc = scene.pushbroom_views(V, S)
+    seed, _ = H.load_seed_features()
+    res = pipeline.reconstruct(imgs, None, seed_features=seed, mode=0, pushbroom=pbs)
+    mm, kp, pts = res["matches"], res["keypoints"], res["points"].cpu().numpy()
+    assert len(mm) > 2000 and np.isfinite(pts).all()
+    err = _ground_truth_error(rig, sc, mm, kp, pts)
+    print("config[4] flow: %d multi-matches, cloud error vs ground truth: median %.4f km, 90 %% %.4f km" %
+          (len(mm), np.median(err), np.percentile(err, 90)))
+    # rolls 2..16 degrees: a 0.25 rad base angle at 400 km; a one-pixel (8 m across track) mismatch is ~0.03 km
+    assert np.median(err) < 0.05 and np.percentile(err, 90) < 0.5
+
+
+_F16_SCRIPT = r"""
+import os, sys, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import helpers as H
+from ssrlcv_amd import capi
+lib = H.oracle()
+rng = np.random.default_rng(3)
+def feats(n, seed):
+    r = np.random.default_rng(seed)
+    f = np.zeros(n, H.FEATURE); f["parent"] = -1
+    f["values"] = r.integers(0, 256, (n, 128), dtype=np.uint8); f["loc"] = r.uniform(0, 1024, (n, 2)).astype(np.float32)
+    return f
+q, t = feats(3000, 1), feats(5000, 2)
+t["values"][:500] = q["values"][:500]          # exact duplicates: distance 0, ties broken by the winner rule
+t["values"][600:700] = 255; q["values"][10:20] = 0   # extreme rows: the largest squared distances
+params = capi.make_match_params(0, 0, 1, 0.0, 0.0, 0.6, 3.0e7)
+out = capi.to_host(capi.match(capi.to_dev(q), len(q), capi.to_dev(t), len(t), params, capi.OUT_DMATCH), H.DMATCH, len(q))
+ref = H.oracle_match_dmatch(lib, 0, 0, q, 1, t, None, None, 0, 0, None, 0.6, 3.0e7)
+assert np.array_equal(out["invalid"], ref["invalid"]) and np.array_equal(out["distance"], ref["distance"])
+assert np.array_equal(out["kp1_loc"], ref["kp1_loc"])
+v = H.load_view("Pipeline2View"); cams = v["cameras"]
+params = capi.make_match_params(1, 0, 1, 25.0, 5.0, 0.6, 200.0 * 200.0, cams[0:1], capi.projection_matrix(cams[1:2]))
+out = capi.to_host(capi.match(capi.to_dev(q), len(q), capi.to_dev(t), len(t), params, capi.OUT_UINT2_PAIR), H.UINT2_PAIR, len(q))
+proj = H.oracle_projection(lib, cams[1:2])
+ref = H.oracle_match_pairs(lib, 1, 0, q, 1, t, cams[0:1], proj, 25.0, 5.0, None, 0.6, 200.0 * 200.0)
+assert np.array_equal(out["a"], ref["a"]) and np.array_equal(out["b"], ref["b"])
+print("F16 OK")
+"""
+
+
+def test_fp16_mfma_matcher_is_bit_exact_too():
+    """The matcher's fp16-MFMA formulation (v_mfma_f32_32x32x16_f16 with the norms carried as base-1024 digits; what
+    the north star names) is selected once per process by SSRLCV_MATCH_F16=1, so it is exercised in a child process:
+    brute force with duplicates / extreme rows and the orbit mode, both equal to the oracle entry for entry."""
+    env = dict(os.environ, SSRLCV_MATCH_F16="1")
+    r = subprocess.run([sys.executable, "-c", _F16_SCRIPT % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "F16 OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("depth", [2, 3, 4])
+def test_convert_to_bw_bit_exact(capi, oracle_lib, depth):
+    rng = np.random.default_rng(depth)
+    n = 300 * 200
+    color = rng.integers(0, 256, n * depth, dtype=np.uint8)
+    color[: 4 * depth] = 255
+    got = capi.convert_to_bw(capi.to_dev(color), depth, n).cpu().numpy()
+    ref = np.zeros(n, np.uint8)
+    oracle_lib.oracle_convert_to_bw(H.P(color), ctypes.c_uint32(depth), H.P(ref), ctypes.c_size_t(n))
+    assert np.array_equal(got, ref)
+    px = color.reshape(n, depth).astype(np.int64)
+    want = px[:, 0] if depth == 2 else px[:, 0] // 4 + px[:, 1] // 2 + px[:, 2] // 4
+    assert np.array_equal(ref, want.astype(np.uint8))
+
+
+def test_keypoint_capacity_overflow_is_reported_and_truncates(capi, oracle_lib):
+    """A plan with a tiny key-point capacity: the lists are truncated at the capacity (in the reference's order), the
+    overflow mask names the octaves, count() raises; the same image with the default capacity matches the oracle."""
+    img = H.synthetic_image(512, 512, seed=4)
+    small = capi.SiftPlan(512, 512, max_keypoints_per_octave=4096)
+    small.extract(capi.to_dev(img))
+    assert small.overflow_mask() & 1
+    with pytest.raises(capi.SsrlcvError):
+        small.count()
+    torch.cuda.synchronize()
+    n = int(small.num_features.item())
+    of = H.oracle_sift(oracle_lib, img)
+    assert 0 < n < len(of)
+    full = capi.SiftPlan(512, 512)
+    full.extract(capi.to_dev(img))
+    assert full.overflow_mask() == 0
+    H.assert_features_equal(full.features_host(H.FEATURE), of)
