@@ -80,6 +80,23 @@ def _value_noise(coords_a, coords_b, cells, lattice):
     return (v00 * (1 - ta) + v10 * ta) * (1 - tb) + (v01 * (1 - ta) + v11 * ta) * tb
 
 
+def _blur_separable(img, g, r):
+    """Zero-padded separable convolution as 2 (2r + 1) shifted multiply-adds (no conv library: MIOpen spends minutes
+    choosing a kernel for a 20480^2 single-channel image)."""
+    n = img.shape[0]
+    pad = torch.zeros(n, n + 2 * r, device=img.device)
+    pad[:, r: r + n] = img
+    out = torch.zeros_like(img)
+    for k in range(2 * r + 1):
+        out += g[k] * pad[:, k: k + n]
+    pad = torch.zeros(n + 2 * r, n, device=img.device)
+    pad[r: r + n] = out
+    out = torch.zeros_like(img)
+    for k in range(2 * r + 1):
+        out += g[k] * pad[k: k + n]
+    return out
+
+
 class Scene:
     """Terrain + texture of one patch.  `texels` = side of the texture raster (2 per nominal image pixel)."""
 
@@ -128,10 +145,7 @@ class Scene:
             r = int(math.ceil(3 * st))
             g = torch.exp(-0.5 * (torch.arange(-r, r + 1, device=dev, dtype=torch.float32) / st) ** 2)
             g = g / g.sum()
-            img = imp.view(1, 1, n, n)
-            img = torch.nn.functional.conv2d(img, g.view(1, 1, 1, -1), padding=(0, r))
-            img = torch.nn.functional.conv2d(img, g.view(1, 1, -1, 1), padding=(r, 0))
-            tex += img.view(n, n)
+            tex += _blur_separable(imp.view(n, n), g, r)
         self.tex = (tex + 128.0).contiguous()
 
     def height(self, a, b):
