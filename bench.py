@@ -16,6 +16,8 @@ Besides the contract keys the JSON line carries
                   roofline from the committed PMC reduction (profiles/);
   matcher       : Mmatches/s of ssrlcv_hip_match_u8x128 (pairs compared / time) on Nq = Nt synthetic descriptors, with
                   its int8-MFMA roofline (2*128*Nq*Nt op), and the band-culled orbit mode;
+  class_api     : the same extraction through ssrlcv::SIFT_FeatureFactory::generateFeatures from host-state pixels
+                  (PCIe included), timed by the C++ host-mirror binary;
   nview         : BASELINE config[3] as one more measured step: V views sharded over the ranks, RCCL all-gather of the
                   feature arrays and of the uint2_pair arrays, replicated merge, bundle-range N-view triangulation,
                   all-gather of the cloud, BA error sweep with its all-reduce -- with the wall share of every stage;
@@ -166,6 +168,37 @@ def cpu_baseline(size, runs=3):
                       % (size, size, len(f), runs, ", ".join("%.2f" % t for t in times))}
 
 
+def class_api_leg(img_u8, size, value_c_abi, iters=5):
+    """The same extraction through the drop-in C++ class API (ssrlcv::SIFT_FeatureFactory::generateFeatures on an Image
+    whose Unity<unsigned char> pixels sit in host memory), timed by the host-mirror binary: the number a caller of the
+    reference sees, H2D of the image (and the restore of its origin state) included; the second figure adds the D2H of
+    the feature array."""
+    exe = os.path.join(ROOT, "ssrlcv_amd", "host", "_build", "host_mirror_test")
+    if not os.path.exists(exe):
+        return {"error": "host mirror binary not built"}
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".raw", dir="/tmp", delete=False) as f:
+        f.write(img_u8.cpu().numpy().tobytes())
+        raw = f.name
+    try:
+        r = subprocess.run([exe, "bench", raw, str(size), str(size), str(iters)], capture_output=True, text=True, timeout=600)
+    finally:
+        os.unlink(raw)
+    if r.returncode != 0:
+        return {"error": (r.stdout + r.stderr)[-400:]}
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    mpix = size * size / 1e6
+    return {"features": j["features"],
+            "generateFeatures_from_host_pixels": {"ms_per_image": j["ms_generateFeatures_from_host_pixels"],
+                                                  "value": mpix / (j["ms_generateFeatures_from_host_pixels"] * 1e-3), "unit": "Mpix/s"},
+            "with_features_to_host": {"ms_per_image": j["ms_with_features_to_host"],
+                                      "value": mpix / (j["ms_with_features_to_host"] * 1e-3), "unit": "Mpix/s"},
+            "c_abi_resident_value": value_c_abi,
+            "note": "one image at a time, synchronous like the reference's methods; plan, workspace and staging buffer "
+                    "are pooled inside the factory; includes the image H2D, the restore of the pixels' origin state "
+                    "(a D2H copy, as upstream) and the exact-size feature copy"}
+
+
 def describe_roofline(ms_per_image, features, size):
     """VALU-issue roofline of the key-point stage from the committed PMC reduction of its kernels (instruction counts per
     feature do not depend on the run; the time does)."""
@@ -241,6 +274,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matcher", action="store_true")
     ap.add_argument("--no-nview", action="store_true")
+    ap.add_argument("--no-class-api", action="store_true")
     ap.add_argument("--nview-views", type=int, default=4)
     ap.add_argument("--nview-size", type=int, default=2048,
                     help="edge of the N-view leg's images (config[3] is 4096; the default keeps the whole run within minutes)")
@@ -337,6 +371,8 @@ def main():
                          "ms_per_image": pyr_ms},
             "describe": describe_roofline(desc_ms, int(np.mean(nfeat)), W),
         }
+        if not args.no_class_api:
+            line["class_api"] = class_api_leg(imgs[0], W, value / world)
         if not args.no_matcher:
             line["matcher"] = bench_matcher(capi, torch, args.match_n, args.match_n, args.match_iters)
             line["matcher_epipolar"] = bench_matcher_epipolar(capi, torch, args.match_n, W, args.match_iters)

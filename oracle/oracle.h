@@ -200,6 +200,8 @@ void oracle_convert_to_bw(const uint8_t* color, uint32_t colorDepth, uint8_t* bw
 /* element-wise evaluation of oracle_libm.h (fn: 0 expf(a), 1 atan2f(a,b), 2 sinf, 3 cosf, 4 tanf, 5 powf(a,b)) */
 void oracle_math_eval(int fn, const float* a, const float* b, float* out, size_t n);
 
+/* P5: V S' U^T of calculateImageHessianInverse (src/PointCloudFactory.cu:1511-1824), n <= 12, row-major */
+void oracle_pinv(const float* H, int n, float* out);
 /* exhaustive check of the 3-operation exact division used by the HIP kernels (see oracle_pointcloud.c) */
 long oracle_check_exact_div3(float d);
 

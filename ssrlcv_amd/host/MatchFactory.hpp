@@ -33,6 +33,17 @@ template <typename T>
 class MatchFactory {
  private:
   ptr::value<Unity<Feature<T>>> seedFeatures;
+  // grow-only matcher workspace kept for the factory's lifetime: generateMatchesExhaustive calls run() once per image
+  // pair and getSeedDistances once per image, and a hipMalloc / hipFree of ~100 MB per call was a fifth of a pair's time
+  ptr::device<unsigned char> wsCache;
+  size_t wsCacheBytes = 0;
+  unsigned char* workspace(size_t bytes) {
+    if (bytes > wsCacheBytes) {
+      wsCache = ptr::device<unsigned char>((long)bytes);
+      wsCacheBytes = bytes;
+    }
+    return wsCache.get();
+  }
 
   static ssrlcv_match_params make_params(int mode, ptr::value<Image> query, ptr::value<Image> target, float epsilon,
                                          float delta, float rel, float absolute) {
@@ -78,16 +89,16 @@ class MatchFactory {
     ssrlcv_match_params p = make_params(mode, query, target, epsilon, delta, relativeThreshold, absoluteThreshold);
     if (fundamental) std::memcpy(p.fundamental, fundamental, sizeof p.fundamental);
     size_t wsBytes = ssrlcv_hip_match_workspace_bytes(nq, nt);
-    ptr::device<unsigned char> ws((long)wsBytes);
+    unsigned char* ws = workspace(wsBytes);
     ptr::value<Unity<OUT>> matches(nullptr, (unsigned long)nq, gpu);
     HipSafeCall(ssrlcv_hip_match_u8x128(reinterpret_cast<const ssrlcv_sift_feature*>(queryFeatures->device.get()), nq,
                                         reinterpret_cast<const ssrlcv_sift_feature*>(targetFeatures->device.get()), nt,
-                                        seed_d, &p, outKind, matches->device.get(), ws.get(), wsBytes, nullptr));
+                                        seed_d, &p, outKind, matches->device.get(), ws, wsBytes, nullptr));
     HipCheckError();
     if (seedDistances != nullptr && seedOrigin != gpu) seedDistances->setMemoryState(seedOrigin);
     // validateMatches (src/MatchFactory.cu:32-108)
     uint32_t left = 0;
-    HipSafeCall(ssrlcv_hip_compact_matches(outKind, matches->device.get(), nq, &left, ws.get(), wsBytes, nullptr));
+    HipSafeCall(ssrlcv_hip_compact_matches(outKind, matches->device.get(), nq, &left, ws, wsBytes, nullptr));
     if (left == 0) {
       logger.info << "No valid matches found";
     } else {
@@ -119,10 +130,9 @@ class MatchFactory {
     uint32_t nq = (uint32_t)features->size(), ns = (uint32_t)seedFeatures->size();
     ptr::value<Unity<float>> out(nullptr, (unsigned long)nq, gpu);
     size_t wsBytes = ssrlcv_hip_match_workspace_bytes(nq, ns);
-    ptr::device<unsigned char> ws((long)wsBytes);
     HipSafeCall(ssrlcv_hip_seed_distances_u8x128(reinterpret_cast<const ssrlcv_sift_feature*>(features->device.get()), nq,
                                                  reinterpret_cast<const ssrlcv_sift_feature*>(seedFeatures->device.get()),
-                                                 ns, out->device.get(), ws.get(), wsBytes, nullptr));
+                                                 ns, out->device.get(), workspace(wsBytes), wsBytes, nullptr));
     HipCheckError();
     if (origin != gpu) features->setMemoryState(origin);
     return out;

@@ -69,9 +69,11 @@ inline float3 rotatePointArbitrary(float3 point, float3 axis, float angle) {
   return matrixMulVector(point, R);
 }
 
-// Moore-Penrose pseudo-inverse V S^-1 U^T of an N x N matrix (row-major), singular values below `cutoff` dropped
-// (the reference's `S > 0.0001 ? 1 / S : 0`, src/PointCloudFactory.cu:1698, src/PoseEstimator.cu:444): one-sided Jacobi
-// SVD in double on the host.  PARITY UNPINNED: no reference fixture reaches the cuSOLVER results it replaces.
+// V S' U^T of an N x N matrix (row-major) as calculateImageHessianInverse builds it (src/PointCloudFactory.cu:1511-1824:
+// cusolverDnSgesvd, then `if (S[i] >= 0.0001) S[i] = 1.0 / S[i]` (:1698) -- a singular value BELOW the cutoff is not
+// zeroed, it keeps its own small value as the factor -- then V S' U^T by two cublasSgemm): one-sided Jacobi SVD in
+// double on the host.  No reference fixture reaches the cuSOLVER results it replaces; held to the oracle's independent
+// restatement and a numpy fixture (tests/test_pinv.py).
 inline std::vector<float> pseudoInverse(const float* M, int N, double cutoff = 1e-4) {
   std::vector<double> U(N * N), Vm(N * N, 0.0);
   for (int i = 0; i < N * N; ++i) U[i] = M[i];
@@ -103,9 +105,10 @@ inline std::vector<float> pseudoInverse(const float* M, int N, double cutoff = 1
     double s = 0;
     for (int r = 0; r < N; ++r) s += U[r * N + k] * U[r * N + k];
     s = std::sqrt(s);
-    if (s < cutoff) continue;  // sigma below the cutoff contributes nothing
+    if (s == 0.0) continue;
+    const double f = s >= cutoff ? 1.0 / s : s;  // :1698
     for (int i = 0; i < N; ++i)
-      for (int j = 0; j < N; ++j) out[i * N + j] += Vm[i * N + k] * (U[j * N + k] / s) / s;  // V S^-1 U^T
+      for (int j = 0; j < N; ++j) out[i * N + j] += Vm[i * N + k] * (U[j * N + k] / s) * f;  // V S' U^T
   }
   std::vector<float> inv(N * N);
   for (int i = 0; i < N * N; ++i) inv[i] = (float)out[i];

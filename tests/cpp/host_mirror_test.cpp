@@ -4,6 +4,8 @@
 //   pipeline2 <dir>     (GPU) SIFT -> seed distances -> double-constrained match -> MatchSet -> triangulate -> BA, through
 //                       the reference's class API; inputs/outputs are .uty / .cpimg files in <dir>
 //   pipeline3 <dir>     (GPU) 3-view: generateMatchesExhaustive -> nViewTriangulate
+//   pinv <in> <out>     pseudoInverse of every 12 x 12 float matrix in a file (no GPU needed)
+//   bench <raw> W H n   (GPU) times SIFT_FeatureFactory::generateFeatures from host-state pixels (PCIe included)
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -239,11 +241,74 @@ static int pose_mode(const std::string& dir) {
   return 0;
 }
 
+// bench <raw u8 file> <W> <H> <iters>: the drop-in class path as a reference caller sees it.  Pixels start in host
+// memory (Unity state cpu, pinned) for every call, so each generateFeatures includes the H2D copy of the image; the
+// second figure also brings the features back (transferMemoryTo(cpu)), i.e. both PCIe legs.  One JSON line.
+#include <chrono>
+static int bench_mode(const std::string& path, unsigned W, unsigned H, int iters) {
+  std::FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) { std::fprintf(stderr, "cannot open %s\n", path.c_str()); return 2; }
+  ptr::host<unsigned char> px((long)W * H, true);
+  size_t got = std::fread(px.get(), 1, (size_t)W * H, f);
+  std::fclose(f);
+  CHECK(got == (size_t)W * H);
+  SIFT_FeatureFactory factory(1.5f, 6.0f);
+  auto run = [&](bool fetch, double& ms, unsigned long& nfeat) {
+    double total = 0;
+    for (int i = -1; i < iters; ++i) {  // i == -1: warm-up (plan + workspace creation)
+      ptr::value<Unity<unsigned char>> pixels(px, (unsigned long)W * H, cpu, true);
+      ptr::value<Image> image(uint2{W, H}, 1u, pixels);
+      image->id = 0;
+      auto t0 = std::chrono::steady_clock::now();
+      auto feats = factory.generateFeatures(image, false, 2, 0.8f);
+      if (fetch) feats->transferMemoryTo(cpu);
+      HipSafeCall(ssrlcv_hip_device_synchronize());
+      auto t1 = std::chrono::steady_clock::now();
+      if (i >= 0) total += std::chrono::duration<double, std::milli>(t1 - t0).count();
+      nfeat = feats->size();
+    }
+    ms = total / iters;
+  };
+  double msGen = 0, msFetch = 0;
+  unsigned long n = 0;
+  run(false, msGen, n);
+  run(true, msFetch, n);
+  std::printf("{\"features\": %lu, \"ms_generateFeatures_from_host_pixels\": %.3f, \"ms_with_features_to_host\": %.3f}\n", n,
+              msGen, msFetch);
+  return 0;
+}
+
+// pinv <in.bin> <out.bin>: ssrlcv::pseudoInverse (host/matrix_util.hpp, the P5 replacement of cuSOLVER + cuBLAS) on every
+// 12 x 12 float matrix of the input file
+static int pinv_mode(const std::string& in, const std::string& out) {
+  std::FILE* f = std::fopen(in.c_str(), "rb");
+  CHECK(f != nullptr);
+  std::vector<float> buf;
+  float m[144];
+  std::FILE* g = std::fopen(out.c_str(), "wb");
+  CHECK(g != nullptr);
+  while (std::fread(m, sizeof(float), 144, f) == 144) {
+    std::vector<float> inv = pseudoInverse(m, 12);
+    std::fwrite(inv.data(), sizeof(float), 144, g);
+  }
+  std::fclose(f);
+  std::fclose(g);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   std::string mode = argc > 1 ? argv[1] : "typeinfo";
   try {
     if (mode == "typeinfo") return typeinfo_mode();
     if (argc < 3) { std::fprintf(stderr, "usage: %s <mode> <dir>\n", argv[0]); return 2; }
+    if (mode == "bench") {
+      if (argc < 6) { std::fprintf(stderr, "usage: %s bench <raw u8 file> <W> <H> <iters>\n", argv[0]); return 2; }
+      return bench_mode(argv[2], (unsigned)std::atoi(argv[3]), (unsigned)std::atoi(argv[4]), std::atoi(argv[5]));
+    }
+    if (mode == "pinv") {
+      if (argc < 4) { std::fprintf(stderr, "usage: %s pinv <in.bin> <out.bin>\n", argv[0]); return 2; }
+      return pinv_mode(argv[2], argv[3]);
+    }
     if (mode == "cpu") return cpu_mode(argv[2]);
     if (mode == "pipeline2") return pipeline_mode(argv[2], 2);
     if (mode == "pipeline3") return pipeline_mode(argv[2], 3);
