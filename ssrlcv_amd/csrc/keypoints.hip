@@ -432,42 +432,93 @@ __device__ __forceinline__ int round_coord(float v) {
 // independent, but not the reference's sum: thetas agreed to ~1e-6 and a handful of peak decisions per million key
 // points flipped.
 constexpr int kThetaChunk = 8;
+
+// Work list of the two sampling kernels: the key points of ALL octaves in one launch.  Every octave's list is cut at
+// its blur-segment boundaries (a segment = one DoG level = one polar table = one class of window sizes: windows grow
+// with the blur index and are the same in every octave, sigma / pixelWidth being the same), and the ranges are laid
+// out largest windows first.  One launch instead of four: the short octaves hold a few thousand key points, i.e. a
+// handful of waves whose run time is that of ONE wave (0.4 ms for a blur-3 window) -- four launches in a row paid that
+// latency four times (1.96 ms of orientation kernels for 216 k key points, 1.3 ms of it for 10 % of them).
+struct RangeTable {
+  uint32_t first[20], count[20], start[20];  // range r = order * 4 + octave: list index, length, first work unit
+  uint32_t total;                            // work units in all ranges
+};
+static_assert(sizeof(RangeTable) <= 256, "lives in an octave's 256-byte bookkeeping slot");
+__device__ __constant__ const int kSegOrder[5] = {3, 2, 1, 4, 0};
+// unitShift: log2 of the key points per work unit (6: one 64-lane block of k_thetas; 0: one wave of k_descriptors)
+__global__ void k_build_ranges(const OctaveState* st, RangeTable* tab, int unitShift) {
+  uint32_t pos = 0;
+  for (int k = 0; k < 5; ++k) {
+    const int seg = kSegOrder[k];
+    for (int o = 0; o < svp::kOctaves; ++o) {
+      const int r = k * 4 + o;
+      uint32_t first = 0, count = 0;
+      if (st[o].hasExtrema) {
+        const int lo = st[o].idx[seg], hi = seg < svp::kDog - 1 ? st[o].idx[seg + 1] : st[o].n;
+        if (hi > lo) { first = (uint32_t)lo; count = (uint32_t)(hi - lo); }
+      }
+      tab->first[r] = first;
+      tab->count[r] = count;
+      tab->start[r] = pos;
+      pos += (count + (1u << unitShift) - 1) >> unitShift;
+    }
+  }
+  tab->total = pos;
+}
+// work unit u -> range (wave-uniform scan of the 20 starts; empty ranges share their successor's start and are skipped)
+__device__ __forceinline__ int range_of(const RangeTable* tab, uint32_t u) {
+  int r = 0;
+#pragma unroll
+  for (int k = 1; k < 20; ++k)
+    if (tab->start[k] <= u) r = k;
+  return r;
+}
+
+struct OctaveSet {  // per-octave arguments of the combined sampling kernels
+  LevelSet L[svp::kOctaves];
+  const ssrlcv_sskeypoint* kps[svp::kOctaves];
+  float pixelWidth[svp::kOctaves];
+  float* thetas[svp::kOctaves];
+  uint32_t* thetaCnt[svp::kOctaves];
+  const void* consts[svp::kOctaves];
+};
+
 template <int MAXO>
-__global__ __launch_bounds__(64) void k_thetas(const OctaveState* st, const ssrlcv_sskeypoint* kps, LevelSet L,
-                                               float pixelWidth, float lambda, float orientationThreshold,
-                                               float* __restrict__ thetas, uint32_t* __restrict__ thetaCnt) {
+__global__ __launch_bounds__(64) void k_thetas(const OctaveState* states, const RangeTable* tab, OctaveSet set, float lambda,
+                                               float orientationThreshold) {
   __shared__ float s_hist[36][64];
-  const int n = st->hasExtrema ? st->n : 0;
-  if ((int)(blockIdx.x * 64) >= n) return;  // block-uniform
+  if (blockIdx.x >= tab->total) return;  // block-uniform
+  const int range = __builtin_amdgcn_readfirstlane(range_of(tab, blockIdx.x));
+  const int octave = range & 3, useg = kSegOrder[range >> 2];
+  const LevelSet& L = set.L[octave];
+  const float pixelWidth = set.pixelWidth[octave];
   const int t = threadIdx.x;
-  const int gi = blockIdx.x * 64 + t;
-  const bool have = gi < n;
+  const uint32_t local = (blockIdx.x - tab->start[range]) * 64 + t;
+  const bool have = local < tab->count[range];
+  const int gi = (int)(tab->first[range] + local);
   const float pi = SSRLCV_PI_F;
   const float rad10 = pi / 18.0f;
   const float inv10 = 1.0f / rad10;
   ssrlcv_sskeypoint kp;
   kp.loc.x = kp.loc.y = 0.0f;
   kp.sigma = 1.0f;
-  if (have) kp = kps[gi];
-  const int seg = have ? segment_of(st, gi) : -1;
+  if (have) kp = set.kps[octave][gi];
   const float kx = kp.loc.x, ky = kp.loc.y;
   const float windowWidth = ceilf(kp.sigma * 3.0f * lambda / pixelWidth);
   const float minx = kx - windowWidth, miny = ky - windowWidth, maxx = kx + windowWidth, maxy = ky + windowWidth;
-  const bool inside = have && !(minx < 0.0f || miny < 0.0f || maxx >= (unsigned)(L.w - 1) || maxy >= (unsigned)(L.h - 1));
+  // (key points live on DoG levels 1..3: refinement discards what would move to level 0 or 4)
+  const bool inside = have && useg >= 1 && useg <= 3 &&
+                      !(minx < 0.0f || miny < 0.0f || maxx >= (unsigned)(L.w - 1) || maxy >= (unsigned)(L.h - 1));
 #pragma unroll
   for (int i = 0; i < 36; ++i) s_hist[i][t] = 0.0f;
   const float weight = 2.0f * lambda * lambda * kp.sigma * kp.sigma;
   const float rweight = 1.0f / weight;
   const int W = L.w;
   const size_t levelStride = svp::polar_level_stride(L.w, L.h);
-  // A wave's key points nearly always share a blur segment (the list is segment-ordered), i.e. a polar table; the few
-  // waves that straddle a boundary take one pass per segment so that the buffer descriptor stays wave-uniform.
-  unsigned long long todo = __ballot(inside);
-  while (todo) {
-    const int lead = __ffsll((long long)todo) - 1;
-    const int useg = __builtin_amdgcn_readlane(seg, lead);
-    bool active = inside && seg == useg;
-    todo &= ~__ballot(active);
+  // every lane of the block is in the same blur segment (the ranges are cut there), so the polar table -- the buffer
+  // descriptor -- is wave-uniform
+  {
+    bool active = inside;
     // entry e of the table (flat index e - 1) is at byte 8 e; reads past the end return 0 (and belong to lanes whose
     // samples are not used: a window row stays inside the level)
     const float2* base = L.polar + (size_t)(useg - 1) * levelStride;
@@ -515,27 +566,36 @@ __global__ __launch_bounds__(64) void k_thetas(const OctaveState* st, const ssrl
         }
       }
       if (active) fetch(x, rowoff);
-      // Branch-free: a sample that does not count (past the row's end, or bin 36 from an angle one ulp below 2 pi, which
-      // the reference's `bin < 36` guard drops... upstream it is an out-of-bounds write, see the oracle) adds
-      // fmaf(0, 0, h) = h to bin 0.  The bin's old value is requested before the Gaussian is evaluated, so the LDS
-      // round trip hides behind it.
-      auto vote = [&](float mag, float ang, float xi, bool valid) {
+      // Two phases per chunk.  (1) The eight samples' Gaussian weights and bins are independent of each other and of the
+      // histogram: evaluated together they overlap their long dependent chains (the f64 Horner steps, the divisions) --
+      // a lone wave, all the short octaves ever have, otherwise spends most of its time waiting on its own results.
+      // (2) The histogram updates, strictly in raster order, branch-free: a sample that does not count (past the row's
+      // end, or bin 36 from an angle one ulp below 2 pi, which the reference's array has no slot for) adds
+      // fmaf(0, 0, h) = h to bin 0.
+      auto weigh = [&](float ang, float xi, float& wgt, int& bin) {
         const float angle = fmod_2pi_above(ang + (2.0f * pi), 2.0f * pi);
-        const int bin = (int)floorf(sv::exact_div3(angle, rad10, inv10));
+        bin = (int)floorf(sv::exact_div3(angle, rad10, inv10));
+        const float tx = xi - kx;
+        wgt = sv::expf_nonpos(sv::exact_div5(-((tx * tx) + cty2), weight, rweight));
+      };
+      auto vote = [&](float mag, float wgt, int bin, bool valid) {
         const bool counts = valid && (unsigned)bin < 36u;
         float* slot = &s_hist[counts ? bin : 0][t];
-        const float h = *slot;
-        const float tx = xi - kx;
-        const float wgt = sv::expf_nonpos(sv::exact_div5(-((tx * tx) + cty2), weight, rweight));
-        *slot = fmaf(counts ? mag : 0.0f, counts ? wgt : 0.0f, h);
+        *slot = fmaf(counts ? mag : 0.0f, counts ? wgt : 0.0f, *slot);
       };
       const bool fast = cact && aligned;
-#pragma unroll
-      for (int i = 0; i < kThetaChunk; ++i)
       {
-        // (element first, cast second: __builtin_bit_cast applied directly to a vector-element lvalue reads element 0)
-        const unsigned um = cur[i >> 1][(i & 1) * 2], ua = cur[i >> 1][(i & 1) * 2 + 1];
-        vote(__builtin_bit_cast(float, um), __builtin_bit_cast(float, ua), xs[i], fast && xs[i] <= maxx);
+        float wg[kThetaChunk], mg[kThetaChunk];
+        int bn[kThetaChunk];
+#pragma unroll
+        for (int i = 0; i < kThetaChunk; ++i) {
+          // (element first, cast second: __builtin_bit_cast applied directly to a vector-element lvalue reads element 0)
+          const unsigned um = cur[i >> 1][(i & 1) * 2], ua = cur[i >> 1][(i & 1) * 2 + 1];
+          mg[i] = __builtin_bit_cast(float, um);
+          weigh(__builtin_bit_cast(float, ua), xs[i], wg[i], bn[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < kThetaChunk; ++i) vote(mg[i], wg[i], bn[i], fast && xs[i] <= maxx);
       }
       // rare (a chunk that crosses a binade with an unlucky fraction, or starts below x = 4): the lane's samples are
       // gathered one by one.  After the fast path in program order, so that its loads do not sit between the prefetch
@@ -548,7 +608,10 @@ __global__ __launch_bounds__(64) void k_thetas(const OctaveState* st, const ssrl
           for (int i = 0; i < kThetaChunk; ++i) {
             if (xi <= maxx) {
               const float2 e = lvl[crow + (unsigned)round_pos(xi)];
-              vote(e.x, e.y, xi, true);
+              float wgt;
+              int bin;
+              weigh(e.y, xi, wgt, bin);
+              vote(e.x, wgt, bin, true);
             }
             xi += 1.0f;
           }
@@ -604,8 +667,8 @@ __global__ __launch_bounds__(64) void k_thetas(const OctaveState* st, const ssrl
   }
   if (have) {
 #pragma unroll
-    for (int i = 0; i < MAXO; ++i) thetas[(size_t)gi * svp::kMaxOrient + i] = outTheta[i];
-    thetaCnt[gi] = cnt;
+    for (int i = 0; i < MAXO; ++i) set.thetas[octave][(size_t)gi * svp::kMaxOrient + i] = outTheta[i];
+    set.thetaCnt[octave][gi] = cnt;
   }
 }
 
@@ -692,14 +755,11 @@ constexpr int kDescCopies = SSRLCV_DESC_COPIES;
 #endif
 // waves_per_eu(4, 8) + an explicit VGPR cap instead of __launch_bounds__(256, 8): the latter also caps the SGPRs at 80
 // (the budget of a 10-wave gfx9 part), and this kernel keeps the rotated cell centres and per-key-point constants there
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8), amdgpu_num_vgpr(SSRLCV_DESC_VGPRS), amdgpu_num_sgpr(102))) void k_descriptors(const OctaveState* st, const ssrlcv_sskeypoint* kps, LevelSet L,
-                                                     float pixelWidth, const DescConst* __restrict__ consts,
-                                                     const uint32_t* featBase, int octave,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8), amdgpu_num_vgpr(SSRLCV_DESC_VGPRS), amdgpu_num_sgpr(102))) void k_descriptors(const RangeTable* tab, OctaveSet set, const uint32_t* featBase,
                                                      ssrlcv_sift_feature* __restrict__ features, uint32_t maxFeatures) {
   // lane-private copies of the 128 bins (copy = lane & 7, bin-major / copy-minor) keep same-address conflicts low
   __shared__ unsigned s_bins[4][(1 + 128 + 2) * kDescCopies];  // one bin of padding in front, two behind (votes of 0)
   __shared__ __attribute__((aligned(8))) uint8_t s_bytes[4][128];
-  const int n = st->hasExtrema ? st->n : 0;
   // the wave index as a scalar: key-point index, list loads and per-key-point constants then live in SGPRs
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   unsigned* bins = s_bins[wave] + kDescCopies;
@@ -707,10 +767,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8), amdg
   const float pi = SSRLCV_PI_F;
   const float rad45 = pi / 4.0f;
   const float inv45 = 1.0f / rad45;
-  const float2* __restrict__ polar = L.polar;  // key points live on levels 1..3, whose polar tables are always built
-  for (int gi = blockIdx.x * 4 + wave; gi < n; gi += gridDim.x * 4) {
-    const DescConst dc = consts[gi];  // gi is wave-uniform: scalar loads
-    const ssrlcv_sskeypoint kp = kps[gi];
+  const uint32_t totalUnits = tab->total;
+  // one work unit = one key point; units walk the octaves' blur segments from the largest windows to the smallest
+  for (uint32_t unit = blockIdx.x * 4 + wave; unit < totalUnits; unit += gridDim.x * 4) {
+    const int range = range_of(tab, unit);
+    const int octave = range & 3;
+    const int gi = (int)(tab->first[range] + (unit - tab->start[range]));
+    const LevelSet& L = set.L[octave];
+    const float pixelWidth = set.pixelWidth[octave];
+    const float2* __restrict__ polar = L.polar;  // key points live on levels 1..3, whose polar tables are always built
+    const DescConst dc = reinterpret_cast<const DescConst*>(set.consts[octave])[gi];  // gi is wave-uniform: scalar loads
+    const ssrlcv_sskeypoint kp = set.kps[octave][gi];
     const int seg = dc.segment;
     const float kx = kp.loc.x, ky = kp.loc.y;
     const float theta = kp.theta;
@@ -1018,6 +1085,8 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
       }
     }
   }
+  ssrlcv_sskeypoint* curBuf[svp::kOctaves];
+  ssrlcv_sskeypoint* othBuf[svp::kOctaves];
   for (int o = 0; o < svp::kOctaves; ++o) {
     const svp::OctavePlan& oc = plan->oct[o];
     OctaveState* st = states + o;
@@ -1111,22 +1180,58 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
         swap();
       }
     }
-    if (stop >= 6) {  // computeKeyPointOrientations (src/FeatureFactory.cu:540-632)
-      if (as) SSRLCV_HIP_TRY(hipStreamWaitEvent(s, as->polarDone[o], 0));
-      else hipLaunchKernelGGL(k_polar, dim3((oc.w + 255) / 256, (oc.h + kPolRows - 1) / kPolRows, 3), dim3(256), 0, s, L, (float2*)(ws + oc.off_polar));
-      float* thetas = (float*)(ws + oc.off_theta);
-      uint32_t* thetaCnt = (uint32_t*)(ws + oc.off_thetaCnt);
-      dim3 g((cap + 63) / 64);  // one lane per key point, one-wave blocks; blocks past the list's end return at once
-      switch (maxO) {
-        case 1: hipLaunchKernelGGL(k_thetas<1>, g, dim3(64), 0, s, st, cur, L, oc.pixelWidth, plan->params.orientationContribWidth, plan->params.orientationThreshold, thetas, thetaCnt); break;
-        case 2: hipLaunchKernelGGL(k_thetas<2>, g, dim3(64), 0, s, st, cur, L, oc.pixelWidth, plan->params.orientationContribWidth, plan->params.orientationThreshold, thetas, thetaCnt); break;
-        case 3: hipLaunchKernelGGL(k_thetas<3>, g, dim3(64), 0, s, st, cur, L, oc.pixelWidth, plan->params.orientationContribWidth, plan->params.orientationThreshold, thetas, thetaCnt); break;
-        default: hipLaunchKernelGGL(k_thetas<4>, g, dim3(64), 0, s, st, cur, L, oc.pixelWidth, plan->params.orientationContribWidth, plan->params.orientationThreshold, thetas, thetaCnt); break;
+    curBuf[o] = cur;
+    othBuf[o] = oth;
+    if (as && o == svp::kOctaves - 1) {  // `chain` is in order: its last event joins octaves 1-3
+      SSRLCV_HIP_TRY(hipEventRecord(as->join[o], s));
+      SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->join[o], 0));
+    }
+  }
+  if (as) {  // the polar stream joins too (its tables are read by the sampling kernels below)
+    SSRLCV_HIP_TRY(hipEventRecord(as->join[svp::kOctaves], as->table));
+    SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->join[svp::kOctaves], 0));
+  }
+  // per-octave arguments of the two combined sampling launches
+  OctaveSet set;
+  uint32_t unitBlocks = 20;  // upper bound of the orientation kernel's grid: one block per 64 key points of a range
+  for (int o = 0; o < svp::kOctaves; ++o) {
+    const svp::OctavePlan& oc = plan->oct[o];
+    set.L[o] = make_levels(plan, ws, o);
+    set.kps[o] = curBuf[o];
+    set.pixelWidth[o] = oc.pixelWidth;
+    set.thetas[o] = (float*)(ws + oc.off_theta);
+    set.thetaCnt[o] = (uint32_t*)(ws + oc.off_thetaCnt);
+    set.consts[o] = ws + oc.off_descConst;
+    unitBlocks += (oc.cap + 63) / 64;
+  }
+  // the two range tables live in the bookkeeping slots of octaves 1 and 2 (octave 0's holds the feature offsets)
+  RangeTable* thetaRanges = (RangeTable*)(ws + plan->oct[1].off_featBase);
+  RangeTable* descRanges = (RangeTable*)(ws + plan->oct[2].off_featBase);
+  if (stop >= 6) {  // computeKeyPointOrientations (src/FeatureFactory.cu:540-632), all octaves in one launch
+    if (!as) {
+      for (int o = 0; o < svp::kOctaves; ++o) {
+        const svp::OctavePlan& oc = plan->oct[o];
+        hipLaunchKernelGGL(k_polar, dim3((oc.w + 255) / 256, (oc.h + kPolRows - 1) / kPolRows, 3), dim3(256), 0, caller,
+                           set.L[o], (float2*)(ws + oc.off_polar));
       }
+    }
+    hipLaunchKernelGGL(k_build_ranges, dim3(1), dim3(1), 0, caller, states, thetaRanges, 6);
+    const float lambdaO = plan->params.orientationContribWidth, othr = plan->params.orientationThreshold;
+    switch (maxO) {
+      case 1: hipLaunchKernelGGL(k_thetas<1>, dim3(unitBlocks), dim3(64), 0, caller, states, thetaRanges, set, lambdaO, othr); break;
+      case 2: hipLaunchKernelGGL(k_thetas<2>, dim3(unitBlocks), dim3(64), 0, caller, states, thetaRanges, set, lambdaO, othr); break;
+      case 3: hipLaunchKernelGGL(k_thetas<3>, dim3(unitBlocks), dim3(64), 0, caller, states, thetaRanges, set, lambdaO, othr); break;
+      default: hipLaunchKernelGGL(k_thetas<4>, dim3(unitBlocks), dim3(64), 0, caller, states, thetaRanges, set, lambdaO, othr); break;
+    }
+    for (int o = 0; o < svp::kOctaves; ++o) {
       // thrust::remove of the -FLT_MAX / -1 slots + expandKeyPoints (:594-611): element space n x maxOrientations
-      const OctaveState* cst = st;
-      const ssrlcv_sskeypoint* src = cur;
-      ssrlcv_sskeypoint* dst = oth;
+      const svp::OctavePlan& oc = plan->oct[o];
+      const uint32_t cap = oc.cap;
+      const OctaveState* cst = states + o;
+      const ssrlcv_sskeypoint* src = curBuf[o];
+      ssrlcv_sskeypoint* dst = othBuf[o];
+      const float* thetas = set.thetas[o];
+      const uint32_t* thetaCnt = set.thetaCnt[o];
       auto keyfn = [=] __device__(uint32_t e2) -> uint32_t {
         uint32_t i = e2 / maxO, j = e2 - i * maxO;
         if (!cst->hasExtrema || (int)i >= cst->n) return 0u;
@@ -1141,37 +1246,33 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
         dst[d] = kp;
       };
       uint32_t* totals = nullptr;
-      if ((e = svc::partition<svp::kDog, 8>(cap * maxO, keyfn, emit, words, &totals, s)) != hipSuccess) return (int)e;
-      hipLaunchKernelGGL(k_book_orient, dim3(1), dim3(1), 0, s, st, totals, cap);
-      swap();
-    }
-    if (cur != A) return SSRLCV_ERR_INVALID_ARG;  // cannot happen: nswaps accounts for every swap above
-    if (as && o == svp::kOctaves - 1) {  // `chain` is in order: its last event joins octaves 1-3
-      SSRLCV_HIP_TRY(hipEventRecord(as->join[o], s));
-      SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->join[o], 0));
+      hipError_t e = svc::partition<svp::kDog, 8>(cap * maxO, keyfn, emit, (uint32_t*)(ws + oc.off_part), &totals, caller);
+      if (e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL(k_book_orient, dim3(1), dim3(1), 0, caller, states + o, totals, cap);
+      ssrlcv_sskeypoint* tmp = curBuf[o];
+      curBuf[o] = othBuf[o];
+      othBuf[o] = tmp;
     }
   }
-  if (as) {  // the polar stream joins too (its tables are read by the descriptor kernels below even when stop < 6 ran none)
-    SSRLCV_HIP_TRY(hipEventRecord(as->join[svp::kOctaves], as->table));
-    SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->join[svp::kOctaves], 0));
-  }
+  for (int o = 0; o < svp::kOctaves; ++o)
+    if (curBuf[o] != (ssrlcv_sskeypoint*)(ws + plan->oct[o].off_kpA)) return SSRLCV_ERR_INVALID_ARG;  // cannot happen: nswaps accounts for every swap
   uint32_t* featBase = (uint32_t*)(ws + plan->oct[0].off_featBase);
   hipLaunchKernelGGL(k_book_featbase, dim3(1), dim3(1), 0, caller, states, featBase, numFeatures, plan->maxFeatures);
   if (stop >= 7) {
     if (!features) return SSRLCV_ERR_INVALID_ARG;
-    // back to back on the caller's stream: run side by side the four persistent grids only took wave slots from each
-    // other (measured 11.0 ms instead of 9.5 ms for a 4096^2 image)
+    uint32_t descBlocks = 0;
     for (int o = 0; o < svp::kOctaves; ++o) {
       const svp::OctavePlan& oc = plan->oct[o];
-      LevelSet L = make_levels(plan, ws, o);
-      DescConst* consts = (DescConst*)(ws + oc.off_descConst);
+      set.kps[o] = curBuf[o];
       hipLaunchKernelGGL(k_desc_consts, dim3(list_blocks(oc.cap)), dim3(256), 0, caller, states + o,
-                         (const ssrlcv_sskeypoint*)(ws + oc.off_kpA), oc.pixelWidth, plan->params.descriptorContribWidth,
-                         consts);
-      hipLaunchKernelGGL(k_descriptors, dim3(list_blocks(oc.cap) * kWaveKernelOversubscription), dim3(256), 0, caller, states + o,
-                         (const ssrlcv_sskeypoint*)(ws + oc.off_kpA), L, oc.pixelWidth, (const DescConst*)consts, featBase, o,
-                         features, plan->maxFeatures);
+                         (const ssrlcv_sskeypoint*)curBuf[o], oc.pixelWidth, plan->params.descriptorContribWidth,
+                         (DescConst*)(ws + oc.off_descConst));
+      descBlocks += list_blocks(oc.cap);
     }
+    // one launch over every octave's key points, largest windows first (see RangeTable)
+    hipLaunchKernelGGL(k_build_ranges, dim3(1), dim3(1), 0, caller, states, descRanges, 0);
+    hipLaunchKernelGGL(k_descriptors, dim3(descBlocks * kWaveKernelOversubscription), dim3(256), 0, caller, descRanges, set,
+                       featBase, features, plan->maxFeatures);
   }
   SSRLCV_LAUNCH_CHECK();
   return SSRLCV_OK;

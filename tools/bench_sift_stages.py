@@ -33,9 +33,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--stages", default="1,2,3,4,5,6,7")
+    ap.add_argument("--scene", action="store_true", help="a tools/scene.py view (realistic feature density) instead of the dense noise image")
     args = ap.parse_args()
     S = args.size
-    img = bench.synth_images(1, S, S, seed=0, device="cuda")[0]
+    if args.scene:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import scene
+        img = scene.pinhole_views(1, S)[0][0]
+    else:
+        img = bench.synth_images(1, S, S, seed=0, device="cuda")[0]
     plan = capi.SiftPlan(S, S)
     print("build_dog  %.3f ms" % timeit(lambda: plan.build_dog(img)))
     prev = 0.0
