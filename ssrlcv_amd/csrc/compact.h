@@ -26,12 +26,28 @@ __host__ __device__ inline uint32_t num_chunks(uint32_t n, int perThread) {
 }
 
 // counts layout: counts[key * numWaves + wave], wave = block * 4 + wave-in-block; numRuns = numBlocks * 4
+// `live` (nullable): device word holding the number of leading elements that can carry a key at all (elements past
+// *live x liveScale all have mask 0, the caller guarantees it).  The key-point lists are allocated for a capacity that is
+// 5..20 times their usual length; with it the passes touch only the runs below that bound -- the single-block scan was
+// walking 40 960 table entries for a list that fills 2 000 of them.
+__device__ __forceinline__ uint32_t live_elements(const int* live, uint32_t liveScale, uint32_t n) {
+  if (!live) return n;
+  const int v = *live;
+  const unsigned long long e = (unsigned long long)(v > 0 ? v : 0) * liveScale;
+  return e < n ? (uint32_t)e : n;
+}
+
 template <int NKEYS, int PER_THREAD, typename MaskFn>
 __global__ __launch_bounds__(kThreads) void k_count(uint32_t n, uint32_t numRuns, MaskFn maskfn,
-                                                    uint32_t* __restrict__ counts) {
+                                                    uint32_t* __restrict__ counts, const int* live, uint32_t liveScale) {
   const unsigned lane = threadIdx.x & 63;
   const uint32_t run = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const uint32_t base = run * (64u * PER_THREAD);
+  if (base >= live_elements(live, liveScale, n)) {  // wave-uniform
+    // with a live bound the scan does not read this run's counts; without one it reads every run of the table
+    if (!live && lane < NKEYS) counts[lane * numRuns + run] = 0;
+    return;
+  }
   uint32_t cnt[NKEYS];
 #pragma unroll
   for (int k = 0; k < NKEYS; ++k) cnt[k] = 0;
@@ -56,18 +72,37 @@ __global__ __launch_bounds__(kThreads) void k_count(uint32_t n, uint32_t numRuns
 // short chains of octaves 1-3 waited up to 0.96 ms for that beside the oversubscribed orientation kernel of octave 0.
 template <int NKEYS, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_scan(uint32_t numBlocks, uint32_t* __restrict__ counts,
-                                                  uint32_t* __restrict__ totals) {
+                                                  uint32_t* __restrict__ totals, uint32_t liveRunsOr0, const int* live,
+                                                  uint32_t liveScale, uint32_t runLen, uint32_t n) {
   __shared__ uint32_t s_wave[THREADS / 64];
   __shared__ uint32_t s_carry;
   __shared__ uint32_t s_keystart[NKEYS + 1];
-  const uint32_t total_entries = NKEYS * numBlocks;
+  // runs that were counted: all of them, or those below the live bound
+  uint32_t lr = numBlocks;
+  if (live) {
+    const uint32_t le = live_elements(live, liveScale, n);
+    lr = (le + runLen - 1) / runLen;
+    if (lr > numBlocks) lr = numBlocks;
+  }
+  (void)liveRunsOr0;
+  if (lr == 0) {
+    if (threadIdx.x <= NKEYS) totals[threadIdx.x] = 0;
+    return;
+  }
+  const uint32_t total_entries = NKEYS * lr;
   if (threadIdx.x == 0) s_carry = 0;
   __syncthreads();
   for (uint32_t start = 0; start < total_entries; start += THREADS * 4) {
     uint32_t i0 = start + threadIdx.x * 4;
-    uint32_t v[4];
+    uint32_t v[4], addr[4], runOf[4], keyOf[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = (i0 + j < total_entries) ? counts[i0 + j] : 0;
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t i = i0 + j;
+      keyOf[j] = i / lr;
+      runOf[j] = i - keyOf[j] * lr;
+      addr[j] = keyOf[j] * numBlocks + runOf[j];
+      v[j] = (i < total_entries) ? counts[addr[j]] : 0;
+    }
     uint32_t tsum = v[0] + v[1] + v[2] + v[3];
     uint32_t x = tsum;  // inclusive scan of per-thread sums inside the wave
 #pragma unroll
@@ -84,8 +119,8 @@ __global__ __launch_bounds__(THREADS) void k_scan(uint32_t numBlocks, uint32_t* 
     for (int j = 0; j < 4; ++j) {
       uint32_t i = i0 + j;
       if (i < total_entries) {
-        counts[i] = excl;
-        if (i % numBlocks == 0) s_keystart[i / numBlocks] = excl;
+        counts[addr[j]] = excl;
+        if (runOf[j] == 0) s_keystart[keyOf[j]] = excl;
       }
       excl += v[j];
     }
@@ -102,10 +137,11 @@ __global__ __launch_bounds__(THREADS) void k_scan(uint32_t numBlocks, uint32_t* 
 // emit(i, key, dst): writes input element i (as a member of `key`) to output slot dst.
 template <int NKEYS, int PER_THREAD, typename MaskFn, typename EmitFn>
 __global__ __launch_bounds__(kThreads) void k_scatter(uint32_t n, uint32_t numRuns, MaskFn maskfn, EmitFn emit,
-                                                      const uint32_t* __restrict__ offsets) {
+                                                      const uint32_t* __restrict__ offsets, const int* live, uint32_t liveScale) {
   const unsigned lane = threadIdx.x & 63;
   const uint32_t run = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const uint32_t base = run * (64u * PER_THREAD);
+  if (base >= live_elements(live, liveScale, n)) return;  // wave-uniform
   const unsigned long long below = (1ull << lane) - 1ull;
   uint32_t off[NKEYS];  // running output offset per key of this wave's run (wave-uniform)
 #pragma unroll
@@ -134,18 +170,24 @@ inline size_t workspace_words(uint32_t n) {
 // Launches the three passes over elements [0, n).  *totals_out = device pointer to NKEYS + 1 words in the workspace.
 template <int NKEYS, int PER_THREAD, typename MaskFn, typename EmitFn>
 inline hipError_t partition(uint32_t n, MaskFn maskfn, EmitFn emit, uint32_t* workspace, uint32_t** totals_out,
-                            hipStream_t stream) {
+                            hipStream_t stream, const int* live = nullptr, uint32_t liveScale = 1) {
   uint32_t nb = num_chunks(n, PER_THREAD);
   uint32_t runs = nb * kWavesPerBlock;
   uint32_t* counts = workspace;
   uint32_t* totals = workspace + (size_t)NKEYS * runs;
   if (totals_out) *totals_out = totals;
   if (nb == 0) return hipMemsetAsync(totals, 0, sizeof(uint32_t) * (NKEYS + 1), stream);
-  hipLaunchKernelGGL((k_count<NKEYS, PER_THREAD, MaskFn>), dim3(nb), dim3(kThreads), 0, stream, n, runs, maskfn, counts);
-  if ((size_t)NKEYS * runs > 16384) hipLaunchKernelGGL((k_scan<NKEYS, 1024>), dim3(1), dim3(1024), 0, stream, runs, counts, totals);
-  else hipLaunchKernelGGL((k_scan<NKEYS, 256>), dim3(1), dim3(256), 0, stream, runs, counts, totals);
+  const uint32_t runLen = 64u * PER_THREAD;
+  hipLaunchKernelGGL((k_count<NKEYS, PER_THREAD, MaskFn>), dim3(nb), dim3(kThreads), 0, stream, n, runs, maskfn, counts, live,
+                     liveScale);
+  // a list partition with a live bound scans a short table: the 256-thread block is enough (and does not wait for 16
+  // free wave slots on one CU)
+  if (!live && (size_t)NKEYS * runs > 16384)
+    hipLaunchKernelGGL((k_scan<NKEYS, 1024>), dim3(1), dim3(1024), 0, stream, runs, counts, totals, 0u, live, liveScale, runLen, n);
+  else
+    hipLaunchKernelGGL((k_scan<NKEYS, 256>), dim3(1), dim3(256), 0, stream, runs, counts, totals, 0u, live, liveScale, runLen, n);
   hipLaunchKernelGGL((k_scatter<NKEYS, PER_THREAD, MaskFn, EmitFn>), dim3(nb), dim3(kThreads), 0, stream, n, runs,
-                     maskfn, emit, counts);
+                     maskfn, emit, counts, live, liveScale);
   return hipGetLastError();
 }
 
@@ -250,8 +292,10 @@ inline hipError_t partition_flags(uint32_t n, const uint8_t* flags, EmitFn emit,
   if (totals_out) *totals_out = totals;
   if (nb == 0) return hipMemsetAsync(totals, 0, sizeof(uint32_t) * (NKEYS + 1), stream);
   hipLaunchKernelGGL((k_count_flags<NKEYS>), dim3(nb), dim3(kThreads), 0, stream, n, runs, flags, counts);
-  if ((size_t)NKEYS * runs > 16384) hipLaunchKernelGGL((k_scan<NKEYS, 1024>), dim3(1), dim3(1024), 0, stream, runs, counts, totals);
-  else hipLaunchKernelGGL((k_scan<NKEYS, 256>), dim3(1), dim3(256), 0, stream, runs, counts, totals);
+  if ((size_t)NKEYS * runs > 16384)
+    hipLaunchKernelGGL((k_scan<NKEYS, 1024>), dim3(1), dim3(1024), 0, stream, runs, counts, totals, 0u, (const int*)nullptr, 1u, (uint32_t)kFlagRun, n);
+  else
+    hipLaunchKernelGGL((k_scan<NKEYS, 256>), dim3(1), dim3(256), 0, stream, runs, counts, totals, 0u, (const int*)nullptr, 1u, (uint32_t)kFlagRun, n);
   hipLaunchKernelGGL((k_scatter_flags<NKEYS, EmitFn>), dim3(nb), dim3(kThreads), 0, stream, n, runs, flags, emit, counts);
   return hipGetLastError();
 }

@@ -1010,7 +1010,7 @@ hipError_t run_discard(OctaveState* st, const ssrlcv_sskeypoint* src, ssrlcv_ssk
   };
   auto emit = [=] __device__(uint32_t i, int, uint32_t d) { dst[d] = src[i]; };
   uint32_t* totals = nullptr;
-  hipError_t e = svc::partition<svp::kDog, 8>(cap, keyfn, emit, words, &totals, stream);
+  hipError_t e = svc::partition<svp::kDog, 8>(cap, keyfn, emit, words, &totals, stream, &st->n);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_book_discard, dim3(1), dim3(1), 0, stream, st, totals);
   return hipGetLastError();
@@ -1158,7 +1158,7 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
         };
         auto emit = [=] __device__(uint32_t i, int, uint32_t d) { dst[d] = src[i]; };
         uint32_t* totals = nullptr;
-        if ((e = svc::partition<svp::kDog, 8>(cap, keyfn, emit, words, &totals, s)) != hipSuccess) return (int)e;
+        if ((e = svc::partition<svp::kDog, 8>(cap, keyfn, emit, words, &totals, s, &st->n)) != hipSuccess) return (int)e;
         hipLaunchKernelGGL(k_book_rescan, dim3(1), dim3(1), 0, s, st, totals);
         swap();
       }
@@ -1246,7 +1246,8 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
         dst[d] = kp;
       };
       uint32_t* totals = nullptr;
-      hipError_t e = svc::partition<svp::kDog, 8>(cap * maxO, keyfn, emit, (uint32_t*)(ws + oc.off_part), &totals, caller);
+      hipError_t e = svc::partition<svp::kDog, 8>(cap * maxO, keyfn, emit, (uint32_t*)(ws + oc.off_part), &totals, caller,
+                                                  &states[o].n, maxO);
       if (e != hipSuccess) return (int)e;
       hipLaunchKernelGGL(k_book_orient, dim3(1), dim3(1), 0, caller, states + o, totals, cap);
       ssrlcv_sskeypoint* tmp = curBuf[o];

@@ -4,8 +4,11 @@
 #pragma once
 #include <cstddef>
 #include <cstdlib>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <type_traits>
+#include <vector>
 #include "Logger.hpp"
 #include "ssrlcv_hip.h"
 
@@ -24,8 +27,86 @@ inline void __hipSafeCall(int status, const char* file, const int line) {
 #define CudaSafeCall(err) HipSafeCall(err)
 #define CudaCheckError() HipCheckError()
 
-template <typename T> struct device_delete { void operator()(T* p) const { HipSafeCall(ssrlcv_hip_free(p)); } };
-template <typename T> struct host_pinned_delete { void operator()(T* p) const { HipSafeCall(ssrlcv_hip_host_free(p)); } };
+// Size-class cache of device and pinned-host blocks.  The reference's Unity<T> allocates and frees on every memory-state
+// change (setMemoryState is "hard": it frees the side it leaves), which its factories do around every call -- image
+// up, image back to its origin state, exact-size result lists.  cudaMalloc / cudaMallocHost of 16..50 MB cost
+// 0.1..3 ms each (pinning pages is the slow one): 3.9 of the 10.2 ms a generateFeatures call took on a 4096^2 image
+// whose pixels start on the host.  Freed blocks are kept per size class (multiples of 256 B up to 1 MiB, of 1 MiB
+// above) up to a byte budget and handed out again; contents are never assumed.  SSRLCV_NO_BLOCK_CACHE=1 turns it off.
+namespace detail {
+class BlockCache {
+  std::mutex mtx;
+  std::map<size_t, std::vector<void*>> freeList[2];  // [0] device, [1] pinned host
+  size_t cached[2] = {0, 0};
+  const size_t budget[2] = {(size_t)24 << 30, (size_t)2 << 30};
+  bool enabled;
+
+ public:
+  BlockCache() : enabled(std::getenv("SSRLCV_NO_BLOCK_CACHE") == nullptr) {}
+  ~BlockCache() {  // process exit: the runtime may already be gone, so return codes are not checked
+    for (int k = 0; k < 2; ++k)
+      for (auto& e : freeList[k])
+        for (void* p : e.second) (void)(k == 0 ? ssrlcv_hip_free(p) : ssrlcv_hip_host_free(p));
+  }
+  static size_t classOf(size_t bytes) {
+    const size_t g = bytes <= ((size_t)1 << 20) ? 256 : ((size_t)1 << 20);
+    return (bytes + g - 1) / g * g;
+  }
+  void* take(int kind, size_t bytes, size_t& cls) {
+    cls = classOf(bytes ? bytes : 1);
+    if (enabled) {
+      std::lock_guard<std::mutex> lock(mtx);
+      auto it = freeList[kind].find(cls);
+      if (it != freeList[kind].end() && !it->second.empty()) {
+        void* p = it->second.back();
+        it->second.pop_back();
+        cached[kind] -= cls;
+        return p;
+      }
+    }
+    void* p = nullptr;
+    int rc = kind == 0 ? ssrlcv_hip_malloc(&p, cls) : ssrlcv_hip_host_malloc(&p, cls);
+    if (rc != 0 && enabled) {  // out of memory with blocks parked in the cache: release them and try once more
+      trim(kind);
+      rc = kind == 0 ? ssrlcv_hip_malloc(&p, cls) : ssrlcv_hip_host_malloc(&p, cls);
+    }
+    __hipSafeCall(rc, __FILE__, __LINE__);
+    return p;
+  }
+  void give(int kind, void* p, size_t cls) {
+    if (!p) return;
+    if (enabled) {
+      std::lock_guard<std::mutex> lock(mtx);
+      if (cached[kind] + cls <= budget[kind]) {
+        freeList[kind][cls].push_back(p);
+        cached[kind] += cls;
+        return;
+      }
+    }
+    __hipSafeCall(kind == 0 ? ssrlcv_hip_free(p) : ssrlcv_hip_host_free(p), __FILE__, __LINE__);
+  }
+  void trim(int kind) {
+    std::lock_guard<std::mutex> lock(mtx);
+    for (auto& e : freeList[kind])
+      for (void* p : e.second) (void)(kind == 0 ? ssrlcv_hip_free(p) : ssrlcv_hip_host_free(p));
+    freeList[kind].clear();
+    cached[kind] = 0;
+  }
+};
+inline BlockCache& blockCache() {
+  static BlockCache c;
+  return c;
+}
+}  // namespace detail
+
+template <typename T> struct device_delete {
+  size_t cls;
+  void operator()(T* p) const { detail::blockCache().give(0, p, cls); }
+};
+template <typename T> struct host_pinned_delete {
+  size_t cls;
+  void operator()(T* p) const { detail::blockCache().give(1, p, cls); }
+};
 template <typename T> struct host_unpinned_delete { void operator()(T* p) const { delete[] p; } };
 
 namespace ptr {
@@ -56,9 +137,9 @@ class device : public base<T> {
   using base<T>::ptr;
   using base<T>::set;
   void set(long n, bool = false) {
-    void* tmp = nullptr;
-    HipSafeCall(ssrlcv_hip_malloc(&tmp, (size_t)n * sizeof(T)));
-    ptr.reset((T*)tmp, device_delete<T>());
+    size_t cls = 0;
+    void* tmp = detail::blockCache().take(0, (size_t)n * sizeof(T), cls);
+    ptr.reset((T*)tmp, device_delete<T>{cls});
   }
   device(long n) { set(n); }
   device() {}
@@ -75,9 +156,9 @@ class host : public base<T> {
   using base<T>::set;
   void set(long n, bool pinned = false) {
     if (pinned) {
-      void* tmp = nullptr;
-      HipSafeCall(ssrlcv_hip_host_malloc(&tmp, (size_t)n * sizeof(T)));
-      ptr.reset((T*)tmp, host_pinned_delete<T>());
+      size_t cls = 0;
+      void* tmp = detail::blockCache().take(1, (size_t)n * sizeof(T), cls);
+      ptr.reset((T*)tmp, host_pinned_delete<T>{cls});
     } else {
       ptr.reset(new T[n], host_unpinned_delete<T>());
     }

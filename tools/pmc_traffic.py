@@ -1,7 +1,7 @@
 
 """HBM traffic per kernel from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected separately, as
 MI355X_MICROARCH.md prescribes): FETCH_SIZE is doubled (gfx950 tallies 128-B read requests at 64 B), both counters are
-in KiB.  usage: pmc_traffic.py <fetch_dir> <write_dir> <images> > profiles/rNN_pyramid_traffic.json"""
+in KiB.  usage: pmc_traffic.py <fetch_dir> <write_dir> <images> [commit] > profiles/rNN_pyramid_traffic.json"""
 import collections
 import csv
 import glob
@@ -46,7 +46,7 @@ def main():
         "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of tools/bench_sift_stages.py at 4096x4096; "
                   "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide streaming reads); KiB units; "
                   "per-kernel totals are over all %d profiled images" % images,
-        "images": images,
+        "images": images, "commit": sys.argv[4] if len(sys.argv) > 4 else None,
         "pyramid_stage_bytes_per_image": pf + pw, "fetch_bytes_corrected": pf, "write_bytes": pw,
         "per_kernel": per}, indent=1))
 
