@@ -455,7 +455,13 @@ struct MfmaCfg {
   static constexpr size_t ldsBytes = sizeof(float) * ((size_t)2 * kMT * SW + (size_t)RINGROWS * RSTR);
 };
 
-template <int R, int TW>
+// ROWS = true: every strip of the launch is full (W % TW == 0) and the rows are 16-byte aligned (W % 4 == 0, aligned
+// base): the horizontal-role waves then stage WHOLE ROWS -- wave w4 owns rows 4 w4 .. 4 w4 + 3 of the 16-row tile, the
+// row index is wave-uniform (mirrored in SGPRs), a lane loads one float4 of the strip's interior and one halo float --
+// 8 loads and 12 LDS writes per thread and step instead of the 23 + 23 of the element-wise staging below (whose
+// per-element mirror / address arithmetic was ~115 VALU instructions per step).  Same values land in the same LDS
+// slots, so the passes and their results are unchanged.
+template <int R, int TW, bool ROWS>
 __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma(ConvArgs a) {
   using C = MfmaCfg<R, TW>;
   constexpr int TPW = C::TPW;
@@ -493,11 +499,25 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma(ConvArgs a) {
   // ---- horizontal role: staging state.  Element e of this thread is float e*256 + htid of the [kMT][SW] tile; its
   // column never changes.  Coordinates are clamped/mirrored into the image, so every load is unconditional: padding
   // columns and the elements past the tile (dropped at the LDS store) re-read a valid pixel, their weight is 0.
-  int gxs[C::STG], rws[C::STG];
-  float pre[C::STG];
-  if (role == 0) {
+  constexpr int NSTG = ROWS ? 1 : C::STG;
+  int gxs[NSTG], rws[NSTG];
+  float pre[NSTG];
+  // row-wise staging state (ROWS): halo lane h < RP owns stage column h (image column x0 - RP + h), lanes RP ..
+  // NH - 1 the columns right of the strip; the overshoot columns past x0 + TW + R carry weight 0 and re-read a valid pixel
+  constexpr int NH = 2 * C::RP + (C::KP - C::K);
+  static_assert(NH <= 64, "one halo float per lane");
+  f32x4 preI[4];
+  float preHl[4];
+  const bool haloLane = lane < NH;
+  const int hcol = lane < C::RP ? lane : TW + lane;  // right halo starts at stage column RP + TW
+  int hgx = lane < C::RP ? x0 - C::RP + lane : x0 + TW + (lane - C::RP);
+  hgx = hgx > W - 1 + R ? W - 1 + R : hgx;
+  hgx = hgx < 0 ? -1 - hgx : hgx;
+  hgx = hgx > W - 1 ? 2 * W - 1 - hgx : hgx;
+  const bool interiorLane = 4 * lane < TW;
+  if (role == 0 && !ROWS) {
 #pragma unroll
-    for (int e = 0; e < C::STG; ++e) {
+    for (int e = 0; e < NSTG; ++e) {
       int idx = e * 256 + htid;
       idx = idx < C::TOT ? idx : C::TOT - 1;
       int r = idx / C::SW, c = idx - r * C::SW;
@@ -510,9 +530,23 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma(ConvArgs a) {
     }
   }
   auto fetch = [&](int s) {
+    if (ROWS) {
+      const int ybase = y0 - R + s * kMT + 4 * __builtin_amdgcn_readfirstlane(w4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        int y = ybase + k;  // wave-uniform
+        y = y > H - 1 + R ? H - 1 + R : y;
+        y = y < 0 ? -1 - y : y;
+        y = y > H - 1 ? 2 * H - 1 - y : y;
+        const float* row = a.in + (size_t)y * W;
+        if (interiorLane) preI[k] = *reinterpret_cast<const f32x4*>(row + x0 + 4 * lane);
+        if (haloLane) preHl[k] = row[hgx];
+      }
+      return;
+    }
     const int ybase = y0 - R + s * kMT;
 #pragma unroll
-    for (int e = 0; e < C::STG; ++e) {
+    for (int e = 0; e < NSTG; ++e) {
       int y = ybase + rws[e];
       y = y > H - 1 + R ? H - 1 + R : y;
       y = y < 0 ? -1 - y : y;
@@ -522,8 +556,21 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma(ConvArgs a) {
   };
   auto stage_write = [&](int buf) {
     float* s_in = s_mem + buf * kMT * C::SW;
+    if (ROWS) {
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int e = 0; e < C::STG; ++e)
+      for (int k = 0; k < 4; ++k) {
+        float* srow = s_in + (4 * w4 + k) * C::SW;  // SW is even and RP a multiple of 4: 8-byte aligned pairs
+        if (interiorLane) {
+          *reinterpret_cast<f32x2*>(srow + C::RP + 4 * lane) = f32x2{preI[k][0], preI[k][1]};
+          *reinterpret_cast<f32x2*>(srow + C::RP + 4 * lane + 2) = f32x2{preI[k][2], preI[k][3]};
+        }
+        if (haloLane) srow[hcol] = preHl[k];
+      }
+      return;
+    }
+#pragma unroll
+    for (int e = 0; e < NSTG; ++e)
       if ((e + 1) * 256 <= C::TOT || e * 256 + htid < C::TOT) s_in[e * 256 + htid] = pre[e];
   };
   float mn = FLT_MAX, mx = -FLT_MAX;
@@ -836,12 +883,14 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
   do {                                                                                                              \
     static int blocksPerCu = 0, cus = 0;                                                                            \
     if (!blocksPerCu) {                                                                                             \
-      SSRLCV_HIP_TRY(hipFuncSetAttribute((const void*)k_gauss_mfma<RR, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+      SSRLCV_HIP_TRY(hipFuncSetAttribute((const void*)k_gauss_mfma<RR, TW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         (int)MfmaCfg<RR, TW>::ldsBytes));                                          \
+      SSRLCV_HIP_TRY(hipFuncSetAttribute((const void*)k_gauss_mfma<RR, TW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                          (int)MfmaCfg<RR, TW>::ldsBytes));                                          \
       int dev = 0, occ = 0;                                                                                         \
       SSRLCV_HIP_TRY(hipGetDevice(&dev));                                                                           \
       SSRLCV_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));                      \
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_gauss_mfma<RR, TW>, kMfmaThreads,       \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_gauss_mfma<RR, TW, true>, kMfmaThreads,  \
                                                        MfmaCfg<RR, TW>::ldsBytes) != hipSuccess || occ < 1)         \
         occ = 1;                                                                                                    \
       blocksPerCu = occ;                                                                                            \
@@ -854,7 +903,10 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
     a.rowsPerBlock = rows;                                                                                          \
     grid = dim3(bxm, (h + rows - 1) / rows);                                                                        \
     const size_t ldsB = MfmaCfg<RR, TW>::ldsBytes;                                                                  \
-    hipLaunchKernelGGL((k_gauss_mfma<RR, TW>), grid, dim3(kMfmaThreads), ldsB, st, a);                              \
+    if (rowStaging && w % (TW) == 0)                                                                                \
+      hipLaunchKernelGGL((k_gauss_mfma<RR, TW, true>), grid, dim3(kMfmaThreads), ldsB, st, a);                      \
+    else                                                                                                            \
+      hipLaunchKernelGGL((k_gauss_mfma<RR, TW, false>), grid, dim3(kMfmaThreads), ldsB, st, a);                     \
   } while (0)
     // 128-column strips let two blocks (8 waves each) share a CU's 160 KB of LDS (R <= 23).  Alone on the chip they are
     // slower than the 256-column ones (more halo, two accumulation chains per wave instead of four: 0.632 / 0.834 / 0.801
@@ -862,6 +914,8 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
     // of the previous octave, whose resident blocks keep the big ones off the CUs: the narrow strips are used for the
     // smaller levels (build_dog 2.57 -> 2.48 ms per 4096^2 image).  SSRLCV_GAUSS_WIDE=1 / SSRLCV_GAUSS_NARROW=1 force one.
     static const bool forceWide = getenv("SSRLCV_GAUSS_WIDE") != nullptr, forceNarrow = getenv("SSRLCV_GAUSS_NARROW") != nullptr;
+    static const bool noRowStaging = getenv("SSRLCV_GAUSS_ELEMENTWISE") != nullptr;
+    const bool rowStaging = !noRowStaging && (w & 3) == 0 && (reinterpret_cast<size_t>(in) & 15) == 0;
     const bool wide = forceWide || (!forceNarrow && (size_t)w * h >= ((size_t)1 << 25));
     switch (RT) {
       case 6: if (wide) SSRLCV_LAUNCH_MFMA(6, 256); else SSRLCV_LAUNCH_MFMA(6, 128); break;
