@@ -180,6 +180,7 @@ struct ConvArgs {
   uint32_t w, h;
   uint32_t rowsPerBlock;
   uint32_t x0base;  // first column of the launch's first strip (k_gauss_fused on the partial last strip)
+  const uint8_t* u8;  // k_gauss_strip<R, true>: the u8 image (w/2 x h/2) whose 2x bilinear upsample is the input
   float wgt[33];  // taps are symmetric (w[k] == w[2R-k] bit for bit): only k = 0..R travel, in SGPRs
 };
 
@@ -304,7 +305,12 @@ __global__ __launch_bounds__(kTX) void k_gauss_fused(ConvArgs a) {
 // step.  Here a wave stages two whole rows per step: the row index is wave-uniform (mirrored in SGPRs), every lane loads
 // one float4 of the strip's interior and lanes 0 .. 2 RP - 1 one halo float each (columns mirrored once, outside the
 // loop); stores go to a uniform row base.  Passes and summation order are identical, so are the results.
-template <int R>
+// UPS = true: the input is the 2x bilinear upsample of a u8 image (S1 + S2), formed in the loader instead of being
+// written out by k_upsample2x_u8x4 and read back: level 0 of octave 0 is HBM bound (268 MB in + 268 MB out per 4096^2
+// image) and then reads 17 MB.  The value of an upsampled pixel is the exact integer form of upsample_at (see
+// k_upsample2x_u8x4): 0.25 * (p[ym][xm] + p[ym][xp'] + p[yp'][xm] + p[yp'][xp']), with the mirror of the convolution
+// applied to the upsampled coordinates first.
+template <int R, bool UPS>
 __global__ __launch_bounds__(kTX) void k_gauss_strip(ConvArgs a) {
   constexpr int RP = (R + 3) / 4 * 4;
   constexpr int SW = kTX + 2 * RP;
@@ -340,14 +346,38 @@ __global__ __launch_bounds__(kTX) void k_gauss_strip(ConvArgs a) {
   const int steps = (nrows + 2 * R + kNR - 1) / kNR;
   float4 preI0, preI1;  // next step's two rows of this wave (named scalars: an indexed pair went to scratch)
   float preH0 = 0.0f, preH1 = 0.0f;
-  auto row_of = [&](int y) {  // wave-uniform mirrored row
+  auto mirror_row = [&](int y) {  // wave-uniform
     y = y > H - 1 + R ? H - 1 + R : y;
     y = y < 0 ? -1 - y : y;
     y = y > H - 1 ? 2 * H - 1 - y : y;
-    return a.in + (size_t)y * W;
+    return y;
+  };
+  auto row_of = [&](int y) { return a.in + (size_t)mirror_row(y) * W; };
+  // UPS: one upsampled row Y of this lane's four columns and of its halo column, from u8 rows ym = Y >> 1 and yp'
+  const int uw = W >> 1, uh = H >> 1;
+  const int c0 = (x0 >> 1) + 2 * lane;                  // source column of outputs 4 lane, 4 lane + 1 (even: 2-byte aligned)
+  const int c2 = c0 + 2 < uw ? c0 + 2 : uw - 1;
+  const int hxm = hx >> 1, hxp = (hx & 1) ? (hxm + 1 < uw ? hxm + 1 : uw - 1) : hxm;
+  auto up_row = [&](int Y, float4& o, float& oh) {
+    Y = mirror_row(Y);
+    const int ym = Y >> 1, yp = (Y & 1) ? (ym + 1 < uh ? ym + 1 : uh - 1) : ym;
+    const uint8_t* r0 = a.u8 + (size_t)ym * uw;
+    const uint8_t* r1 = a.u8 + (size_t)yp * uw;
+    const uint32_t p0 = *reinterpret_cast<const uint16_t*>(r0 + c0), p1 = *reinterpret_cast<const uint16_t*>(r1 + c0);
+    const uint32_t a0 = (p0 & 255u) + (p1 & 255u), a1 = (p0 >> 8) + (p1 >> 8), a2 = (uint32_t)r0[c2] + (uint32_t)r1[c2];
+    o.x = (float)(2 * a0) * 0.25f;
+    o.y = (float)(a0 + a1) * 0.25f;
+    o.z = (float)(2 * a1) * 0.25f;
+    o.w = (float)(a1 + a2) * 0.25f;
+    if (halo) oh = (float)((uint32_t)r0[hxm] + (uint32_t)r0[hxp] + (uint32_t)r1[hxm] + (uint32_t)r1[hxp]) * 0.25f;
   };
   auto fetch = [&](int s) {
     const int ybase = y0 - R + s * kNR + 2 * wave;
+    if (UPS) {
+      up_row(ybase, preI0, preH0);
+      up_row(ybase + 1, preI1, preH1);
+      return;
+    }
     const float* r0 = row_of(ybase);
     const float* r1 = row_of(ybase + 1);
     preI0 = *reinterpret_cast<const float4*>(r0 + x0 + 4 * lane);
@@ -818,8 +848,14 @@ __global__ __launch_bounds__(256) void k_dog(DogArgs a) {
   }
 }
 
+// u8src (nullable): the convolution's input is the 2x upsample of this u8 image (w/2 x h/2) and `in` is not read; only
+// honoured where upsample_fusable() says so (row-staged VALU kernel on full, aligned strips)
+bool upsample_fusable(uint32_t w, uint32_t h, int taps) {
+  static const bool off = getenv("SSRLCV_NO_UPSAMPLE_FUSION") != nullptr || getenv("SSRLCV_GAUSS_MFMA") != nullptr;
+  return !off && taps / 2 <= 8 && w % kTX == 0 && (w & 3) == 0 && (h & 1) == 0;
+}
 int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h, int taps, const float* weights_host,
-                float* minmax, hipStream_t st) {
+                float* minmax, hipStream_t st, const uint8_t* u8src = nullptr) {
   if (taps < 1 || (taps & 1) == 0 || taps > svp::kMaxTaps) return SSRLCV_ERR_INVALID_ARG;
   int R = taps / 2;
   if (R > 32) return SSRLCV_ERR_UNSUPPORTED;  // the pipeline's sigma ladder never exceeds 65 taps
@@ -831,6 +867,8 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
   a.w = w;
   a.h = h;
   a.x0base = 0;
+  a.u8 = u8src;
+  if (u8src && !upsample_fusable(w, h, taps)) return SSRLCV_ERR_INVALID_ARG;
   memset(a.wgt, 0, sizeof a.wgt);
   // pad the tap set symmetrically into the smallest templated radius: extra taps carry weight 0 and would change
   // the fmaf chain (0*x + s is exact, so the result is identical) -- only exact radii are dispatched below anyway.
@@ -857,11 +895,12 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
   if (!useMfma) {
     // full strips with 16-byte aligned rows take the row-staged kernel, a partial last strip (or everything, when the
     // rows are not aligned) the generic one
-    const bool aligned = (w & 3) == 0 && (reinterpret_cast<size_t>(in) & 15) == 0;
+    const bool aligned = (w & 3) == 0 && (u8src || (reinterpret_cast<size_t>(in) & 15) == 0);
     const uint32_t nFull = aligned ? w / kTX : 0;
 #define SSRLCV_LAUNCH_VALU(RR)                                                                              \
   do {                                                                                                       \
-    if (nFull) hipLaunchKernelGGL(k_gauss_strip<RR>, dim3(nFull, grid.y), dim3(kTX), 0, st, a);              \
+    if (nFull && u8src) hipLaunchKernelGGL((k_gauss_strip<RR, true>), dim3(nFull, grid.y), dim3(kTX), 0, st, a); \
+    else if (nFull) hipLaunchKernelGGL((k_gauss_strip<RR, false>), dim3(nFull, grid.y), dim3(kTX), 0, st, a); \
     if (nFull < bx) {                                                                                        \
       a.x0base = nFull * kTX;                                                                                \
       hipLaunchKernelGGL(k_gauss_fused<RR>, dim3(bx - nFull, grid.y), dim3(kTX), 0, st, a);                  \
@@ -1247,6 +1286,7 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
   // S1+S2: u8 -> f32 + one 2x upsample (startingOctave = -1)
   float* in = (float*)(ws + plan->off_in0);
   int rc;
+  bool fuseUpsample = false;
   if (plan->padMode == 1) {  // S3 before S2: zero border around the u8 input ((float)0 == 0.0f: the order of S1 and S3 is free)
     const uint32_t pw = plan->W + 2 * plan->padX, ph = plan->H + 2 * plan->padY;
     uint8_t* padded = (uint8_t*)(ws + plan->off_pad);
@@ -1258,6 +1298,9 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
     rc = ssrlcv_hip_upsample2x_u8(pixels, plan->W, plan->H, up, stream);
     hipLaunchKernelGGL(k_add_border<float>, dim3((plan->oct[0].w + 255) / 256, plan->oct[0].h), dim3(256), 0, st, up,
                        2 * plan->W, 2 * plan->H, in, plan->padX, plan->padY);
+  } else if (upsample_fusable(plan->oct[0].w, plan->oct[0].h, plan->oct[0].taps[0])) {
+    rc = 0;  // S1 + S2 happen in the loader of octave 0's first level
+    fuseUpsample = true;
   } else {
     rc = ssrlcv_hip_upsample2x_u8(pixels, plan->W, plan->H, in, stream);
   }
@@ -1272,7 +1315,8 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
     const float* lv[svp::kGauss];
     for (int b = 0; b < svp::kGauss; ++b) {
       float* dst = (float*)(ws + offGauss[b]);
-      rc = launch_conv(src, dst, nullptr, oc.w, oc.h, oc.taps[b], oc.weights[b], mm + 2 * b, st);
+      rc = launch_conv(src, dst, nullptr, oc.w, oc.h, oc.taps[b], oc.weights[b], mm + 2 * b, st,
+                       (fuseUpsample && o == 0 && b == 0) ? pixels : nullptr);
       if (rc) return rc;
       lv[b] = dst;
       src = dst;
