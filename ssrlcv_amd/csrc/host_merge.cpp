@@ -65,7 +65,8 @@ int ssrlcv_merge_matches_host(uint32_t numImages, const uint32_t* numFeatures, u
   auto list_of = [&](uint32_t img, uint32_t feat) { return base[img] + feat; };
   std::vector<ssrlcv_multimatch> mm;
   std::vector<U2> mem;
-  std::vector<U2> inter;
+  mm.reserve(total / 2 + 16);
+  mem.reserve(total + total / 2 + 16);
   for (uint32_t i = 0; i + 1 < V; ++i) {
     for (uint32_t f = 0; i + 2 < V && f < numFeatures[i]; ++f) {  // only images 0..V-3 seed multi-matches (:969)
       const size_t a = list_of(i, f);
@@ -77,11 +78,22 @@ int ssrlcv_merge_matches_host(uint32_t numImages, const uint32_t* numFeatures, u
         if (head.x == V - 1) break;
         const size_t next = list_of(head.x, head.y);
         if (len[next] == 0) break;
-        inter.clear();
-        std::set_intersection(entries.begin() + start[prev], entries.begin() + start[prev] + len[prev],
-                              entries.begin() + start[next], entries.begin() + start[next] + len[next],
-                              std::back_inserter(inter));
-        if (inter.size() != len[next]) { badMatch = true; break; }
+        // |set_intersection(list[prev], list[next])| (:984-990) without materialising it: both lists are sorted by the
+        // same operator< (an image's list holds at most one entry per later image, appended in pair order), and
+        // std::set_intersection's merge is replayed literally
+        uint32_t common = 0;
+        {
+          const U2* p1 = &entries[start[prev]];
+          const U2* e1 = p1 + len[prev];
+          const U2* p2 = &entries[start[next]];
+          const U2* e2 = p2 + len[next];
+          while (p1 != e1 && p2 != e2) {
+            if (*p1 < *p2) ++p1;
+            else if (*p2 < *p1) ++p2;
+            else { ++common; ++p1; ++p2; }
+          }
+        }
+        if (common != len[next]) { badMatch = true; break; }
         else if (len[next] == 1) break;
         else prev = next;
       }

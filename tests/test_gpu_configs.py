@@ -92,6 +92,53 @@ def test_config3_four_view_4096_flow(capi):
     assert np.median(err) < 0.03 and np.percentile(err, 90) < 0.15
 
 
+def test_scene_pair_1024_hip_equals_oracle_end_to_end(capi, oracle_lib):
+    """A 1024^2 two-view scene of the benchmark's generator through both implementations: HIP features bit-equal to the
+    oracle's, therefore the same seed distances, the same double-constrained match list and the same cloud -- and that
+    cloud sits on the generator's ground truth."""
+    import scene
+    S = 1024
+    imgs, cams, rig, sc = scene.pinhole_views(2, S)
+    seed, _ = H.load_seed_features()
+    plans = [capi.SiftPlan(S, S) for _ in range(2)]
+    feats = []
+    for p, im in zip(plans, imgs):
+        p.extract(im)
+        feats.append(p.features_host(H.FEATURE))
+    ofeats = [H.oracle_sift(oracle_lib, im.cpu().numpy()) for im in imgs]
+    for g, o in zip(feats, ofeats):
+        assert len(g) > 20000
+        H.assert_features_equal(g, o)
+    n0, n1 = len(feats[0]), len(feats[1])
+    sd_d = capi.seed_distances(plans[0].features, n0, capi.to_dev(seed), len(seed))
+    osd = H.oracle_seed_distances(oracle_lib, ofeats[0], seed)
+    assert np.array_equal(sd_d.cpu().numpy()[:n0], osd)
+    params = capi.make_match_params(1, 0, 1, 25.0, 5.0, 0.6, 200.0 * 200.0, cams[0:1], capi.projection_matrix(cams[1:2]))
+    out_d = capi.match(plans[0].features, n0, plans[1].features, n1, params, capi.OUT_DMATCH, seed_d=sd_d)
+    n = capi.compact_matches(capi.OUT_DMATCH, out_d, n0, capi.match_workspace(n0, n1))
+    dm = capi.to_host(out_d, H.DMATCH, n)
+    proj = H.oracle_projection(oracle_lib, cams[1:2])
+    odm = H.oracle_match_dmatch(oracle_lib, 1, 0, ofeats[0], 1, ofeats[1], cams[0:1], proj, 25.0, 5.0, osd, 0.6, 200.0 * 200.0)
+    odm = odm[odm["invalid"] == 0]
+    assert n == len(odm) > 3000
+    for name in ("kp0_loc", "kp1_loc", "distance"):
+        assert np.array_equal(dm[name], odm[name]), name
+    mm = np.zeros(n, H.MULTIMATCH)
+    mm["numKeyPoints"], mm["index"] = 2, 2 * np.arange(n)
+    kp = np.zeros(2 * n, H.KEYPOINT)
+    kp["parentId"][1::2] = 1
+    kp["loc"][0::2], kp["loc"][1::2] = dm["kp0_loc"], dm["kp1_loc"]
+    b_d, l_d = capi.generate_bundles(capi.to_dev(mm), capi.to_dev(kp), n, capi.to_dev(cams), 2, len(kp))
+    pts = capi.triangulate(l_d, b_d, n)[0].cpu().numpy().reshape(-1, 3)
+    ob, ol, _ = H.oracle_bundles(oracle_lib, mm, kp, cams)
+    opts, _, _ = H.oracle_triangulate(oracle_lib, False, ob, ol)
+    assert np.array_equal(pts, opts)            # bit-equal clouds
+    err = _ground_truth_error(rig, sc, mm, kp, pts)
+    print("scene 1024^2 pair: %d features, %d matches, cloud vs ground truth: median %.4f km (GSD %.4f km)" %
+          (n0, n, np.median(err), rig.gsd))
+    assert np.median(err) < 3 * rig.gsd and np.percentile(err, 90) < 0.3
+
+
 def _gloo_worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
