@@ -181,6 +181,12 @@ struct ConvArgs {
   uint32_t rowsPerBlock;
   uint32_t x0base;  // first column of the launch's first strip (k_gauss_fused on the partial last strip)
   const uint8_t* u8;  // k_gauss_strip<R, true>: the u8 image (w/2 x h/2) whose 2x bilinear upsample is the input
+  // k_gauss_mfma<R, TW, true>: while it streams its input (gaussian level b+1) the loader also emits DoG level b =
+  // normalised(level b+1) - normalised(level b): both levels are complete, so their min / max are final
+  const float* dogPrev;       // level b (nullptr: no DoG emission)
+  float* dogOut;              // DoG level b
+  const float* dogLvlMinMax;  // {min_b, max_b, min_b+1, max_b+1}
+  float* dogMinMax;           // {min, max} of DoG level b (atomics)
   float wgt[33];  // taps are symmetric (w[k] == w[2R-k] bit for bit): only k = 0..R travel, in SGPRs
 };
 
@@ -545,6 +551,19 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma(ConvArgs a) {
   hgx = hgx < 0 ? -1 - hgx : hgx;
   hgx = hgx > W - 1 ? 2 * W - 1 - hgx : hgx;
   const bool interiorLane = 4 * lane < TW;
+  // DoG emission (ROWS only): the rows of this block's own output range pass through the loader exactly once
+  const bool emitDog = ROWS && a.dogOut != nullptr;
+  f32x4 prevI[4];
+  int emitRow[4] = {-1, -1, -1, -1};
+  float dmn = FLT_MAX, dmx = -FLT_MAX;
+  float lmn0 = 0.0f, lmn1 = 0.0f;
+  sv::Divisor rng0 = {1.0f, 1.0f}, rng1 = {1.0f, 1.0f};
+  if (emitDog && role == 0) {
+    lmn0 = a.dogLvlMinMax[0];
+    rng0 = sv::make_divisor(a.dogLvlMinMax[1] - lmn0);
+    lmn1 = a.dogLvlMinMax[2];
+    rng1 = sv::make_divisor(a.dogLvlMinMax[3] - lmn1);
+  }
   if (role == 0 && !ROWS) {
 #pragma unroll
     for (int e = 0; e < NSTG; ++e) {
@@ -571,6 +590,12 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma(ConvArgs a) {
         const float* row = a.in + (size_t)y * W;
         if (interiorLane) preI[k] = *reinterpret_cast<const f32x4*>(row + x0 + 4 * lane);
         if (haloLane) preHl[k] = row[hgx];
+        if (emitDog) {
+          const int yr = ybase + k;  // un-mirrored: a row of this block's own range is inside the image
+          emitRow[k] = (yr >= y0 && yr < y0 + nrows) ? yr : -1;
+          if (emitRow[k] >= 0 && interiorLane)
+            prevI[k] = *reinterpret_cast<const f32x4*>(a.dogPrev + (size_t)yr * W + x0 + 4 * lane);
+        }
       }
       return;
     }
@@ -596,6 +621,19 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma(ConvArgs a) {
           *reinterpret_cast<f32x2*>(srow + C::RP + 4 * lane + 2) = f32x2{preI[k][2], preI[k][3]};
         }
         if (haloLane) srow[hcol] = preHl[k];
+        if (emitDog && emitRow[k] >= 0 && interiorLane) {
+          // the arithmetic of k_dog: both levels normalised with the shared-reciprocal IEEE quotient, then subtracted
+          f32x4 d;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float cur = sv::div_by(preI[k][c] - lmn1, rng1);
+            const float prv = sv::div_by(prevI[k][c] - lmn0, rng0);
+            d[c] = cur - prv;
+            dmn = fminf(dmn, d[c]);
+            dmx = fmaxf(dmx, d[c]);
+          }
+          __builtin_nontemporal_store(d, reinterpret_cast<f32x4*>(a.dogOut + (size_t)emitRow[k] * W + x0 + 4 * lane));
+        }
       }
       return;
     }
@@ -734,6 +772,7 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma(ConvArgs a) {
   }
   if (role == 1 && pendJ != kNoPending) store_pending();
   if (a.minmax) block_minmax_commit(mn, mx, a.minmax, s_mem);
+  if (emitDog) block_minmax_commit(dmn, dmx, a.dogMinMax, s_mem);
 }
 
 // Generic two-pass fallback for tap counts the pipeline never produces (taps > 65): one 1-D pass per launch.
@@ -789,6 +828,9 @@ struct DogArgs {
   float* dogMinMax;        // 5 x {min,max}, nullable
   size_t n;
 };
+// FIRST: the first DoG level this launch produces (levels below it were emitted by the convolution loaders, see
+// k_gauss_mfma); their {min, max} slots receive the neutral FLT_MAX / -FLT_MAX from here
+template <int FIRST>
 __global__ __launch_bounds__(256) void k_dog(DogArgs a) {
   float lmn[svp::kGauss];
   sv::Divisor range[svp::kGauss];  // (v - min) / (max - min) as the IEEE quotient through a shared reciprocal (device_math.h)
@@ -803,14 +845,14 @@ __global__ __launch_bounds__(256) void k_dog(DogArgs a) {
   size_t stride = (size_t)gridDim.x * 256 * 4;
   for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < a.n; i += stride) {
     typedef float f32x4nt __attribute__((ext_vector_type(4)));
-    const f32x4nt p0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(a.lvl[0] + i));  // streamed once
+    const f32x4nt p0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(a.lvl[FIRST] + i));  // streamed once
     float4 prev = make_float4(p0.x, p0.y, p0.z, p0.w);
-    prev.x = sv::div_by(prev.x - lmn[0], range[0]);
-    prev.y = sv::div_by(prev.y - lmn[0], range[0]);
-    prev.z = sv::div_by(prev.z - lmn[0], range[0]);
-    prev.w = sv::div_by(prev.w - lmn[0], range[0]);
+    prev.x = sv::div_by(prev.x - lmn[FIRST], range[FIRST]);
+    prev.y = sv::div_by(prev.y - lmn[FIRST], range[FIRST]);
+    prev.z = sv::div_by(prev.z - lmn[FIRST], range[FIRST]);
+    prev.w = sv::div_by(prev.w - lmn[FIRST], range[FIRST]);
 #pragma unroll
-    for (int b = 0; b < svp::kDog; ++b) {
+    for (int b = FIRST; b < svp::kDog; ++b) {
       const f32x4nt c0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(a.lvl[b + 1] + i));
       float4 cur = make_float4(c0.x, c0.y, c0.z, c0.w);
       cur.x = sv::div_by(cur.x - lmn[b + 1], range[b + 1]);
@@ -854,8 +896,30 @@ bool upsample_fusable(uint32_t w, uint32_t h, int taps) {
   static const bool off = getenv("SSRLCV_NO_UPSAMPLE_FUSION") != nullptr || getenv("SSRLCV_GAUSS_MFMA") != nullptr;
   return !off && taps / 2 <= 8 && w % kTX == 0 && (w & 3) == 0 && (h & 1) == 0;
 }
+// DoG emission by a convolution's loader (k_gauss_mfma<.., true>): possible where that kernel runs on full, aligned strips
+struct DogFuse {
+  const float* prev;       // gaussian level b (the convolution's input is level b+1)
+  float* out;              // DoG level b
+  const float* lvlMinMax;  // {min_b, max_b, min_b+1, max_b+1}
+  float* dogMinMax;        // {min, max} of DoG level b
+};
+bool dog_fusable(const float* in, uint32_t w, uint32_t h, int taps) {
+  // Off by default: measured on MI355X (4096^2 image) the stage went from 2.36 to 2.58 ms with it -- the loader's
+  // 15 VALU instructions per pixel compete with the f32 MFMAs for the same issue slots (they do not overlap on this
+  // part) and the two extra streams push the convolutions towards the HBM bound, which costs more than the four DoG
+  // levels the streaming kernel no longer has to produce (0.71 -> 0.19 ms).  SSRLCV_DOG_FUSION=1 enables it (same results).
+  static const bool on = getenv("SSRLCV_DOG_FUSION") != nullptr && getenv("SSRLCV_GAUSS_VALU") == nullptr &&
+                         getenv("SSRLCV_GAUSS_ELEMENTWISE") == nullptr;
+  if (!on) return false;
+  const int R = taps / 2;
+  if (R < 9 || R > 32) return false;  // the MFMA formulation serves R >= 11 (templated radii 11, 16, 23, 32)
+  static const bool forceWide = getenv("SSRLCV_GAUSS_WIDE") != nullptr, forceNarrow = getenv("SSRLCV_GAUSS_NARROW") != nullptr;
+  const bool wide = R > 23 || forceWide || (!forceNarrow && (size_t)w * h >= ((size_t)1 << 25));
+  const uint32_t tw = wide ? 256 : 128;
+  return (w & 3) == 0 && (reinterpret_cast<size_t>(in) & 15) == 0 && w % tw == 0;
+}
 int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h, int taps, const float* weights_host,
-                float* minmax, hipStream_t st, const uint8_t* u8src = nullptr) {
+                float* minmax, hipStream_t st, const uint8_t* u8src = nullptr, const DogFuse* dog = nullptr) {
   if (taps < 1 || (taps & 1) == 0 || taps > svp::kMaxTaps) return SSRLCV_ERR_INVALID_ARG;
   int R = taps / 2;
   if (R > 32) return SSRLCV_ERR_UNSUPPORTED;  // the pipeline's sigma ladder never exceeds 65 taps
@@ -869,6 +933,17 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
   a.x0base = 0;
   a.u8 = u8src;
   if (u8src && !upsample_fusable(w, h, taps)) return SSRLCV_ERR_INVALID_ARG;
+  a.dogPrev = nullptr;
+  a.dogOut = nullptr;
+  a.dogLvlMinMax = nullptr;
+  a.dogMinMax = nullptr;
+  if (dog) {
+    if (!dog_fusable(in, w, h, taps)) return SSRLCV_ERR_INVALID_ARG;
+    a.dogPrev = dog->prev;
+    a.dogOut = dog->out;
+    a.dogLvlMinMax = dog->lvlMinMax;
+    a.dogMinMax = dog->dogMinMax;
+  }
   memset(a.wgt, 0, sizeof a.wgt);
   // pad the tap set symmetrically into the smallest templated radius: extra taps carry weight 0 and would change
   // the fmaf chain (0*x + s is exact, so the result is identical) -- only exact radii are dispatched below anyway.
@@ -1101,8 +1176,8 @@ int ssrlcv_hip_normalize(float* data, size_t n, const float* minmax, ssrlcv_stre
   return SSRLCV_OK;
 }
 
-int ssrlcv_hip_dog_normalised_sub(const float* const levels_host[6], const float* levelMinMax, uint32_t w, uint32_t h,
-                                  float* const dog_host[5], float* dogMinMax, ssrlcv_stream_t stream) {
+static int launch_dog(const float* const levels_host[6], const float* levelMinMax, uint32_t w, uint32_t h,
+                      float* const dog_host[5], float* dogMinMax, int firstDog, ssrlcv_stream_t stream) {
   if (!levels_host || !levelMinMax || !dog_host || !w || !h) return SSRLCV_ERR_INVALID_ARG;
   size_t n = (size_t)w * h;
   if (n % 4) return SSRLCV_ERR_INVALID_ARG;
@@ -1114,9 +1189,19 @@ int ssrlcv_hip_dog_normalised_sub(const float* const levels_host[6], const float
   a.n = n;
   size_t blocks = (n / 4 + 255) / 256;
   if (blocks > 1024) blocks = 1024;  // 4 blocks per CU; each block ends with 10 same-address atomics
-  hipLaunchKernelGGL(k_dog, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  switch (firstDog) {
+    case 4: hipLaunchKernelGGL(k_dog<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a); break;
+    case 3: hipLaunchKernelGGL(k_dog<3>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a); break;
+    case 2: hipLaunchKernelGGL(k_dog<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a); break;
+    case 1: hipLaunchKernelGGL(k_dog<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a); break;
+    default: hipLaunchKernelGGL(k_dog<0>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a); break;
+  }
   SSRLCV_LAUNCH_CHECK();
   return SSRLCV_OK;
+}
+int ssrlcv_hip_dog_normalised_sub(const float* const levels_host[6], const float* levelMinMax, uint32_t w, uint32_t h,
+                                  float* const dog_host[5], float* dogMinMax, ssrlcv_stream_t stream) {
+  return launch_dog(levels_host, levelMinMax, w, h, dog_host, dogMinMax, 0, stream);
 }
 
 // ---- plan ------------------------------------------------------------------------------------------------------------
@@ -1313,10 +1398,25 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
     if (as && o >= 2) SSRLCV_HIP_TRY(hipStreamWaitEvent(st, as->dogDone[o - 2], 0));  // buffer set free again
     const float* src = in;
     const float* lv[svp::kGauss];
+    float* dogs[svp::kDog];
+    for (int b = 0; b < svp::kDog; ++b) dogs[b] = (float*)(ws + oc.off_dog[b]);
+    // DoG level b - 2 rides in the loader of the convolution that produces level b (it streams level b - 1 anyway, and
+    // both of its operands are complete); whatever is left after level 5 goes to the streaming DoG kernel
+    int firstDog = 0;
     for (int b = 0; b < svp::kGauss; ++b) {
       float* dst = (float*)(ws + offGauss[b]);
+      DogFuse df;
+      const DogFuse* dfp = nullptr;
+      if (b >= 2 && firstDog == b - 2 && dog_fusable(src, oc.w, oc.h, oc.taps[b])) {
+        df.prev = lv[b - 2];
+        df.out = dogs[b - 2];
+        df.lvlMinMax = mm + 2 * (b - 2);
+        df.dogMinMax = mm + 2 * svp::kGauss + 2 * (b - 2);
+        dfp = &df;
+        firstDog = b - 1;
+      }
       rc = launch_conv(src, dst, nullptr, oc.w, oc.h, oc.taps[b], oc.weights[b], mm + 2 * b, st,
-                       (fuseUpsample && o == 0 && b == 0) ? pixels : nullptr);
+                       (fuseUpsample && o == 0 && b == 0) ? pixels : nullptr, dfp);
       if (rc) return rc;
       lv[b] = dst;
       src = dst;
@@ -1331,9 +1431,7 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
       SSRLCV_HIP_TRY(hipEventRecord(as->convDone[o], st));
       SSRLCV_HIP_TRY(hipStreamWaitEvent(sd, as->convDone[o], 0));
     }
-    float* dogs[svp::kDog];
-    for (int b = 0; b < svp::kDog; ++b) dogs[b] = (float*)(ws + oc.off_dog[b]);
-    rc = ssrlcv_hip_dog_normalised_sub(lv, mm, oc.w, oc.h, dogs, mm + 2 * svp::kGauss, (ssrlcv_stream_t)sd);
+    rc = launch_dog(lv, mm, oc.w, oc.h, dogs, mm + 2 * svp::kGauss, firstDog, (ssrlcv_stream_t)sd);
     if (rc) return rc;
     if (as) SSRLCV_HIP_TRY(hipEventRecord(as->dogDone[o], sd));
   }
