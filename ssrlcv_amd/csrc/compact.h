@@ -37,6 +37,39 @@ __device__ __forceinline__ uint32_t live_elements(const int* live, uint32_t live
   return e < n ? (uint32_t)e : n;
 }
 
+// Bookkeeping that has to follow a partition (it rewrites the list's length / segment table, which the scatter's mask
+// functor still reads) used to be a one-thread kernel of its own after every partition: ~6 us each, five per octave
+// chain, all on the critical path of the short octaves.  It now runs in the LAST block of the scatter kernel to finish
+// (a block counter next to the totals, zeroed by the scan): every other block has then evaluated its masks.
+struct NoPost {
+  __device__ void operator()(const uint32_t*) const {}
+};
+// Only the `participants` leading blocks count themselves (same-address atomics serialise at ~50 ns each: all 2 048
+// blocks of a capacity-sized launch would cost more than the kernel this replaces); the blocks behind them are past
+// the live bound and touch nothing the bookkeeping changes.
+template <typename T> struct is_no_post { static constexpr bool value = false; };
+template <typename PostFn>
+__device__ __forceinline__ void last_block_post(uint32_t* done, const uint32_t* totals, uint32_t participants, PostFn post) {
+  if (is_no_post<PostFn>::value) return;
+  if (participants == 0) participants = 1;
+  if (blockIdx.x >= participants) return;  // block-uniform
+  __shared__ bool s_last;
+  __syncthreads();  // the block's emits are issued
+  if (threadIdx.x == 0) {
+    __threadfence();
+    s_last = atomicAdd(done, 1u) == participants - 1;
+  }
+  __syncthreads();
+  if (s_last && threadIdx.x == 0) {
+    __threadfence();
+    post(totals);
+  }
+}
+
+template <> struct is_no_post<NoPost> { static constexpr bool value = true; };
+template <typename PostFn>
+__global__ void k_post_only(const uint32_t* totals, PostFn post) { post(totals); }
+
 template <int NKEYS, int PER_THREAD, typename MaskFn>
 __global__ __launch_bounds__(kThreads) void k_count(uint32_t n, uint32_t numRuns, MaskFn maskfn,
                                                     uint32_t* __restrict__ counts, const int* live, uint32_t liveScale) {
@@ -85,6 +118,7 @@ __global__ __launch_bounds__(THREADS) void k_scan(uint32_t numBlocks, uint32_t* 
     if (lr > numBlocks) lr = numBlocks;
   }
   (void)liveRunsOr0;
+  if (threadIdx.x == 0) totals[NKEYS + 1] = 0;  // block counter of the scatter kernel (last_block_post)
   if (lr == 0) {
     if (threadIdx.x <= NKEYS) totals[threadIdx.x] = 0;
     return;
@@ -135,48 +169,58 @@ __global__ __launch_bounds__(THREADS) void k_scan(uint32_t numBlocks, uint32_t* 
 }
 
 // emit(i, key, dst): writes input element i (as a member of `key`) to output slot dst.
-template <int NKEYS, int PER_THREAD, typename MaskFn, typename EmitFn>
+template <int NKEYS, int PER_THREAD, typename MaskFn, typename EmitFn, typename PostFn>
 __global__ __launch_bounds__(kThreads) void k_scatter(uint32_t n, uint32_t numRuns, MaskFn maskfn, EmitFn emit,
-                                                      const uint32_t* __restrict__ offsets, const int* live, uint32_t liveScale) {
+                                                      const uint32_t* __restrict__ offsets, const int* live, uint32_t liveScale,
+                                                      uint32_t* totals, PostFn post) {
   const unsigned lane = threadIdx.x & 63;
   const uint32_t run = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const uint32_t base = run * (64u * PER_THREAD);
-  if (base >= live_elements(live, liveScale, n)) return;  // wave-uniform
-  const unsigned long long below = (1ull << lane) - 1ull;
-  uint32_t off[NKEYS];  // running output offset per key of this wave's run (wave-uniform)
+  if (base < live_elements(live, liveScale, n)) {  // wave-uniform
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t off[NKEYS];  // running output offset per key of this wave's run (wave-uniform)
 #pragma unroll
-  for (int k = 0; k < NKEYS; ++k) off[k] = offsets[k * numRuns + run];
-  for (int r = 0; r < PER_THREAD; ++r) {
-    if (base + r * 64u >= n) break;  // wave-uniform
-    uint32_t i = base + r * 64u + lane;
-    uint32_t mask = (i < n) ? maskfn(i) : 0u;
-    if (__ballot(mask != 0u) == 0ull) continue;  // nothing kept in these 64 elements (the common case for pixels)
+    for (int k = 0; k < NKEYS; ++k) off[k] = offsets[k * numRuns + run];
+    for (int r = 0; r < PER_THREAD; ++r) {
+      if (base + r * 64u >= n) break;  // wave-uniform
+      uint32_t i = base + r * 64u + lane;
+      uint32_t mask = (i < n) ? maskfn(i) : 0u;
+      if (__ballot(mask != 0u) == 0ull) continue;  // nothing kept in these 64 elements (the common case for pixels)
 #pragma unroll
-    for (int k = 0; k < NKEYS; ++k) {
-      const bool has = (mask >> k) & 1u;
-      const unsigned long long m = __ballot(has);
-      if (has) emit(i, k, off[k] + (uint32_t)__popcll(m & below));
-      off[k] += (uint32_t)__popcll(m);
+      for (int k = 0; k < NKEYS; ++k) {
+        const bool has = (mask >> k) & 1u;
+        const unsigned long long m = __ballot(has);
+        if (has) emit(i, k, off[k] + (uint32_t)__popcll(m & below));
+        off[k] += (uint32_t)__popcll(m);
+      }
     }
   }
+  const uint32_t le = live_elements(live, liveScale, n);
+  last_block_post(totals + NKEYS + 1, totals, (le + kThreads * PER_THREAD - 1) / (kThreads * PER_THREAD), post);
 }
 
-// Workspace (in uint32 words): NKEYS * numRuns counts + (NKEYS + 1) totals.
+// Workspace (in uint32 words): NKEYS * numRuns counts + (NKEYS + 1) totals + the scatter kernel's block counter.
 template <int NKEYS, int PER_THREAD>
 inline size_t workspace_words(uint32_t n) {
-  return (size_t)NKEYS * kWavesPerBlock * num_chunks(n, PER_THREAD) + NKEYS + 1;
+  return (size_t)NKEYS * kWavesPerBlock * num_chunks(n, PER_THREAD) + NKEYS + 2;
 }
 
 // Launches the three passes over elements [0, n).  *totals_out = device pointer to NKEYS + 1 words in the workspace.
-template <int NKEYS, int PER_THREAD, typename MaskFn, typename EmitFn>
+// post(totals): device functor run once, after every element has been emitted (see last_block_post)
+template <int NKEYS, int PER_THREAD, typename MaskFn, typename EmitFn, typename PostFn = NoPost>
 inline hipError_t partition(uint32_t n, MaskFn maskfn, EmitFn emit, uint32_t* workspace, uint32_t** totals_out,
-                            hipStream_t stream, const int* live = nullptr, uint32_t liveScale = 1) {
+                            hipStream_t stream, const int* live = nullptr, uint32_t liveScale = 1, PostFn post = PostFn()) {
   uint32_t nb = num_chunks(n, PER_THREAD);
   uint32_t runs = nb * kWavesPerBlock;
   uint32_t* counts = workspace;
   uint32_t* totals = workspace + (size_t)NKEYS * runs;
   if (totals_out) *totals_out = totals;
-  if (nb == 0) return hipMemsetAsync(totals, 0, sizeof(uint32_t) * (NKEYS + 1), stream);
+  if (nb == 0) {  // nothing to partition: totals are zero, the bookkeeping still has to happen
+    hipError_t e0 = hipMemsetAsync(totals, 0, sizeof(uint32_t) * (NKEYS + 2), stream);
+    if (e0 != hipSuccess) return e0;
+    hipLaunchKernelGGL((k_post_only<PostFn>), dim3(1), dim3(1), 0, stream, totals, post);
+    return hipGetLastError();
+  }
   const uint32_t runLen = 64u * PER_THREAD;
   hipLaunchKernelGGL((k_count<NKEYS, PER_THREAD, MaskFn>), dim3(nb), dim3(kThreads), 0, stream, n, runs, maskfn, counts, live,
                      liveScale);
@@ -186,8 +230,8 @@ inline hipError_t partition(uint32_t n, MaskFn maskfn, EmitFn emit, uint32_t* wo
     hipLaunchKernelGGL((k_scan<NKEYS, 1024>), dim3(1), dim3(1024), 0, stream, runs, counts, totals, 0u, live, liveScale, runLen, n);
   else
     hipLaunchKernelGGL((k_scan<NKEYS, 256>), dim3(1), dim3(256), 0, stream, runs, counts, totals, 0u, live, liveScale, runLen, n);
-  hipLaunchKernelGGL((k_scatter<NKEYS, PER_THREAD, MaskFn, EmitFn>), dim3(nb), dim3(kThreads), 0, stream, n, runs,
-                     maskfn, emit, counts, live, liveScale);
+  hipLaunchKernelGGL((k_scatter<NKEYS, PER_THREAD, MaskFn, EmitFn, PostFn>), dim3(nb), dim3(kThreads), 0, stream, n, runs,
+                     maskfn, emit, counts, live, liveScale, totals, post);
   return hipGetLastError();
 }
 
@@ -247,9 +291,10 @@ __global__ __launch_bounds__(kThreads) void k_count_flags(uint32_t n, uint32_t n
   if (lane < NKEYS) counts[lane * numRuns + run] = mine;
 }
 
-template <int NKEYS, typename EmitFn>
+template <int NKEYS, typename EmitFn, typename PostFn>
 __global__ __launch_bounds__(kThreads) void k_scatter_flags(uint32_t n, uint32_t numRuns, const uint8_t* __restrict__ flags,
-                                                            EmitFn emit, const uint32_t* __restrict__ offsets) {
+                                                            EmitFn emit, const uint32_t* __restrict__ offsets, uint32_t* totals,
+                                                            PostFn post) {
   const unsigned lane = threadIdx.x & 63;
   const uint32_t run = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const uint32_t base = run * (uint32_t)kFlagRun;
@@ -274,15 +319,16 @@ __global__ __launch_bounds__(kThreads) void k_scatter_flags(uint32_t n, uint32_t
       }
     }
   }
+  last_block_post(totals + NKEYS + 1, totals, gridDim.x, post);
 }
 
 // partition() for byte flags; falls back to the generic kernels when the fast path's requirements do not hold.
-template <int NKEYS, typename EmitFn>
+template <int NKEYS, typename EmitFn, typename PostFn = NoPost>
 inline hipError_t partition_flags(uint32_t n, const uint8_t* flags, EmitFn emit, uint32_t* workspace, uint32_t** totals_out,
-                                  hipStream_t stream) {
+                                  hipStream_t stream, PostFn post = PostFn()) {
   if (n % 64u != 0u || (reinterpret_cast<size_t>(flags) & 15u) != 0u) {
     auto maskfn = [=] __device__(uint32_t i) -> uint32_t { return (uint32_t)flags[i]; };
-    return partition<NKEYS, kFlagRun / 64>(n, maskfn, emit, workspace, totals_out, stream);
+    return partition<NKEYS, kFlagRun / 64>(n, maskfn, emit, workspace, totals_out, stream, nullptr, 1u, post);
   }
   const uint32_t runs0 = (n + kFlagRun - 1) / kFlagRun;
   const uint32_t nb = (runs0 + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -290,13 +336,19 @@ inline hipError_t partition_flags(uint32_t n, const uint8_t* flags, EmitFn emit,
   uint32_t* counts = workspace;
   uint32_t* totals = workspace + (size_t)NKEYS * runs;
   if (totals_out) *totals_out = totals;
-  if (nb == 0) return hipMemsetAsync(totals, 0, sizeof(uint32_t) * (NKEYS + 1), stream);
+  if (nb == 0) {
+    hipError_t e0 = hipMemsetAsync(totals, 0, sizeof(uint32_t) * (NKEYS + 2), stream);
+    if (e0 != hipSuccess) return e0;
+    hipLaunchKernelGGL((k_post_only<PostFn>), dim3(1), dim3(1), 0, stream, totals, post);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL((k_count_flags<NKEYS>), dim3(nb), dim3(kThreads), 0, stream, n, runs, flags, counts);
   if ((size_t)NKEYS * runs > 16384)
     hipLaunchKernelGGL((k_scan<NKEYS, 1024>), dim3(1), dim3(1024), 0, stream, runs, counts, totals, 0u, (const int*)nullptr, 1u, (uint32_t)kFlagRun, n);
   else
     hipLaunchKernelGGL((k_scan<NKEYS, 256>), dim3(1), dim3(256), 0, stream, runs, counts, totals, 0u, (const int*)nullptr, 1u, (uint32_t)kFlagRun, n);
-  hipLaunchKernelGGL((k_scatter_flags<NKEYS, EmitFn>), dim3(nb), dim3(kThreads), 0, stream, n, runs, flags, emit, counts);
+  hipLaunchKernelGGL((k_scatter_flags<NKEYS, EmitFn, PostFn>), dim3(nb), dim3(kThreads), 0, stream, n, runs, flags, emit, counts,
+                     totals, post);
   return hipGetLastError();
 }
 

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_extrema_flags(LevelSet L, uint8_t* __re
   }
 }
 
-// ---- bookkeeping kernels (one thread) ------------------------------------------------------------------------------------
+// ---- bookkeeping (one thread: the last block of the partition that precedes it, see compact.h last_block_post) ----------
 __global__ void k_state_reset(OctaveState* st) {
   for (int i = 0; i < svp::kDog; ++i) { st->idx[i] = 0; st->stale[i] = 0; }
   st->n = 0;
@@ -99,7 +99,7 @@ __global__ void k_state_reset(OctaveState* st) {
   st->overflow = 0;
 }
 // after searchForExtrema (src/FeatureFactory.cu:98-151): totals = counts for b = 1,2,3
-__global__ void k_book_extrema(OctaveState* st, const uint32_t* totals, uint32_t cap) {
+__device__ __forceinline__ void book_extrema(OctaveState* st, const uint32_t* totals, uint32_t cap) {
   uint32_t c1 = totals[0], c2 = totals[1], total = totals[3];
   // the list is grouped by blur (1, 2, 3) and the scatter drops everything past `cap`: on overflow the list is
   // truncated there (the flag is reported by ssrlcv_sift_plan_overflow; the reference's lists are unbounded)
@@ -118,7 +118,7 @@ __global__ void k_book_extrema(OctaveState* st, const uint32_t* totals, uint32_t
   st->hasExtrema = total != 0;
 }
 // after discardExtrema (src/FeatureFactory.cu:161-215): totals[s] = survivors of segment s
-__global__ void k_book_discard(OctaveState* st, const uint32_t* totals) {
+__device__ __forceinline__ void book_discard(OctaveState* st, const uint32_t* totals) {
   if (!st->hasExtrema) return;
   int kept = 0;
   for (int i = 0; i < svp::kDog; ++i) {
@@ -130,7 +130,7 @@ __global__ void k_book_discard(OctaveState* st, const uint32_t* totals) {
 }
 // stable_sort by blur + host re-scan of refineExtremaLocation (src/FeatureFactory.cu:249-259): totals[v] = survivors
 // with blur == v.  Entries of idx the loop does not reach keep what k_book_discard wrote.
-__global__ void k_book_rescan(OctaveState* st, const uint32_t* totals) {
+__device__ __forceinline__ void book_rescan(OctaveState* st, const uint32_t* totals) {
   if (!st->hasExtrema) return;
   st->idx[0] = 0;
   st->idx[1] = 0;
@@ -146,7 +146,8 @@ __global__ void k_book_rescan(OctaveState* st, const uint32_t* totals) {
   st->idx[svp::kDog - 1] = st->n;
 }
 // after computeKeyPointOrientations (src/FeatureFactory.cu:561-630): totals[s] = oriented key points of segment s
-__global__ void k_book_orient(OctaveState* st, const uint32_t* totals, uint32_t cap) {
+__global__ void k_book_extrema(OctaveState* st, const uint32_t* totals, uint32_t cap) { book_extrema(st, totals, cap); }
+__device__ __forceinline__ void book_orient(OctaveState* st, const uint32_t* totals, uint32_t cap) {
   if (!st->hasExtrema) return;
   int total = 0;
   for (int b = 0; b < svp::kDog; ++b) {
@@ -1010,10 +1011,8 @@ hipError_t run_discard(OctaveState* st, const ssrlcv_sskeypoint* src, ssrlcv_ssk
   };
   auto emit = [=] __device__(uint32_t i, int, uint32_t d) { dst[d] = src[i]; };
   uint32_t* totals = nullptr;
-  hipError_t e = svc::partition<svp::kDog, 8>(cap, keyfn, emit, words, &totals, stream, &st->n);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_book_discard, dim3(1), dim3(1), 0, stream, st, totals);
-  return hipGetLastError();
+  auto post = [=] __device__(const uint32_t* tot) { book_discard(st, tot); };
+  return svc::partition<svp::kDog, 8>(cap, keyfn, emit, words, &totals, stream, &st->n, 1u, post);
 }
 
 // Grid of the wave-per-key-point kernels (orientations, descriptors) in units of list_blocks(): their waves walk the
@@ -1135,6 +1134,8 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
       uint32_t* totals = nullptr;
       hipError_t e = svc::partition_flags<3>(P, flags, emit, words, &totals, s);
       if (e != hipSuccess) return (int)e;
+      // (a kernel of its own here: the pixel-domain scatter has thousands of blocks, and counting them down with one
+      // same-address atomic each costs more than this launch)
       hipLaunchKernelGGL(k_book_extrema, dim3(1), dim3(1), 0, s, st, totals, cap);
     }
     ssrlcv_sskeypoint* cur = (nswaps & 1) ? B : A;
@@ -1158,8 +1159,8 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
         };
         auto emit = [=] __device__(uint32_t i, int, uint32_t d) { dst[d] = src[i]; };
         uint32_t* totals = nullptr;
-        if ((e = svc::partition<svp::kDog, 8>(cap, keyfn, emit, words, &totals, s, &st->n)) != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(k_book_rescan, dim3(1), dim3(1), 0, s, st, totals);
+        auto post = [=] __device__(const uint32_t* tot) { book_rescan(st, tot); };
+        if ((e = svc::partition<svp::kDog, 8>(cap, keyfn, emit, words, &totals, s, &st->n, 1u, post)) != hipSuccess) return (int)e;
         swap();
       }
     }
@@ -1246,10 +1247,11 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
         dst[d] = kp;
       };
       uint32_t* totals = nullptr;
+      OctaveState* sto = states + o;
+      auto post = [=] __device__(const uint32_t* tot) { book_orient(sto, tot, cap); };
       hipError_t e = svc::partition<svp::kDog, 8>(cap * maxO, keyfn, emit, (uint32_t*)(ws + oc.off_part), &totals, caller,
-                                                  &states[o].n, maxO);
+                                                  &states[o].n, maxO, post);
       if (e != hipSuccess) return (int)e;
-      hipLaunchKernelGGL(k_book_orient, dim3(1), dim3(1), 0, caller, states + o, totals, cap);
       ssrlcv_sskeypoint* tmp = curBuf[o];
       curBuf[o] = othBuf[o];
       othBuf[o] = tmp;

@@ -1,4 +1,5 @@
-"""GPU parity: fp16-MFMA 128-D matcher (C ABI) vs the CPU oracle -- indices and distances bit-exact."""
+"""GPU parity: the MFMA 128-D matcher (C ABI; int8 formulation by default, the fp16 one in tests/test_gpu_configs.py) vs
+the CPU oracle -- indices and distances bit-exact."""
 import numpy as np
 import pytest
 

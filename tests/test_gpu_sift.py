@@ -1,7 +1,9 @@
 """GPU parity: SIFT leg (pyramid, key points, orientations, descriptors) through the C ABI vs the CPU oracle.
 
-Pure-arithmetic stages (S1-S12) must be bit-exact; stages that call libm on the device (powf in refinement's sigma,
-atan2f/expf in orientation, sinf/cosf/expf/atan2f in descriptors) are compared within the tolerances stated inline.
+Everything is bit-exact: the pure-arithmetic stages (S1-S12) always were; the stages that call elementary functions
+(powf in refinement's sigma, atan2f / expf in orientation, sinf / cosf / expf / atan2f in descriptors) use the functions
+of ssrlcv_amd/csrc/sv_math.h, the same source text as the oracle's oracle/oracle_libm.h, and the kernels replay the
+reference's operation order (sequential orientation histogram, vote association, IEEE divisions).
 """
 import ctypes
 
@@ -230,8 +232,7 @@ def test_nview_flow_single_rank_matches_3view_fixture(capi):
 def test_degenerate_images_match_oracle(capi, oracle_lib, kind):
     """Edge inputs: a constant image (every normalisation is 0/0: no extrema, no features, no fault), an all-zero image
     of a size makeBinnable pads, uniform noise on a padded size (feature-dense), a one-pixel checkerboard and a single
-    bright pixel.  Feature count, order and locations are the oracle's; orientations and descriptors within the usual
-    tolerance."""
+    bright pixel.  Every feature field is the oracle's, bit for bit."""
     img = {
         "const": np.full((256, 256), 128, np.uint8),
         "zeros": np.zeros((264, 300), np.uint8),
