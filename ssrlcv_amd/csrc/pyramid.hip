@@ -188,7 +188,22 @@ struct ConvArgs {
   const float* dogLvlMinMax;  // {min_b, max_b, min_b+1, max_b+1}
   float* dogMinMax;           // {min, max} of DoG level b (atomics)
   float wgt[33];  // taps are symmetric (w[k] == w[2R-k] bit for bit): only k = 0..R travel, in SGPRs
+#ifdef SSRLCV_LAB
+  long long* stamps;  // tools/gauss_lab.hip: s_memtime stamps of one block, [wave][step][8]
+#endif
 };
+#ifdef SSRLCV_LAB
+long long* g_lab_stamps = nullptr;
+#define LAB_STAMP(slot)                                                                                   \
+  do {                                                                                                    \
+    if (a.stamps && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && it < 64) {              \
+      const long long t_ = (long long)__builtin_amdgcn_s_memtime();                                       \
+      if (lane == 0) a.stamps[((size_t)wave * 64 + it) * 8 + (slot)] = t_;                                \
+    }                                                                                                     \
+  } while (0)
+#else
+#define LAB_STAMP(slot) do { } while (0)
+#endif
 
 constexpr int kTX = 256;  // strip width = threads per block
 constexpr int kNR = 8;    // rows per marching step
@@ -680,6 +695,7 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma(ConvArgs a) {
   }
   __syncthreads();
   for (int it = 0; it <= steps; ++it) {
+    LAB_STAMP(0);
     if (role == 0) {
       if (it < steps) {
         // ---- horizontal pass: H rows 16 it .. 16 it + 15 of this strip into the ring.  The wave's four column tiles
@@ -706,6 +722,7 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma(ConvArgs a) {
           for (int t4 = 0; t4 < TPW; ++t4) acc[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks % 3][t4], tz[ks], acc[t4], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
+        LAB_STAMP(1);
         // D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
         const int slot0 = (it * kMT) % C::RINGROWS;
 #pragma unroll
@@ -716,17 +733,21 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma(ConvArgs a) {
           dst[2 * C::RSTR] = acc[t4][2];
           dst[3 * C::RSTR] = acc[t4][3];
         }
+        LAB_STAMP(2);
         // next step's rows into the other stage (last read one iteration ago), the step after that into registers
         if (it + 1 < steps) {
           stage_write((it + 1) & 1);
+          LAB_STAMP(3);
           if (it + 2 < steps) fetch(it + 2);
         }
+        LAB_STAMP(4);
       }
     } else {
       // ---- vertical role.  The result of the previous iteration is stored first: its VALU / store work then runs
       // while the horizontal waves occupy the matrix pipe, and this wave's MFMAs run while they stage the next rows
       // (with both roles doing MFMAs first and bookkeeping second, neither overlapped anything).
       if (pendJ != kNoPending) store_pending();
+      LAB_STAMP(1);
       // vertical pass of step it - 1: output rows j = jbase + ii, ii = 0..15; B row kk is H row jbase + kk
       const int jbase = (it - 1) * kMT - 2 * R;
       if (it >= 1 && jbase + kMT > 0 && jbase < nrows) {
@@ -767,12 +788,501 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma(ConvArgs a) {
         }
         pendJ = jbase;
       }
+      LAB_STAMP(2);
     }
     __syncthreads();
   }
   if (role == 1 && pendJ != kNoPending) store_pending();
   if (a.minmax) block_minmax_commit(mn, mx, a.minmax, s_mem);
   if (emitDog) block_minmax_commit(dmn, dmx, a.dogMinMax, s_mem);
+}
+
+// ---- k_gauss_mfma, second edition: the same products with (almost) no vector instruction beside them ----------------
+// An f32 MFMA runs on the SIMD's fp32 FMA lanes (v_mfma_f32_16x16x4_f32 issues at the vector fp32 rate and
+// SQ_VALU_MFMA_COEXEC_CYCLES is 0 on these kernels): while one executes, no vector-ALU instruction of EITHER wave of the
+// SIMD issues, and an MFMA behind a vector instruction waits for it -- tools/mfma_lds_rate.hip: ONE v_add_u32 between the
+// k-steps of the vertical pass's loop (4 MFMAs) takes the loop from 35.6 to 45 cycles per MFMA, i.e. a lone vector
+// instruction among MFMAs costs a whole MFMA slot (~37 cycles), whichever wave it comes from.  s_memtime stamps in
+// k_gauss_mfma (tools/gauss_lab.hip, 65 taps, cycles per 16-row step of 8024, 5120 of them MFMA issue): the vertical
+// wave's MFMA loop took 4138 instead of 2560 -- 100 vector instructions of ring-offset arithmetic in front of it and
+// the horizontal wave's address arithmetic, exec-mask regions and LDS address adds dripping in between its MFMAs.
+// This edition keeps the products, their order and the LDS layout and removes the vector instructions:
+//  * radii are padded to even values (11 -> 12, 23 -> 24: zero taps, same k-step count), so k-step ks of the vertical
+//    pass reads four rows of ONE 16-row ring tile: tile and in-tile row are compile-time, the tile's slot is scalar;
+//  * every LDS address of a step is formed at the top of the step in ONE batch of v_add (scalar slot / stage offsets
+//    + static lane parts) and pinned; inside the loops there are only MFMAs, LDS and scalar instructions;
+//  * rows are fetched through a buffer descriptor (row = scalar byte offset, lane part static; the mirror only on the
+//    steps that touch the image border), the four halo accesses share one exec region;
+//  * the result is stored through a scalar row base + static lane offset, unmasked on interior steps; min / max are one
+//    batch of v_min3 / v_max3.
+// Only for full, aligned strips (the row-staged case); everything else stays on k_gauss_mfma.  Bit-identical results.
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) f32x2v lds_f32x2;
+__device__ __forceinline__ unsigned lds_addr(const float* p) { return (unsigned)(size_t)(const lds_f32*)p; }
+__device__ __forceinline__ float lds_ld(unsigned a) { return *(const lds_f32*)(size_t)a; }
+__device__ __forceinline__ void lds_st(unsigned a, float v) { *(lds_f32*)(size_t)a = v; }
+__device__ __forceinline__ void lds_st2(unsigned a, f32x2v v) { *(lds_f32x2*)(size_t)a = v; }
+
+// wave priority of the horizontal role: raised for its MFMA loop (see the schedule note in the kernel)
+#ifndef SSRLCV_MFMA2_PRIO
+#define SSRLCV_MFMA2_PRIO 1
+#endif
+#if SSRLCV_MFMA2_PRIO == 1
+#define MFMA2_PRIO_LOOP() __builtin_amdgcn_s_setprio(3)
+#define MFMA2_PRIO_SIDE() __builtin_amdgcn_s_setprio(0)
+#elif SSRLCV_MFMA2_PRIO == 2
+#define MFMA2_PRIO_LOOP() __builtin_amdgcn_s_setprio(0)
+#define MFMA2_PRIO_SIDE() __builtin_amdgcn_s_setprio(3)
+#else
+#define MFMA2_PRIO_SIDE() do { } while (0)
+#define MFMA2_PRIO_LOOP() do { } while (0)
+#endif
+
+template <int R, int TW>
+struct Mfma2Cfg : MfmaCfg<R, TW> {
+  static constexpr int D = 2 * R;
+  static constexpr int CMIN = -((D + 15) / 16);  // first ring tile a vertical pass reads, relative to H tile it - 1
+  static constexpr int NC = -CMIN + 1;
+  static constexpr int NT = MfmaCfg<R, TW>::RINGROWS / kMT;  // ring tiles
+};
+
+template <int R, int TW>
+__global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma2(ConvArgs a) {
+  using C = Mfma2Cfg<R, TW>;
+  static_assert((2 * R) % 4 == 0 && C::K == C::KP, "radius must be even");
+  static_assert(C::NT >= C::NC + 1, "the ring holds the tiles of one vertical pass beside the tile being written");
+  constexpr int TPW = C::TPW, D = C::D, NT = C::NT, CMIN = C::CMIN, NC = C::NC;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float s_mem[];
+  const int W = (int)a.w, H = (int)a.h;
+  const int x0 = blockIdx.x * TW;
+  const int y0 = blockIdx.y * (int)a.rowsPerBlock;
+  int nrows = (int)a.rowsPerBlock;
+  if (y0 + nrows > H) nrows = H - y0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = (wave ^ (wave >> 2)) & 1, w4 = wave >> 1;  // one wave of each role per SIMD, see k_gauss_mfma
+  const int li = lane & 15, lk = lane >> 4;
+  float tz[C::KS];
+#pragma unroll
+  for (int s = 0; s < C::KS; ++s) {
+    int t = 4 * s + lk - li;
+    int ti = t <= R ? t : 2 * R - t;
+    tz[s] = (t >= 0 && t <= 2 * R) ? a.wgt[ti < 0 ? 0 : ti] : 0.0f;
+  }
+#pragma unroll
+  for (int s = 0; s < C::KS; ++s) asm volatile("" : "+v"(tz[s]));
+  for (int i = tid; i < (int)(C::ldsBytes / sizeof(float)); i += kMfmaThreads) s_mem[i] = 0.0f;
+
+  // LDS byte addresses, static lane parts (stage [2][kMT][SW] in front, ring [RINGROWS][RSTR] behind)
+  constexpr unsigned kStageBytes = (unsigned)kMT * C::SW * 4u, kTileBytes = (unsigned)kMT * C::RSTR * 4u;
+  const unsigned ldsBase = lds_addr(s_mem), ringBase = ldsBase + 2u * kStageBytes;
+  const unsigned aLane = ldsBase + (unsigned)(li * C::SW + (w4 * TPW) * 16 + (C::RP - R) + lk) * 4u;      // horizontal A reads
+  const unsigned hLane = ringBase + (unsigned)((lk * 4) * C::RSTR + (w4 * TPW) * 16 + li) * 4u;          // ring writes
+  const unsigned sLane = ldsBase + (unsigned)((4 * w4) * C::SW + C::RP + 4 * lane) * 4u;                  // stage writes, interior
+  const unsigned gLane = ldsBase + (unsigned)((4 * w4) * C::SW + (lane < C::RP ? lane : TW + lane)) * 4u;  // stage writes, halo
+  const unsigned vLane = ringBase + (unsigned)(lk * C::RSTR + (w4 * TPW) * 16 + li) * 4u;                 // vertical reads
+
+  // ---- horizontal role: staging
+  constexpr int NH = 2 * C::RP;
+  static_assert(NH <= 64, "one halo float per lane");
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((uint32_t)W * (uint32_t)H * 4u), 0x00020000);
+  const bool haloLane = lane < NH, interiorLane = 4 * lane < TW;
+  int hgx = lane < C::RP ? x0 - C::RP + lane : x0 + TW + (lane - C::RP);
+  hgx = hgx > W - 1 + R ? W - 1 + R : hgx;
+  hgx = hgx < 0 ? -1 - hgx : hgx;
+  hgx = hgx > W - 1 ? 2 * W - 1 - hgx : hgx;
+  const int vInt = (x0 + 4 * lane) * 4, vHalo = hgx * 4;  // byte offsets inside a row
+  u32x4 preI[4];
+  unsigned preH[4];
+  auto fetch = [&](int s) {
+    const int ybase = y0 - R + s * kMT + 4 * w4;  // wave-uniform
+    unsigned soff[4];
+    if (ybase >= 0 && ybase + 3 < H) {
+      const unsigned b = (unsigned)ybase * (unsigned)W * 4u;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) soff[k] = b + (unsigned)k * (unsigned)W * 4u;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        int y = ybase + k;
+        y = y > H - 1 + R ? H - 1 + R : y;
+        y = y < 0 ? -1 - y : y;
+        y = y > H - 1 ? 2 * H - 1 - y : y;
+        soff[k] = (unsigned)y * (unsigned)W * 4u;
+      }
+    }
+    if (interiorLane) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) preI[k] = __builtin_amdgcn_raw_buffer_load_b128(rin, vInt, (int)soff[k], 0);
+    }
+    if (haloLane) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) preH[k] = __builtin_amdgcn_raw_buffer_load_b32(rin, vHalo, (int)soff[k], 0);
+    }
+  };
+  // sRow: LDS address of this lane's first interior float in stage row 4 w4 of the target buffer; gRow: of its halo float
+  auto stage_write = [&](unsigned sRow, unsigned gRow) {
+    if (interiorLane) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned e0 = preI[k][0], e1 = preI[k][1], e2 = preI[k][2], e3 = preI[k][3];
+        // SW even, RP a multiple of 4: 8-byte aligned pairs
+        lds_st2(sRow + (unsigned)(k * C::SW) * 4u, f32x2v{__builtin_bit_cast(float, e0), __builtin_bit_cast(float, e1)});
+        lds_st2(sRow + (unsigned)(k * C::SW + 2) * 4u, f32x2v{__builtin_bit_cast(float, e2), __builtin_bit_cast(float, e3)});
+      }
+    }
+    if (haloLane) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) lds_st(gRow + (unsigned)(k * C::SW) * 4u, __builtin_bit_cast(float, preH[k]));
+    }
+  };
+  // ---- vertical role: stores
+  const unsigned vOut = ((unsigned)li * (unsigned)W + (unsigned)(x0 + (w4 * TPW) * 16 + lk * 4)) * 4u;
+  float mn = FLT_MAX, mx = -FLT_MAX;
+  constexpr int kNoPending = -(1 << 30);
+  f32x4 pend[TPW];
+  int pendJ = kNoPending;
+  auto store_pending = [&]() {
+    const int jbase = pendJ;  // uniform
+    char* const orow = reinterpret_cast<char*>(a.out) + (size_t)(long)(y0 + jbase) * (size_t)W * 4u;
+    if (jbase >= 0 && jbase + kMT <= nrows) {
+#pragma unroll
+      for (int t4 = 0; t4 < TPW; ++t4) *reinterpret_cast<f32x4*>(orow + vOut + t4 * 64) = pend[t4];
+#pragma unroll
+      for (int t4 = 0; t4 < TPW; ++t4) {
+        const f32x4 v = pend[t4];
+        mn = __builtin_fminf(__builtin_fminf(mn, v[0]), v[1]);
+        mn = __builtin_fminf(__builtin_fminf(mn, v[2]), v[3]);
+        mx = __builtin_fmaxf(__builtin_fmaxf(mx, v[0]), v[1]);
+        mx = __builtin_fmaxf(__builtin_fmaxf(mx, v[2]), v[3]);
+      }
+    } else {
+      const int j = jbase + li;
+      if (j >= 0 && j < nrows) {
+#pragma unroll
+        for (int t4 = 0; t4 < TPW; ++t4) {
+          const f32x4 v = pend[t4];
+          *reinterpret_cast<f32x4*>(orow + vOut + t4 * 64) = v;
+          mn = fminf(fminf(mn, v[0]), fminf(v[1], fminf(v[2], v[3])));
+          mx = fmaxf(fmaxf(mx, v[0]), fmaxf(v[1], fmaxf(v[2], v[3])));
+        }
+      }
+    }
+    pendJ = kNoPending;
+  };
+  const int steps = (nrows + 2 * R + kMT - 1) / kMT;
+  if (role == 0) fetch(0);
+  __syncthreads();  // zero fill complete
+  if (role == 0) {
+    stage_write(sLane, gLane);
+    if (steps > 1) fetch(1);
+  }
+  // Schedule of a step.  Both waves of a SIMD start their MFMA loops right behind the barrier: the horizontal wave at
+  // high priority (its loop then runs at the full MFMA rate and its ring / stage / fetch work, which has no vector
+  // instruction, proceeds under the vertical wave's MFMAs), the vertical wave in the slots left over and alone afterwards.
+  // Vector instructions of one wave do not issue while the other streams MFMAs (s_memtime: a 20-add address batch of
+  // the vertical wave, placed in front of its loop, waited for the END of the horizontal wave's 80 MFMAs, s_setprio or
+  // not), so each wave forms the NEXT step's LDS addresses in one batch at the end of its step, behind its last MFMA.
+  unsigned aRow = 0, hRow[4] = {0, 0, 0, 0}, sRow = 0, gRow = 0;  // horizontal role: this step's LDS addresses
+  unsigned tb[NC];  // vertical role: LDS addresses (lane part included) of the ring tiles this step reads
+#pragma unroll
+  for (int c = 0; c < NC; ++c) tb[c] = 0;
+  auto h_addresses = [&](int it, int tph /* (it - 1) mod NT */) {
+    const unsigned par = (unsigned)(it & 1) * kStageBytes;  // uniform
+    aRow = aLane + par;
+    const unsigned slotH = (unsigned)(tph + 1 == NT ? 0 : tph + 1) * kTileBytes;  // H tile `it` goes to slot it mod NT
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hRow[r] = hLane + slotH + (unsigned)(r * C::RSTR) * 4u;
+    sRow = sLane + (kStageBytes - par);  // the other buffer
+    gRow = gLane + (kStageBytes - par);
+    asm volatile("" : "+v"(aRow), "+v"(hRow[0]), "+v"(hRow[1]), "+v"(hRow[2]), "+v"(hRow[3]), "+v"(sRow), "+v"(gRow));
+  };
+  auto v_addresses = [&](int tph /* (it - 1) mod NT */) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      int slot = tph + CMIN + c;  // uniform; ring tile c (CMIN .. 0, relative to H tile it - 1) sits in slot (tph + c) mod NT
+      slot = slot < 0 ? slot + NT : slot;
+      tb[c] = vLane + (unsigned)slot * kTileBytes;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) asm volatile("" : "+v"(tb[c]));
+  };
+  // Vertical-pass operand reads: k-step ks takes rows (4 ks - D) .. + 3 relative to H tile it - 1, i.e. in-tile row
+  // `within` of ring tile c -- both compile-time -- so the read is tile address + a 16-bit immediate.  Written as inline
+  // asm: left to the compiler, pairs of reads become ds_read2_b32, whose 8-bit offsets do not reach the row, and every
+  // k-step gets a v_add_u32 for its row -- the vector instruction among MFMAs this kernel exists to avoid.  The reads
+  // are therefore invisible to the compiler's s_waitcnt insertion: the loop waits explicitly (LDS returns in order).
+  float bv[3][TPW];
+  auto v_read = [&](int ks) {
+    const int rel = 4 * ks - D;
+    const int c = (rel >= 0 ? rel / 16 : -((-rel + 15) / 16));
+    const int within = rel - 16 * c;
+#pragma unroll
+    for (int t4 = 0; t4 < TPW; ++t4)
+      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bv[ks % 3][t4]) : "v"(tb[c - CMIN]), "n"((within * C::RSTR + t4 * 16) * 4));
+  };
+  // wait until at most `left` LDS reads are in flight; the operands of k-step ks pass through the statement, so that
+  // nothing that uses them can move in front of it
+  auto v_wait = [&](int ks, int left) {
+    if constexpr (TPW == 4) {
+      if (left == 8) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(bv[ks % 3][0]), "+v"(bv[ks % 3][1]), "+v"(bv[ks % 3][2]), "+v"(bv[ks % 3][3]));
+      else if (left == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bv[ks % 3][0]), "+v"(bv[ks % 3][1]), "+v"(bv[ks % 3][2]), "+v"(bv[ks % 3][3]));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[ks % 3][0]), "+v"(bv[ks % 3][1]), "+v"(bv[ks % 3][2]), "+v"(bv[ks % 3][3]));
+    } else {
+      static_assert(TPW == 4 || TPW == 2, "tiles per wave");
+      if (left == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bv[ks % 3][0]), "+v"(bv[ks % 3][1]));
+      else if (left == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bv[ks % 3][0]), "+v"(bv[ks % 3][1]));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[ks % 3][0]), "+v"(bv[ks % 3][1]));
+    }
+  };
+  static_assert((12 * C::RSTR + (TPW - 1) * 16) * 4 < 65536, "ds_read_b32 immediate");
+  static_assert(D >= 12, "the first two k-steps of a vertical pass read tiles that are complete one step earlier");
+  if (role == 0) {
+    h_addresses(0, NT - 1);
+  } else {
+    v_addresses(0);  // step 1 reads relative to H tile 0
+    v_read(0);       // (zeros so far: step 1's first rows lie above the strip)
+    v_read(1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  int tphase = NT - 1;  // ((it - 1) mod NT) for it = 0
+  for (int it = 0; it <= steps; ++it) {
+    LAB_STAMP(0);
+    const int tnext = tphase + 1 == NT ? 0 : tphase + 1;  // (it mod NT) = tphase of step it + 1
+    if (role == 0) {
+      if (it < steps) {
+        MFMA2_PRIO_LOOP();
+        f32x4 acc[TPW];
+#pragma unroll
+        for (int t4 = 0; t4 < TPW; ++t4) acc[t4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        float av[3][TPW];
+#pragma unroll
+        for (int t4 = 0; t4 < TPW; ++t4) av[0][t4] = lds_ld(aRow + (unsigned)(t4 * 16) * 4u);
+        if (C::KS > 1) {
+#pragma unroll
+          for (int t4 = 0; t4 < TPW; ++t4) av[1][t4] = lds_ld(aRow + (unsigned)(t4 * 16 + 4) * 4u);
+        }
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+          if (ks + 2 < C::KS) {
+#pragma unroll
+            for (int t4 = 0; t4 < TPW; ++t4) av[(ks + 2) % 3][t4] = lds_ld(aRow + (unsigned)(t4 * 16 + 4 * (ks + 2)) * 4u);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t4 = 0; t4 < TPW; ++t4) acc[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks % 3][t4], tz[ks], acc[t4], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        MFMA2_PRIO_SIDE();
+        LAB_STAMP(1);
+#pragma unroll
+        for (int t4 = 0; t4 < TPW; ++t4) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lds_st(hRow[r] + (unsigned)(t4 * 16) * 4u, acc[t4][r]);
+        }
+        LAB_STAMP(2);
+        if (it + 1 < steps) {
+          stage_write(sRow, gRow);
+          LAB_STAMP(3);
+          if (it + 2 < steps) fetch(it + 2);
+        }
+        LAB_STAMP(4);
+        if (it + 1 < steps) h_addresses(it + 1, tnext);
+      }
+    } else {
+      const int jbase = (it - 1) * kMT - D;
+      if (it >= 1 && jbase + kMT > 0 && jbase < nrows) {  // uniform
+#pragma unroll
+        for (int t4 = 0; t4 < TPW; ++t4) pend[t4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        // the operands of k-steps 0 and 1 were read before the barrier (complete tiles); k-step ks + 2 is requested
+        // before the MFMAs of ks, so at most 3 k-steps (12 reads) are in flight and the oldest 4 belong to ks
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+          if (ks + 2 < C::KS) v_read(ks + 2);
+          v_wait(ks, ks + 2 < C::KS ? 2 * TPW : ks + 1 < C::KS ? TPW : 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t4 = 0; t4 < TPW; ++t4) pend[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[ks % 3][t4], tz[ks], pend[t4], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        LAB_STAMP(1);
+        pendJ = jbase;
+        store_pending();
+      }
+      LAB_STAMP(2);
+      if (it < steps) {
+        v_addresses(tnext);
+        v_read(0);  // next step's first operands: tiles that are complete already
+        v_read(1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the barrier waits for them anyway; explicit because the compiler does not see these reads)
+      }
+      LAB_STAMP(3);
+    }
+    tphase = tnext;
+    __syncthreads();
+  }
+  if (a.minmax) block_minmax_commit(mn, mx, a.minmax, s_mem);
+}
+
+// ---- S4 for the small levels: one tile per block, no marching ---------------------------------------------------------
+// The marching kernels pay a 2R-row warm-up and one barrier per 8 or 16 rows; a 1024^2 or 2048^2 level gives them 64 to
+// 256 blocks of 8 to 12 sequential steps each -- 16 to 60 us per level for work the chip does in 2 (octaves 2 and 3: 0.40 ms
+// of a 2.2 ms pyramid for 8 % of its pixels).  Here a block owns a 64 x 64 output tile: it stages the (64 + 2R)-row input
+// region once, its 8 waves run the horizontal pass of all row groups side by side, one barrier, then the vertical pass
+// of the 16 output tiles, two per wave.  Same banded-Toeplitz MFMA chains in the same k order as k_gauss_mfma (the
+// operands come from the same relative LDS positions), so the result is bit-identical.  The halo makes the block read
+// 4x and compute 2-3x what it writes: only for levels that are latency-bound anyway (they sit in L2).
+template <int R>
+struct TileCfg {
+  static constexpr int TW = 64, TH = 64;
+  static constexpr int K = 16 + 2 * R, KS = (K + 3) / 4, KP = KS * 4, RP = (R + 3) / 4 * 4;
+  static constexpr int HR = (TH + 2 * R + 15) / 16 * 16;  // staged input rows = rows of the horizontal pass
+  static constexpr int CW = TW + 2 * RP + (KP - K);       // staged columns the A operands reach
+  static constexpr int SW = (CW + 4 + 29) / 32 * 32 + 2;  // == 2 (mod 32): conflict-free A reads (see MfmaCfg)
+  static constexpr int RSTR = TW + 16;                    // == 16 (mod 32)
+  static constexpr int NC = (CW + 63) / 64;               // staged floats per lane and row
+  static constexpr size_t ldsBytes = sizeof(float) * ((size_t)HR * SW + (size_t)HR * RSTR);
+};
+constexpr int kTileThreads = 512;
+
+template <int R>
+__global__ __launch_bounds__(kTileThreads) void k_gauss_tile(ConvArgs a) {
+  using C = TileCfg<R>;
+  extern __shared__ __attribute__((aligned(16))) float s_mem[];
+  float* s_in = s_mem;                  // [HR][SW]
+  float* s_h = s_mem + C::HR * C::SW;   // [HR][RSTR]
+  const int W = (int)a.w, H = (int)a.h;
+  const int x0 = blockIdx.x * C::TW, y0 = blockIdx.y * C::TH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  float tz[C::KS];
+#pragma unroll
+  for (int s = 0; s < C::KS; ++s) {
+    int t = 4 * s + lk - li;
+    int ti = t <= R ? t : 2 * R - t;
+    tz[s] = (t >= 0 && t <= 2 * R) ? a.wgt[ti < 0 ? 0 : ti] : 0.0f;
+  }
+  // ---- stage rows y0 - R .. y0 - R + HR - 1, columns x0 - RP .. x0 - RP + CW - 1 (mirrored into the image; what lies
+  // beyond W - 1 + R / H - 1 + R only meets zero weights or outputs that are not stored and re-reads a valid pixel)
+  int gx[C::NC];
+#pragma unroll
+  for (int i = 0; i < C::NC; ++i) {
+    int x = x0 - C::RP + i * 64 + lane;
+    x = x > W - 1 + R ? W - 1 + R : x;
+    x = x < 0 ? -1 - x : x;
+    x = x > W - 1 ? 2 * W - 1 - x : x;
+    gx[i] = x;
+  }
+  constexpr int RB = 4;  // rows in flight per wave
+  for (int r0 = wave * RB; r0 < C::HR; r0 += 8 * RB) {
+    float v[RB][C::NC];
+#pragma unroll
+    for (int k = 0; k < RB; ++k) {
+      int y = y0 - R + r0 + k;  // wave-uniform
+      y = y > H - 1 + R ? H - 1 + R : y;
+      y = y < 0 ? -1 - y : y;
+      y = y > H - 1 ? 2 * H - 1 - y : y;
+      const float* row = a.in + (size_t)y * W;
+#pragma unroll
+      for (int i = 0; i < C::NC; ++i) v[k][i] = row[gx[i]];
+    }
+#pragma unroll
+    for (int k = 0; k < RB; ++k) {
+#pragma unroll
+      for (int i = 0; i < C::NC; ++i)
+        if ((i + 1) * 64 <= C::CW || i * 64 + lane < C::CW) s_in[(r0 + k) * C::SW + i * 64 + lane] = v[k][i];
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < C::KS; ++s) asm volatile("" : "+v"(tz[s]));
+  __syncthreads();
+  // ---- horizontal pass: row group g (16 rows) x 4 column tiles per wave
+  for (int g = wave; g < C::HR / 16; g += 8) {
+    const float* arow = s_in + (16 * g + li) * C::SW + (C::RP - R) + lk;
+    f32x4 acc[4];
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) acc[t4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float av[3][4];
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) av[0][t4] = arow[t4 * 16];
+    if (C::KS > 1) {
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) av[1][t4] = arow[t4 * 16 + 4];
+    }
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      if (ks + 2 < C::KS) {
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) av[(ks + 2) % 3][t4] = arow[t4 * 16 + 4 * (ks + 2)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) acc[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks % 3][t4], tz[ks], acc[t4], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      float* dst = s_h + (16 * g + lk * 4) * C::RSTR + t4 * 16 + li;
+      dst[0] = acc[t4][0];
+      dst[C::RSTR] = acc[t4][1];
+      dst[2 * C::RSTR] = acc[t4][2];
+      dst[3 * C::RSTR] = acc[t4][3];
+    }
+  }
+  __syncthreads();
+  // ---- vertical pass (transposed, as in k_gauss_mfma): output row tile rt, column tiles 2 (wave & 1) and + 1
+  float mn = FLT_MAX, mx = -FLT_MAX;
+  {
+    const int rt = wave >> 1, ct0 = 2 * (wave & 1);
+    int boff[C::KS];
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      int kk = 4 * ks + lk;
+      kk = kk > C::K - 1 ? C::K - 1 : kk;
+      boff[ks] = (16 * rt + kk) * C::RSTR;
+    }
+    const float* colp = s_h + ct0 * 16 + li;
+    f32x4 pend[2];
+    pend[0] = pend[1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float bv[3][2];
+    bv[0][0] = colp[boff[0]];
+    bv[0][1] = colp[boff[0] + 16];
+    if (C::KS > 1) {
+      bv[1][0] = colp[boff[1]];
+      bv[1][1] = colp[boff[1] + 16];
+    }
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      if (ks + 2 < C::KS) {
+        bv[(ks + 2) % 3][0] = colp[boff[ks + 2]];
+        bv[(ks + 2) % 3][1] = colp[boff[ks + 2] + 16];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      pend[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[ks % 3][0], tz[ks], pend[0], 0, 0, 0);
+      pend[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[ks % 3][1], tz[ks], pend[1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int gy = y0 + 16 * rt + li;
+    const bool vec4 = (W & 3) == 0 && (reinterpret_cast<size_t>(a.out) & 15) == 0;
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      const int gxo = x0 + (ct0 + t2) * 16 + lk * 4;
+      float* o = a.out + ((size_t)gy * W + gxo);
+      const f32x4 v = pend[t2];
+      if (gy < H && vec4 && gxo + 3 < W) {
+        *reinterpret_cast<f32x4*>(o) = v;
+        mn = fminf(fminf(mn, v[0]), fminf(v[1], fminf(v[2], v[3])));
+        mx = fmaxf(fmaxf(mx, v[0]), fmaxf(v[1], fmaxf(v[2], v[3])));
+      } else if (gy < H) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (gxo + r < W) { o[r] = v[r]; mn = fminf(mn, v[r]); mx = fmaxf(mx, v[r]); }
+      }
+    }
+  }
+  if (a.minmax) block_minmax_commit(mn, mx, a.minmax, s_mem);
 }
 
 // Generic two-pass fallback for tap counts the pipeline never produces (taps > 65): one 1-D pass per launch.
@@ -826,39 +1336,41 @@ struct DogArgs {
   float* dog[svp::kDog];
   const float* lvlMinMax;  // 6 x {min,max}
   float* dogMinMax;        // 5 x {min,max}, nullable
+  float* partial;          // PARTIAL mode: float[2 * kDog][kDogMaxWaves], slot = global wave index
   size_t n;
 };
-// FIRST: the first DoG level this launch produces (levels below it were emitted by the convolution loaders, see
-// k_gauss_mfma); their {min, max} slots receive the neutral FLT_MAX / -FLT_MAX from here
-template <int FIRST>
-__global__ __launch_bounds__(256) void k_dog(DogArgs a) {
+// One launch produces the DoG levels first .. last - 1 (wave-uniform kernel arguments): the levels below `first` were
+// made by an earlier launch of the split schedule (or emitted by the convolution loaders, see k_gauss_mfma), the ones from
+// `last` on follow once their Gaussian levels are complete.  Only the produced levels' {min, max} slots are touched.
+template <bool PARTIAL>
+__global__ __launch_bounds__(256) void k_dog(DogArgs a, int first, int last) {
   float lmn[svp::kGauss];
   sv::Divisor range[svp::kGauss];  // (v - min) / (max - min) as the IEEE quotient through a shared reciprocal (device_math.h)
 #pragma unroll
   for (int b = 0; b < svp::kGauss; ++b) {
-    lmn[b] = a.lvlMinMax[2 * b];
-    range[b] = sv::make_divisor(a.lvlMinMax[2 * b + 1] - lmn[b]);
+    lmn[b] = 0.0f;
+    range[b] = sv::Divisor{1.0f, 1.0f};
+    if (b >= first && b <= last) {  // levels above `last` may still be in the making
+      lmn[b] = a.lvlMinMax[2 * b];
+      range[b] = sv::make_divisor(a.lvlMinMax[2 * b + 1] - lmn[b]);
+    }
   }
   float dmn[svp::kDog], dmx[svp::kDog];
 #pragma unroll
   for (int b = 0; b < svp::kDog; ++b) { dmn[b] = FLT_MAX; dmx[b] = -FLT_MAX; }
+  typedef float f32x4nt __attribute__((ext_vector_type(4)));
+  auto normalised = [&](const float* lvl, size_t i, float mn, const sv::Divisor& rg) {
+    const f32x4nt c0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(lvl + i));  // streamed once
+    return make_float4(sv::div_by(c0.x - mn, rg), sv::div_by(c0.y - mn, rg), sv::div_by(c0.z - mn, rg), sv::div_by(c0.w - mn, rg));
+  };
   size_t stride = (size_t)gridDim.x * 256 * 4;
   for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < a.n; i += stride) {
-    typedef float f32x4nt __attribute__((ext_vector_type(4)));
-    const f32x4nt p0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(a.lvl[FIRST] + i));  // streamed once
-    float4 prev = make_float4(p0.x, p0.y, p0.z, p0.w);
-    prev.x = sv::div_by(prev.x - lmn[FIRST], range[FIRST]);
-    prev.y = sv::div_by(prev.y - lmn[FIRST], range[FIRST]);
-    prev.z = sv::div_by(prev.z - lmn[FIRST], range[FIRST]);
-    prev.w = sv::div_by(prev.w - lmn[FIRST], range[FIRST]);
+    float4 prev = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
-    for (int b = FIRST; b < svp::kDog; ++b) {
-      const f32x4nt c0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(a.lvl[b + 1] + i));
-      float4 cur = make_float4(c0.x, c0.y, c0.z, c0.w);
-      cur.x = sv::div_by(cur.x - lmn[b + 1], range[b + 1]);
-      cur.y = sv::div_by(cur.y - lmn[b + 1], range[b + 1]);
-      cur.z = sv::div_by(cur.z - lmn[b + 1], range[b + 1]);
-      cur.w = sv::div_by(cur.w - lmn[b + 1], range[b + 1]);
+    for (int b = 0; b < svp::kDog; ++b) {
+      if (b < first || b >= last) continue;  // uniform
+      if (b == first) prev = normalised(a.lvl[b], i, lmn[b], range[b]);
+      const float4 cur = normalised(a.lvl[b + 1], i, lmn[b + 1], range[b + 1]);
       float4 d = make_float4(cur.x - prev.x, cur.y - prev.y, cur.z - prev.z, cur.w - prev.w);
       __builtin_nontemporal_store(f32x4nt{d.x, d.y, d.z, d.w}, reinterpret_cast<f32x4nt*>(a.dog[b] + i));
       dmn[b] = fminf(fminf(dmn[b], d.x), fminf(d.y, fminf(d.z, d.w)));
@@ -866,12 +1378,33 @@ __global__ __launch_bounds__(256) void k_dog(DogArgs a) {
       prev = cur;
     }
   }
+  if (PARTIAL) {
+    // no LDS, no atomics: every wave leaves its {min, max} in its own slot and k_dog_finalize reduces them.  Blocks of
+    // this mode are short-lived (large grids), so that convolution blocks queued on another stream find room on the CUs.
+    const int lane = threadIdx.x & 63;
+    const size_t slot = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+#pragma unroll
+    for (int b = 0; b < svp::kDog; ++b) {
+      if (b < first || b >= last) continue;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        dmn[b] = fminf(dmn[b], __shfl_xor(dmn[b], o, 64));
+        dmx[b] = fmaxf(dmx[b], __shfl_xor(dmx[b], o, 64));
+      }
+      if (lane == 0) {
+        a.partial[(size_t)(2 * b) * svp::kDogMaxWaves + slot] = dmn[b];
+        a.partial[(size_t)(2 * b + 1) * svp::kDogMaxWaves + slot] = dmx[b];
+      }
+    }
+    return;
+  }
   if (a.dogMinMax) {
-    // the five {min, max} pairs in one block reduction: wave shuffles, one barrier, ten lanes finish and commit
+    // the {min, max} pairs in one block reduction: wave shuffles, one barrier, up to ten lanes finish and commit
     __shared__ float s_red[4][2 * svp::kDog];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int b = 0; b < svp::kDog; ++b) {
+      if (b < first || b >= last) continue;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
         dmn[b] = fminf(dmn[b], __shfl_xor(dmn[b], o, 64));
@@ -880,13 +1413,40 @@ __global__ __launch_bounds__(256) void k_dog(DogArgs a) {
       if (lane == 0) { s_red[wave][2 * b] = dmn[b]; s_red[wave][2 * b + 1] = dmx[b]; }
     }
     __syncthreads();
-    if (threadIdx.x < 2 * svp::kDog) {
-      const int t = threadIdx.x;
+    const int t = threadIdx.x;
+    if (t < 2 * svp::kDog && (t >> 1) >= first && (t >> 1) < last) {
       float v = s_red[0][t];
       for (int w = 1; w < 4; ++w) v = (t & 1) ? fmaxf(v, s_red[w][t]) : fminf(v, s_red[w][t]);
       if (t & 1) atomic_max_f(a.dogMinMax + t, v);
       else atomic_min_f(a.dogMinMax + t, v);
     }
+  }
+}
+
+// PARTIAL mode, second step: block b reduces the per-wave partials of DoG level first + b and stores its {min, max}
+__global__ __launch_bounds__(256) void k_dog_finalize(const float* __restrict__ partial, unsigned waves, int first,
+                                                      float* __restrict__ dogMinMax) {
+  const int b = first + (int)blockIdx.x;
+  const float* pmn = partial + (size_t)(2 * b) * svp::kDogMaxWaves;
+  const float* pmx = partial + (size_t)(2 * b + 1) * svp::kDogMaxWaves;
+  float mn = FLT_MAX, mx = -FLT_MAX;
+  for (unsigned i = threadIdx.x; i < waves; i += 256) {
+    mn = fminf(mn, pmn[i]);
+    mx = fmaxf(mx, pmx[i]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, o, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  }
+  __shared__ float s_red[8];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_red[2 * wave] = mn; s_red[2 * wave + 1] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) { mn = fminf(mn, s_red[2 * w]); mx = fmaxf(mx, s_red[2 * w + 1]); }
+    dogMinMax[2 * b] = mn;
+    dogMinMax[2 * b + 1] = mx;
   }
 }
 
@@ -931,6 +1491,9 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
   a.w = w;
   a.h = h;
   a.x0base = 0;
+#ifdef SSRLCV_LAB
+  a.stamps = g_lab_stamps;
+#endif
   a.u8 = u8src;
   if (u8src && !upsample_fusable(w, h, taps)) return SSRLCV_ERR_INVALID_ARG;
   a.dogPrev = nullptr;
@@ -966,7 +1529,36 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
   // within 12 % of copy speed there.  Default: MFMA from 23 taps up.  SSRLCV_GAUSS_VALU=1 / SSRLCV_GAUSS_MFMA=1 force
   // one of them for every radius.
   static const bool forceValu = getenv("SSRLCV_GAUSS_VALU") != nullptr, forceMfma = getenv("SSRLCV_GAUSS_MFMA") != nullptr;
-  const bool useMfma = forceMfma || (!forceValu && RT >= 11);
+  static const int mfmaMinR = getenv("SSRLCV_GAUSS_MFMA_MINR") ? atoi(getenv("SSRLCV_GAUSS_MFMA_MINR")) : 11;
+  const bool useMfma = forceMfma || (!forceValu && !u8src && RT >= mfmaMinR);
+  // small levels (<= 1024^2): the tile kernel (no marching).  Measured inside build_dog on a 4096^2 image (octave 3 =
+  // 1024^2, octave 2 = 2048^2): marching kernels everywhere 2.079 ms, tile kernel for octave 3 2.065, for octaves 2 and
+  // 3 2.133 (a 2048^2 level is 1024 tiles, four rounds of one-per-CU blocks).  SSRLCV_GAUSS_TILE_MAXPX=<pixels> moves
+  // the threshold (0 = never).
+  static const size_t tileMaxPx = getenv("SSRLCV_GAUSS_TILE_MAXPX") ? (size_t)atoll(getenv("SSRLCV_GAUSS_TILE_MAXPX")) : ((size_t)1 << 20);
+  if (!u8src && !dog && !forceValu && (size_t)w * h <= tileMaxPx) {
+#define SSRLCV_LAUNCH_TILE(RR)                                                                                     \
+  do {                                                                                                              \
+    static bool attr = false;                                                                                       \
+    if (!attr) {                                                                                                    \
+      SSRLCV_HIP_TRY(hipFuncSetAttribute((const void*)k_gauss_tile<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         (int)TileCfg<RR>::ldsBytes));                                              \
+      attr = true;                                                                                                  \
+    }                                                                                                               \
+    hipLaunchKernelGGL(k_gauss_tile<RR>, dim3((w + 63) / 64, (h + 63) / 64), dim3(kTileThreads), TileCfg<RR>::ldsBytes, st, a); \
+  } while (0)
+    switch (RT) {
+      case 6: SSRLCV_LAUNCH_TILE(6); break;
+      case 8: SSRLCV_LAUNCH_TILE(8); break;
+      case 11: SSRLCV_LAUNCH_TILE(11); break;
+      case 16: SSRLCV_LAUNCH_TILE(16); break;
+      case 23: SSRLCV_LAUNCH_TILE(23); break;
+      default: SSRLCV_LAUNCH_TILE(32); break;
+    }
+#undef SSRLCV_LAUNCH_TILE
+    SSRLCV_LAUNCH_CHECK();
+    return SSRLCV_OK;
+  }
   if (!useMfma) {
     // full strips with 16-byte aligned rows take the row-staged kernel, a partial last strip (or everything, when the
     // rows are not aligned) the generic one
@@ -1031,6 +1623,48 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
     static const bool noRowStaging = getenv("SSRLCV_GAUSS_ELEMENTWISE") != nullptr;
     const bool rowStaging = !noRowStaging && (w & 3) == 0 && (reinterpret_cast<size_t>(in) & 15) == 0;
     const bool wide = forceWide || (!forceNarrow && (size_t)w * h >= ((size_t)1 << 25));
+    // second edition (k_gauss_mfma2): full aligned strips only, radii padded to even values
+    static const bool noMfma2 = getenv("SSRLCV_GAUSS_MFMA1") != nullptr;
+    if (!noMfma2 && !dog && rowStaging && (reinterpret_cast<size_t>(out) & 15) == 0 && (uint64_t)w * h * 4 < ((uint64_t)1 << 32) &&
+        w % (wide || R > 24 ? 256u : 128u) == 0) {
+      const int R2 = R <= 6 ? 6 : R <= 8 ? 8 : R <= 12 ? 12 : R <= 16 ? 16 : R <= 24 ? 24 : 32;
+      memset(a.wgt, 0, sizeof a.wgt);
+      for (int k = 0; k <= R; ++k) a.wgt[(R2 - R) + k] = weights_host[k];
+#define SSRLCV_LAUNCH_MFMA2(RR, TW)                                                                                 \
+  do {                                                                                                              \
+    static int blocksPerCu = 0, cus = 0;                                                                            \
+    if (!blocksPerCu) {                                                                                             \
+      SSRLCV_HIP_TRY(hipFuncSetAttribute((const void*)k_gauss_mfma2<RR, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         (int)MfmaCfg<RR, TW>::ldsBytes));                                          \
+      int dev = 0, occ = 0;                                                                                         \
+      SSRLCV_HIP_TRY(hipGetDevice(&dev));                                                                           \
+      SSRLCV_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));                      \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_gauss_mfma2<RR, TW>, kMfmaThreads,       \
+                                                       MfmaCfg<RR, TW>::ldsBytes) != hipSuccess || occ < 1)         \
+        occ = 1;                                                                                                    \
+      blocksPerCu = occ;                                                                                            \
+    }                                                                                                               \
+    const uint32_t bxm = w / (TW);                                                                                  \
+    uint32_t by = ((uint32_t)(blocksPerCu * cus) + bxm - 1) / bxm;                                                  \
+    rows = (h + by - 1) / by;                                                                                       \
+    rows = rows < 64 ? 64 : rows;                                                                                   \
+    rows = (rows + kMT - 1) / kMT * kMT;                                                                            \
+    a.rowsPerBlock = rows;                                                                                          \
+    const size_t ldsB2 = MfmaCfg<RR, TW>::ldsBytes;                                                                 \
+    hipLaunchKernelGGL((k_gauss_mfma2<RR, TW>), dim3(bxm, (h + rows - 1) / rows), dim3(kMfmaThreads), ldsB2, st, a); \
+  } while (0)
+      switch (R2) {
+        case 6: if (wide) SSRLCV_LAUNCH_MFMA2(6, 256); else SSRLCV_LAUNCH_MFMA2(6, 128); break;
+        case 8: if (wide) SSRLCV_LAUNCH_MFMA2(8, 256); else SSRLCV_LAUNCH_MFMA2(8, 128); break;
+        case 12: if (wide) SSRLCV_LAUNCH_MFMA2(12, 256); else SSRLCV_LAUNCH_MFMA2(12, 128); break;
+        case 16: if (wide) SSRLCV_LAUNCH_MFMA2(16, 256); else SSRLCV_LAUNCH_MFMA2(16, 128); break;
+        case 24: if (wide) SSRLCV_LAUNCH_MFMA2(24, 256); else SSRLCV_LAUNCH_MFMA2(24, 128); break;
+        default: SSRLCV_LAUNCH_MFMA2(32, 256); break;
+      }
+#undef SSRLCV_LAUNCH_MFMA2
+      SSRLCV_LAUNCH_CHECK();
+      return SSRLCV_OK;
+    }
     switch (RT) {
       case 6: if (wide) SSRLCV_LAUNCH_MFMA(6, 256); else SSRLCV_LAUNCH_MFMA(6, 128); break;
       case 8: if (wide) SSRLCV_LAUNCH_MFMA(8, 256); else SSRLCV_LAUNCH_MFMA(8, 128); break;
@@ -1067,8 +1701,11 @@ PlanAsync* plan_async(const ssrlcv_sift_plan* plan) {
         auto it = pool.find(dev);
         if (ok && it == pool.end()) {
           std::pair<hipStream_t, hipStream_t> pr{nullptr, nullptr};
+          int least = 0, greatest = 0;
+          (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+          const int tablePrio = getenv("SSRLCV_SIDE_LOW_PRIORITY") ? least : 0;
           ok = hipStreamCreateWithFlags(&pr.first, hipStreamNonBlocking) == hipSuccess &&
-               hipStreamCreateWithFlags(&pr.second, hipStreamNonBlocking) == hipSuccess;
+               hipStreamCreateWithPriority(&pr.second, hipStreamNonBlocking, tablePrio) == hipSuccess;
           if (ok) it = pool.emplace(dev, pr).first;
         }
         if (ok) {
@@ -1080,6 +1717,8 @@ PlanAsync* plan_async(const ssrlcv_sift_plan* plan) {
         for (hipEvent_t& e : a->convDone) mk(e);
         for (hipEvent_t& e : a->dogDone) mk(e);
         for (hipEvent_t& e : a->polarDone) mk(e);
+        for (auto& lv : a->levelDone)
+          for (hipEvent_t& e : lv) mk(e);
       }
       if (ok) {
         plan->async = a;
@@ -1176,9 +1815,13 @@ int ssrlcv_hip_normalize(float* data, size_t n, const float* minmax, ssrlcv_stre
   return SSRLCV_OK;
 }
 
+// partial (nullable): workspace for the atomic-free mode (float[2 * kDog][kDogMaxWaves]); with it `maxBlocks` may be large
+// (short-lived blocks), without it the grid stays small because every block ends with same-address atomics
 static int launch_dog(const float* const levels_host[6], const float* levelMinMax, uint32_t w, uint32_t h,
-                      float* const dog_host[5], float* dogMinMax, int firstDog, ssrlcv_stream_t stream) {
+                      float* const dog_host[5], float* dogMinMax, int firstDog, int lastDog, unsigned maxBlocks,
+                      float* partial, ssrlcv_stream_t stream) {
   if (!levels_host || !levelMinMax || !dog_host || !w || !h) return SSRLCV_ERR_INVALID_ARG;
+  if (firstDog < 0 || lastDog > svp::kDog || firstDog >= lastDog) return SSRLCV_ERR_INVALID_ARG;
   size_t n = (size_t)w * h;
   if (n % 4) return SSRLCV_ERR_INVALID_ARG;
   DogArgs a;
@@ -1186,22 +1829,25 @@ static int launch_dog(const float* const levels_host[6], const float* levelMinMa
   for (int b = 0; b < svp::kDog; ++b) a.dog[b] = dog_host[b];
   a.lvlMinMax = levelMinMax;
   a.dogMinMax = dogMinMax;
+  a.partial = partial;
   a.n = n;
   size_t blocks = (n / 4 + 255) / 256;
-  if (blocks > 1024) blocks = 1024;  // 4 blocks per CU; each block ends with 10 same-address atomics
-  switch (firstDog) {
-    case 4: hipLaunchKernelGGL(k_dog<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a); break;
-    case 3: hipLaunchKernelGGL(k_dog<3>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a); break;
-    case 2: hipLaunchKernelGGL(k_dog<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a); break;
-    case 1: hipLaunchKernelGGL(k_dog<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a); break;
-    default: hipLaunchKernelGGL(k_dog<0>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a); break;
+  if (partial && dogMinMax) {
+    if (maxBlocks > svp::kDogMaxBlocks) maxBlocks = svp::kDogMaxBlocks;
+    if (blocks > maxBlocks) blocks = maxBlocks;
+    hipLaunchKernelGGL(k_dog<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, firstDog, lastDog);
+    hipLaunchKernelGGL(k_dog_finalize, dim3((unsigned)(lastDog - firstDog)), dim3(256), 0, (hipStream_t)stream, partial,
+                       (unsigned)blocks * 4, firstDog, dogMinMax);
+  } else {
+    if (blocks > 1024) blocks = 1024;  // 4 blocks per CU; each block ends with up to 10 same-address atomics
+    hipLaunchKernelGGL(k_dog<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, firstDog, lastDog);
   }
   SSRLCV_LAUNCH_CHECK();
   return SSRLCV_OK;
 }
 int ssrlcv_hip_dog_normalised_sub(const float* const levels_host[6], const float* levelMinMax, uint32_t w, uint32_t h,
                                   float* const dog_host[5], float* dogMinMax, ssrlcv_stream_t stream) {
-  return launch_dog(levels_host, levelMinMax, w, h, dog_host, dogMinMax, 0, stream);
+  return launch_dog(levels_host, levelMinMax, w, h, dog_host, dogMinMax, 0, svp::kDog, 1024, nullptr, stream);
 }
 
 // ---- plan ------------------------------------------------------------------------------------------------------------
@@ -1309,6 +1955,7 @@ int ssrlcv_sift_plan_create(uint32_t w, uint32_t h, const ssrlcv_sift_params* pa
     }
   }
   p->off_extremaCounts = take(256);
+  p->off_dogPartial = take(sizeof(float) * 2 * svp::kDog * svp::kDogMaxWaves);
   p->total = off;
   p->maxFeatures = maxFeat;
   *out = p;
@@ -1355,6 +2002,40 @@ int ssrlcv_sift_plan_level(const ssrlcv_sift_plan* plan, void* workspace, int ki
 }
 
 // ScaleSpace::ScaleSpace with makeDOG = true (src/FeatureFactory.cu:338-440)
+namespace {
+// DoG schedule.  Default: on octaves of >= 2^24 pixels the DoG levels 0..2 start on the side stream as soon as gaussian
+// level 3 is complete, beside the FMA-bound convolutions of levels 4 and 5 (which leave half of the HBM bandwidth idle);
+// the rest follows after level 5 as before.  Measured on a 4096^2 image: 2.071 -> 2.006 ms (the split re-reads level 3:
+// +0.27 GB; cuts at 2 and 4, at 4 only, or on octave 1 as well were slower or equal).
+// SSRLCV_DOG_CUTS="o:b,b;o:b" (developer switch) replaces it: after gaussian level b of octave o, the DoG levels below b
+// that are not yet made are launched; "" = no early launches.  SSRLCV_DOG_EARLY_BLOCKS / SSRLCV_DOG_BLOCKS = grid sizes.
+struct DogSchedule {
+  unsigned cutMask[svp::kOctaves];
+  unsigned earlyBlocks, blocks;
+  bool atomics, binLate, fromEnv;
+  DogSchedule() {
+    for (unsigned& m : cutMask) m = 0;
+    earlyBlocks = 1024;
+    if (const char* e = getenv("SSRLCV_DOG_EARLY_BLOCKS")) earlyBlocks = (unsigned)atoi(e) > 0 ? (unsigned)atoi(e) : 1024;
+    blocks = 1024;
+    if (const char* e = getenv("SSRLCV_DOG_BLOCKS")) blocks = (unsigned)atoi(e) > 0 ? (unsigned)atoi(e) : 1024;
+    atomics = getenv("SSRLCV_DOG_ATOMICS") != nullptr;
+    binLate = getenv("SSRLCV_BIN_LATE") != nullptr;
+    const char* c = getenv("SSRLCV_DOG_CUTS");
+    fromEnv = c != nullptr;
+    if (!c) return;
+    int o = -1;
+    for (const char* p = c; *p; ++p) {
+      if (*p >= '0' && *p <= '9') {
+        const int v = *p - '0';
+        if (p[1] == ':') { o = v < svp::kOctaves ? v : -1; ++p; }
+        else if (o >= 0 && v >= 1 && v < svp::kGauss - 1) cutMask[o] |= 1u << v;
+      }
+    }
+  }
+};
+}  // namespace
+
 int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixels, void* workspace,
                               ssrlcv_stream_t stream) {
   if (!plan || !pixels || !workspace) return SSRLCV_ERR_INVALID_ARG;
@@ -1367,6 +2048,8 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
   // two sets of gaussian buffers so that octave o+1 never overwrites what DoG(o) is still reading.
   svp::PlanAsync* as = svp::plan_async(plan);
   hipStream_t sd = as ? as->table : st;
+  static const DogSchedule sched;
+  float* dogPartial = sched.atomics ? nullptr : (float*)(ws + plan->off_dogPartial);
   hipLaunchKernelGGL(k_init_minmax, dim3(1), dim3(64), 0, st, mmAll, pairs);
   // S1+S2: u8 -> f32 + one 2x upsample (startingOctave = -1)
   float* in = (float*)(ws + plan->off_in0);
@@ -1397,7 +2080,7 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
     const size_t* offGauss = (o & 1) ? plan->off_gauss1 : plan->off_gauss;
     if (as && o >= 2) SSRLCV_HIP_TRY(hipStreamWaitEvent(st, as->dogDone[o - 2], 0));  // buffer set free again
     const float* src = in;
-    const float* lv[svp::kGauss];
+    const float* lv[svp::kGauss] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     float* dogs[svp::kDog];
     for (int b = 0; b < svp::kDog; ++b) dogs[b] = (float*)(ws + oc.off_dog[b]);
     // DoG level b - 2 rides in the loader of the convolution that produces level b (it streams level b - 1 anyway, and
@@ -1420,18 +2103,29 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
       if (rc) return rc;
       lv[b] = dst;
       src = dst;
-    }
-    if (o + 1 < svp::kOctaves) {
-      // next octave input = 2x2 bin of the UN-normalised level 3 (src/FeatureFactory.cu:392-399)
-      rc = ssrlcv_hip_bin2x(lv[3], oc.w, oc.h, nextIn[o], stream);
-      if (rc) return rc;
-      in = nextIn[o];
+      if (b == (sched.binLate ? svp::kGauss - 1 : 3) && o + 1 < svp::kOctaves) {
+        // next octave input = 2x2 bin of the UN-normalised level 3 (src/FeatureFactory.cu:392-399)
+        rc = ssrlcv_hip_bin2x(lv[3], oc.w, oc.h, nextIn[o], stream);
+        if (rc) return rc;
+        in = nextIn[o];
+      }
+      // split schedule: the DoG levels whose operands are complete start on the side stream while the remaining (FMA-bound)
+      // convolutions of this octave run -- with a small grid, so that they take the HBM bandwidth those leave idle
+      // instead of crowding them out
+      const bool cutHere = sched.fromEnv ? ((sched.cutMask[o] >> b) & 1) != 0 : (b == 3 && (size_t)oc.w * oc.h >= ((size_t)1 << 24));
+      if (as && b < svp::kGauss - 1 && cutHere && b > firstDog) {
+        SSRLCV_HIP_TRY(hipEventRecord(as->levelDone[o][b], st));
+        SSRLCV_HIP_TRY(hipStreamWaitEvent(sd, as->levelDone[o][b], 0));
+        rc = launch_dog(lv, mm, oc.w, oc.h, dogs, mm + 2 * svp::kGauss, firstDog, b, sched.earlyBlocks, dogPartial, (ssrlcv_stream_t)sd);
+        if (rc) return rc;
+        firstDog = b;
+      }
     }
     if (as) {
       SSRLCV_HIP_TRY(hipEventRecord(as->convDone[o], st));
       SSRLCV_HIP_TRY(hipStreamWaitEvent(sd, as->convDone[o], 0));
     }
-    rc = launch_dog(lv, mm, oc.w, oc.h, dogs, mm + 2 * svp::kGauss, firstDog, (ssrlcv_stream_t)sd);
+    rc = launch_dog(lv, mm, oc.w, oc.h, dogs, mm + 2 * svp::kGauss, firstDog, svp::kDog, sched.blocks, dogPartial, (ssrlcv_stream_t)sd);
     if (rc) return rc;
     if (as) SSRLCV_HIP_TRY(hipEventRecord(as->dogDone[o], sd));
   }

@@ -72,10 +72,14 @@ struct OctavePlan {
 // polar tables earlier, beside the convolutions of octaves 1-3, was measured too: the convolutions lose as much as the
 // chain gains (every one of these kernels fills the chip on its own), so the order below is kept.
 // One call per plan may be in flight at a time.
+constexpr unsigned kDogMaxBlocks = 16384;               // grid bound of the streaming DoG kernel (256-thread blocks)
+constexpr unsigned kDogMaxWaves = kDogMaxBlocks * 4;
+
 struct PlanAsync {
   hipStream_t chain, table;
   hipEvent_t fork;
   hipEvent_t join[kOctaves + 1], convDone[kOctaves], dogDone[kOctaves], polarDone[kOctaves];
+  hipEvent_t levelDone[kOctaves][kGauss];  // build_dog: gaussian level b of octave o complete (split DoG schedule)
 };
 
 }  // namespace svp
@@ -96,6 +100,7 @@ struct ssrlcv_sift_plan {
   size_t off_minmax;   // floats: [oct][kGauss + kDog][2]
   size_t off_state;    // OctaveState[kOctaves]
   size_t off_extremaCounts;  // scratch for the pixel-domain partition
+  size_t off_dogPartial;     // per-wave {min, max} partials of the streaming DoG kernel: float[2 * kDog][kDogMaxWaves]
   size_t total;
   uint32_t maxFeatures;
   int stopStage;

@@ -249,3 +249,50 @@ def test_degenerate_images_match_oracle(capi, oracle_lib, kind):
     # bit for bit, the single pixel included: its mirror symmetry leaves exactly tied histogram peaks, and which of two
     # tied bins wins is decided by the last bit of expf / atan2f -- the same bit on both sides now (sv_math.h)
     H.assert_features_equal(gf, of)
+
+
+_CONV_SCRIPT = r"""
+import ctypes, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import numpy as np
+import helpers as H
+from ssrlcv_amd import capi
+lib = H.oracle()
+n = 0
+for (w, h) in [(512, 264), (1024, 200), (256, 1100), (384, 136), (1000, 72)]:
+    for sigma in (0.70710678, 1.0, 1.4142135, 2.0, 2.828427, 4.0):
+        taps, wgt = capi.gauss_kernel(sigma, 0.5)
+        rng = np.random.default_rng(w + h + taps)
+        src = (rng.standard_normal((h, w)) * 40 + 120).astype(np.float32)
+        ref = np.zeros((h, w), np.float32)
+        lib.oracle_conv_separable(H.P(src), ctypes.c_uint32(w), ctypes.c_uint32(h), ctypes.c_int(taps), H.P(wgt), H.P(ref))
+        out_d, mm_d = capi.gauss_sep_conv(capi.to_dev(src), w, h, wgt)
+        out = out_d.cpu().numpy().reshape(h, w)
+        assert np.array_equal(out, ref), (w, h, taps, int((out != ref).sum()))
+        mm = mm_d.cpu().numpy()
+        assert mm[0] == ref.min() and mm[1] == ref.max(), (w, h, taps)
+        n += 1
+print("CONV OK", n)
+"""
+
+
+@pytest.mark.parametrize("variant", [
+    {"SSRLCV_GAUSS_TILE_MAXPX": "0"},                                   # marching kernels: strips, k_gauss_mfma2 (128 columns)
+    {"SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_GAUSS_WIDE": "1"},         # 256-column strips
+    {"SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_GAUSS_MFMA1": "1"},        # first-edition MFMA kernel
+    {"SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_GAUSS_MFMA_MINR": "6"},    # MFMA for every radius
+    {"SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_GAUSS_MFMA_MINR": "6", "SSRLCV_GAUSS_WIDE": "1"},
+    {"SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_GAUSS_VALU": "1"},         # VALU formulation for every radius
+    {"SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_GAUSS_ELEMENTWISE": "1", "SSRLCV_GAUSS_MFMA1": "1"},
+], ids=lambda v: "+".join(k.replace("SSRLCV_GAUSS_", "") + "=" + x for k, x in v.items()))
+def test_every_gaussian_formulation_is_bit_exact(variant):
+    """The formulation is chosen per process (environment) and by level size: the default suite reaches the tile kernel
+    on its small images; the marching kernels (VALU strips, both MFMA editions, 128- and 256-column strips) are run here
+    in child processes on sizes with full and partial strips, each against the oracle bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **variant)
+    r = subprocess.run([sys.executable, "-c", _CONV_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "CONV OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

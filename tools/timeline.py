@@ -15,7 +15,8 @@ def main():
     c = sqlite3.connect(sys.argv[1])
     lim = int(sys.argv[2]) if len(sys.argv) > 2 else 400
     rows = c.execute("select name,start,end,stream_id from kernels order by start").fetchall()
-    ups = [i for i, r in enumerate(rows) if "k_upsample2x" in r[0]]
+    # every build_dog call starts with k_init_minmax
+    ups = [i for i, r in enumerate(rows) if "k_init_minmax" in r[0]]
     i0 = ups[-1]
     t0 = rows[i0][1]
     for r in rows[i0:i0 + lim]:
