@@ -187,6 +187,8 @@ struct ConvArgs {
   float* dogOut;              // DoG level b
   const float* dogLvlMinMax;  // {min_b, max_b, min_b+1, max_b+1}
   float* dogMinMax;           // {min, max} of DoG level b (atomics)
+  // k_gauss_mfma2 / k_gauss_tile: also emit the 2x2 bin of the output (S5, the next octave's input) from the accumulators
+  float* binOut;  // (w/2) x (h/2), nullptr: no bin
   float wgt[33];  // taps are symmetric (w[k] == w[2R-k] bit for bit): only k = 0..R travel, in SGPRs
 #ifdef SSRLCV_LAB
   long long* stamps;  // tools/gauss_lab.hip: s_memtime stamps of one block, [wave][step][8]
@@ -797,6 +799,23 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma(ConvArgs a) {
   if (emitDog) block_minmax_commit(dmn, dmx, a.dogMinMax, s_mem);
 }
 
+// S5 folded into a vertical-pass epilogue: lane (li, lk) holds four consecutive x of output row y (= row li of a 16-row
+// tile that starts on an even row); the row below sits in lane li ^ 1 of the same quad (DPP quad_perm [1,0,3,2]).  Even
+// lanes then form binImage's ((r0.x + r1.x) + r0.y + r1.y) / 4 (src/Image.cu:1380-1392) for their two column pairs and
+// store them -- the level is not read again by a bin kernel.  `valid`: both rows and all four columns are inside the image.
+__device__ __forceinline__ void bin2x_from_tile(const f32x4 v, bool valid, float* __restrict__ binOut, size_t binIndex /* of the first pair */) {
+  float p[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    p[r] = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (float)v[r]), 0xB1, 0xF, 0xF, true));
+  if (valid && (threadIdx.x & 1) == 0) {
+    const float s0 = v[0] + p[0] + v[1] + p[1];  // reference operand order (left to right)
+    const float s1 = v[2] + p[2] + v[3] + p[3];
+    typedef float f32x2b __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<f32x2b*>(binOut + binIndex) = f32x2b{s0 / 4.0f, s1 / 4.0f};
+  }
+}
+
 // ---- k_gauss_mfma, second edition: the same products with (almost) no vector instruction beside them ----------------
 // An f32 MFMA runs on the SIMD's fp32 FMA lanes (v_mfma_f32_16x16x4_f32 issues at the vector fp32 rate and
 // SQ_VALU_MFMA_COEXEC_CYCLES is 0 on these kernels): while one executes, no vector-ALU instruction of EITHER wave of the
@@ -946,6 +965,13 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma2(ConvArgs a) {
   auto store_pending = [&]() {
     const int jbase = pendJ;  // uniform
     char* const orow = reinterpret_cast<char*>(a.out) + (size_t)(long)(y0 + jbase) * (size_t)W * 4u;
+    if (a.binOut) {  // uniform; li == lane & 15 has the parity of threadIdx.x
+      const int j = jbase + li;
+      const bool pairOk = j >= 0 && (j | 1) < nrows;  // this row and its partner (rows 2m, 2m + 1 share a tile: jbase is even)
+      const size_t bi = (size_t)((y0 + j) >> 1) * (size_t)(W >> 1) + (size_t)((x0 + (w4 * TPW) * 16 + lk * 4) >> 1);
+#pragma unroll
+      for (int t4 = 0; t4 < TPW; ++t4) bin2x_from_tile(pend[t4], pairOk, a.binOut, bi + (size_t)t4 * 8);
+    }
     if (jbase >= 0 && jbase + kMT <= nrows) {
 #pragma unroll
       for (int t4 = 0; t4 < TPW; ++t4) *reinterpret_cast<f32x4*>(orow + vOut + t4 * 64) = pend[t4];
@@ -1128,22 +1154,28 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma2(ConvArgs a) {
 
 // ---- S4 for the small levels: one tile per block, no marching ---------------------------------------------------------
 // The marching kernels pay a 2R-row warm-up and one barrier per 8 or 16 rows; a 1024^2 or 2048^2 level gives them 64 to
-// 256 blocks of 8 to 12 sequential steps each -- 16 to 60 us per level for work the chip does in 2 (octaves 2 and 3: 0.40 ms
+// 512 blocks of 8 to 12 sequential steps each -- 16 to 60 us per level for work the chip does in 2 (octaves 2 and 3: 0.40 ms
 // of a 2.2 ms pyramid for 8 % of its pixels).  Here a block owns a 64 x 64 output tile: it stages the (64 + 2R)-row input
-// region once, its 8 waves run the horizontal pass of all row groups side by side, one barrier, then the vertical pass
-// of the 16 output tiles, two per wave.  Same banded-Toeplitz MFMA chains in the same k order as k_gauss_mfma (the
-// operands come from the same relative LDS positions), so the result is bit-identical.  The halo makes the block read
-// 4x and compute 2-3x what it writes: only for levels that are latency-bound anyway (they sit in L2).
+// region once (every load of a wave in flight at the same time), its 8 waves run the horizontal pass of the (up to 8) row
+// groups side by side and keep the result in registers across a barrier, so that the H rows can go where the input was:
+// the tile needs 50 to 67 KB of LDS, two blocks share a CU and one block's loads run under the other's MFMAs.  Then the
+// vertical pass of the 16 output tiles, two per wave.  Same banded-Toeplitz MFMA chains in the same k order as
+// k_gauss_mfma (the operands come from the same relative LDS positions), so the result is bit-identical.  The halo makes
+// the block read 4x and compute 2-3x what it writes: only for levels that are latency-bound anyway (they sit in L2).
 template <int R>
 struct TileCfg {
   static constexpr int TW = 64, TH = 64;
   static constexpr int K = 16 + 2 * R, KS = (K + 3) / 4, KP = KS * 4, RP = (R + 3) / 4 * 4;
   static constexpr int HR = (TH + 2 * R + 15) / 16 * 16;  // staged input rows = rows of the horizontal pass
+  static_assert(HR / 16 <= 8, "one row group per wave");
   static constexpr int CW = TW + 2 * RP + (KP - K);       // staged columns the A operands reach
-  static constexpr int SW = (CW + 4 + 29) / 32 * 32 + 2;  // == 2 (mod 32): conflict-free A reads (see MfmaCfg)
+  static constexpr int SW = CW % 4 == 2 ? CW : CW + 2;    // == 2 (mod 4): 2 x odd (mod 32), conflict-free A reads (see MfmaCfg)
+  static_assert(CW % 2 == 0 && SW % 4 == 2, "stage row stride");
   static constexpr int RSTR = TW + 16;                    // == 16 (mod 32)
+  static_assert(RSTR <= SW, "the H rows reuse the input's LDS");
   static constexpr int NC = (CW + 63) / 64;               // staged floats per lane and row
-  static constexpr size_t ldsBytes = sizeof(float) * ((size_t)HR * SW + (size_t)HR * RSTR);
+  static constexpr int RPW = HR / 8;                      // staged rows per wave
+  static constexpr size_t ldsBytes = sizeof(float) * (size_t)HR * SW;
 };
 constexpr int kTileThreads = 512;
 
@@ -1151,8 +1183,8 @@ template <int R>
 __global__ __launch_bounds__(kTileThreads) void k_gauss_tile(ConvArgs a) {
   using C = TileCfg<R>;
   extern __shared__ __attribute__((aligned(16))) float s_mem[];
-  float* s_in = s_mem;                  // [HR][SW]
-  float* s_h = s_mem + C::HR * C::SW;   // [HR][RSTR]
+  float* s_in = s_mem;  // [HR][SW], then
+  float* s_h = s_mem;   // [HR][RSTR] in the same place
   const int W = (int)a.w, H = (int)a.h;
   const int x0 = blockIdx.x * C::TW, y0 = blockIdx.y * C::TH;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1165,7 +1197,8 @@ __global__ __launch_bounds__(kTileThreads) void k_gauss_tile(ConvArgs a) {
     tz[s] = (t >= 0 && t <= 2 * R) ? a.wgt[ti < 0 ? 0 : ti] : 0.0f;
   }
   // ---- stage rows y0 - R .. y0 - R + HR - 1, columns x0 - RP .. x0 - RP + CW - 1 (mirrored into the image; what lies
-  // beyond W - 1 + R / H - 1 + R only meets zero weights or outputs that are not stored and re-reads a valid pixel)
+  // beyond W - 1 + R / H - 1 + R only meets zero weights or outputs that are not stored and re-reads a valid pixel).
+  // Wave w owns rows w * RPW .. + RPW - 1; all of its loads are issued before the first LDS write.
   int gx[C::NC];
 #pragma unroll
   for (int i = 0; i < C::NC; ++i) {
@@ -1175,11 +1208,11 @@ __global__ __launch_bounds__(kTileThreads) void k_gauss_tile(ConvArgs a) {
     x = x > W - 1 ? 2 * W - 1 - x : x;
     gx[i] = x;
   }
-  constexpr int RB = 4;  // rows in flight per wave
-  for (int r0 = wave * RB; r0 < C::HR; r0 += 8 * RB) {
-    float v[RB][C::NC];
+  {
+    float v[C::RPW][C::NC];
+    const int r0 = wave * C::RPW;
 #pragma unroll
-    for (int k = 0; k < RB; ++k) {
+    for (int k = 0; k < C::RPW; ++k) {
       int y = y0 - R + r0 + k;  // wave-uniform
       y = y > H - 1 + R ? H - 1 + R : y;
       y = y < 0 ? -1 - y : y;
@@ -1189,7 +1222,7 @@ __global__ __launch_bounds__(kTileThreads) void k_gauss_tile(ConvArgs a) {
       for (int i = 0; i < C::NC; ++i) v[k][i] = row[gx[i]];
     }
 #pragma unroll
-    for (int k = 0; k < RB; ++k) {
+    for (int k = 0; k < C::RPW; ++k) {
 #pragma unroll
       for (int i = 0; i < C::NC; ++i)
         if ((i + 1) * 64 <= C::CW || i * 64 + lane < C::CW) s_in[(r0 + k) * C::SW + i * 64 + lane] = v[k][i];
@@ -1198,12 +1231,13 @@ __global__ __launch_bounds__(kTileThreads) void k_gauss_tile(ConvArgs a) {
 #pragma unroll
   for (int s = 0; s < C::KS; ++s) asm volatile("" : "+v"(tz[s]));
   __syncthreads();
-  // ---- horizontal pass: row group g (16 rows) x 4 column tiles per wave
-  for (int g = wave; g < C::HR / 16; g += 8) {
-    const float* arow = s_in + (16 * g + li) * C::SW + (C::RP - R) + lk;
-    f32x4 acc[4];
+  // ---- horizontal pass: row group `wave` (16 rows) x 4 column tiles, kept in registers until every wave has read its input
+  f32x4 acc[4];
 #pragma unroll
-    for (int t4 = 0; t4 < 4; ++t4) acc[t4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int t4 = 0; t4 < 4; ++t4) acc[t4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  const bool hasGroup = wave < C::HR / 16;  // uniform
+  if (hasGroup) {
+    const float* arow = s_in + (16 * wave + li) * C::SW + (C::RP - R) + lk;
     float av[3][4];
 #pragma unroll
     for (int t4 = 0; t4 < 4; ++t4) av[0][t4] = arow[t4 * 16];
@@ -1222,9 +1256,12 @@ __global__ __launch_bounds__(kTileThreads) void k_gauss_tile(ConvArgs a) {
       for (int t4 = 0; t4 < 4; ++t4) acc[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks % 3][t4], tz[ks], acc[t4], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+  }
+  __syncthreads();  // the input is consumed: its LDS becomes the H rows
+  if (hasGroup) {
 #pragma unroll
     for (int t4 = 0; t4 < 4; ++t4) {
-      float* dst = s_h + (16 * g + lk * 4) * C::RSTR + t4 * 16 + li;
+      float* dst = s_h + (16 * wave + lk * 4) * C::RSTR + t4 * 16 + li;
       dst[0] = acc[t4][0];
       dst[C::RSTR] = acc[t4][1];
       dst[2 * C::RSTR] = acc[t4][2];
@@ -1266,6 +1303,14 @@ __global__ __launch_bounds__(kTileThreads) void k_gauss_tile(ConvArgs a) {
     }
     const int gy = y0 + 16 * rt + li;
     const bool vec4 = (W & 3) == 0 && (reinterpret_cast<size_t>(a.out) & 15) == 0;
+    if (a.binOut) {  // uniform
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const int gxo = x0 + (ct0 + t2) * 16 + lk * 4;
+        const bool pairOk = (gy | 1) < H && gxo + 3 < W;  // launch_conv folds the bin only for even W, H with W % 4 == 0
+        bin2x_from_tile(pend[t2], pairOk, a.binOut, (size_t)(gy >> 1) * (size_t)(W >> 1) + (size_t)(gxo >> 1));
+      }
+    }
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {
       const int gxo = x0 + (ct0 + t2) * 16 + lk * 4;
@@ -1478,8 +1523,11 @@ bool dog_fusable(const float* in, uint32_t w, uint32_t h, int taps) {
   const uint32_t tw = wide ? 256 : 128;
   return (w & 3) == 0 && (reinterpret_cast<size_t>(in) & 15) == 0 && w % tw == 0;
 }
+// binOut (nullable): where the 2x2 bin of the result may be written by the convolution itself; *binned tells whether it was
+// (only k_gauss_mfma2 / k_gauss_tile do it, for even sizes with W % 4 == 0) -- otherwise the caller runs k_bin2x
 int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h, int taps, const float* weights_host,
-                float* minmax, hipStream_t st, const uint8_t* u8src = nullptr, const DogFuse* dog = nullptr) {
+                float* minmax, hipStream_t st, const uint8_t* u8src = nullptr, const DogFuse* dog = nullptr,
+                float* binOut = nullptr, bool* binned = nullptr) {
   if (taps < 1 || (taps & 1) == 0 || taps > svp::kMaxTaps) return SSRLCV_ERR_INVALID_ARG;
   int R = taps / 2;
   if (R > 32) return SSRLCV_ERR_UNSUPPORTED;  // the pipeline's sigma ladder never exceeds 65 taps
@@ -1491,6 +1539,10 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
   a.w = w;
   a.h = h;
   a.x0base = 0;
+  a.binOut = nullptr;
+  if (binned) *binned = false;
+  static const bool noBinFold = getenv("SSRLCV_NO_BIN_FUSION") != nullptr;
+  const bool canBin = binOut && !noBinFold && (w & 3) == 0 && (h & 1) == 0 && (reinterpret_cast<size_t>(binOut) & 7) == 0;
 #ifdef SSRLCV_LAB
   a.stamps = g_lab_stamps;
 #endif
@@ -1537,6 +1589,7 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
   // the threshold (0 = never).
   static const size_t tileMaxPx = getenv("SSRLCV_GAUSS_TILE_MAXPX") ? (size_t)atoll(getenv("SSRLCV_GAUSS_TILE_MAXPX")) : ((size_t)1 << 20);
   if (!u8src && !dog && !forceValu && (size_t)w * h <= tileMaxPx) {
+    if (canBin) { a.binOut = binOut; if (binned) *binned = true; }
 #define SSRLCV_LAUNCH_TILE(RR)                                                                                     \
   do {                                                                                                              \
     static bool attr = false;                                                                                       \
@@ -1628,6 +1681,7 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
     if (!noMfma2 && !dog && rowStaging && (reinterpret_cast<size_t>(out) & 15) == 0 && (uint64_t)w * h * 4 < ((uint64_t)1 << 32) &&
         w % (wide || R > 24 ? 256u : 128u) == 0) {
       const int R2 = R <= 6 ? 6 : R <= 8 ? 8 : R <= 12 ? 12 : R <= 16 ? 16 : R <= 24 ? 24 : 32;
+      if (canBin) { a.binOut = binOut; if (binned) *binned = true; }
       memset(a.wgt, 0, sizeof a.wgt);
       for (int k = 0; k <= R; ++k) a.wgt[(R2 - R) + k] = weights_host[k];
 #define SSRLCV_LAUNCH_MFMA2(RR, TW)                                                                                 \
@@ -2012,7 +2066,7 @@ namespace {
 struct DogSchedule {
   unsigned cutMask[svp::kOctaves];
   unsigned earlyBlocks, blocks;
-  bool atomics, binLate, fromEnv;
+  bool atomics, fromEnv;
   DogSchedule() {
     for (unsigned& m : cutMask) m = 0;
     earlyBlocks = 1024;
@@ -2020,7 +2074,6 @@ struct DogSchedule {
     blocks = 1024;
     if (const char* e = getenv("SSRLCV_DOG_BLOCKS")) blocks = (unsigned)atoi(e) > 0 ? (unsigned)atoi(e) : 1024;
     atomics = getenv("SSRLCV_DOG_ATOMICS") != nullptr;
-    binLate = getenv("SSRLCV_BIN_LATE") != nullptr;
     const char* c = getenv("SSRLCV_DOG_CUTS");
     fromEnv = c != nullptr;
     if (!c) return;
@@ -2098,15 +2151,20 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
         dfp = &df;
         firstDog = b - 1;
       }
+      // next octave input = 2x2 bin of the UN-normalised level 3 (src/FeatureFactory.cu:392-399): written by level 3's
+      // convolution itself where that kernel can (see launch_conv), by k_bin2x otherwise
+      bool binned = false;
       rc = launch_conv(src, dst, nullptr, oc.w, oc.h, oc.taps[b], oc.weights[b], mm + 2 * b, st,
-                       (fuseUpsample && o == 0 && b == 0) ? pixels : nullptr, dfp);
+                       (fuseUpsample && o == 0 && b == 0) ? pixels : nullptr, dfp,
+                       (b == 3 && o + 1 < svp::kOctaves) ? nextIn[o] : nullptr, &binned);
       if (rc) return rc;
       lv[b] = dst;
       src = dst;
-      if (b == (sched.binLate ? svp::kGauss - 1 : 3) && o + 1 < svp::kOctaves) {
-        // next octave input = 2x2 bin of the UN-normalised level 3 (src/FeatureFactory.cu:392-399)
-        rc = ssrlcv_hip_bin2x(lv[3], oc.w, oc.h, nextIn[o], stream);
-        if (rc) return rc;
+      if (b == 3 && o + 1 < svp::kOctaves) {
+        if (!binned) {
+          rc = ssrlcv_hip_bin2x(lv[3], oc.w, oc.h, nextIn[o], stream);
+          if (rc) return rc;
+        }
         in = nextIn[o];
       }
       // split schedule: the DoG levels whose operands are complete start on the side stream while the remaining (FMA-bound)
