@@ -296,3 +296,47 @@ def test_every_gaussian_formulation_is_bit_exact(variant):
     env = dict(os.environ, **variant)
     r = subprocess.run([sys.executable, "-c", _CONV_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "CONV OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+_PYRAMID_SCRIPT = r"""
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import numpy as np
+import helpers as H
+from ssrlcv_amd import capi
+lib = H.oracle()
+for (w, h) in [(512, 384), (262, 260)]:
+    img = H.synthetic_image(w, h, seed=5)
+    osf = H.OracleSift(lib, img)
+    plan = capi.SiftPlan(w, h)
+    plan.build_dog(capi.to_dev(img))
+    for o in range(4):
+        for b in range(5):
+            lvl, (mn, mx) = plan.level(0, o, b)
+            ref = osf.level(1, o, b)
+            assert np.array_equal(lvl, ref), (w, h, o, b, int((lvl != ref).sum()))
+            assert (mn, mx) == osf.minmax(1, o, b), (w, h, o, b)
+    osf.close()
+print("PYRAMID OK")
+"""
+
+
+@pytest.mark.parametrize("variant", [
+    {"SSRLCV_NO_BIN_FUSION": "1"},                                  # 2x2 bin by k_bin2x instead of the level-3 convolution
+    {"SSRLCV_DOG_ATOMICS": "1"},                                    # DoG min / max by block atomics instead of partials + finalize
+    {"SSRLCV_DOG_CUTS": "0:2,4;1:3;2:1,2,3,4"},                     # split DoG launches beside the convolutions
+    {"SSRLCV_DOG_CUTS": "", "SSRLCV_DOG_BLOCKS": "4096"},           # no early launch, a large DoG grid
+    {"SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_SIFT_SERIAL": "1"},    # marching kernels only, one stream
+    {"SSRLCV_GAUSS_TILE_MAXPX": "100000000"},                       # tile kernel for every level
+], ids=lambda v: "+".join(k.replace("SSRLCV_", "") + "=" + x for k, x in v.items()))
+def test_every_pyramid_schedule_is_bit_exact(variant):
+    """build_dog's developer switches (who makes the 2x2 bin, how the DoG kernel reduces min / max and when it is launched,
+    which Gaussian kernel a level takes) change the schedule, never a bit: every DoG level and its {min, max} against the
+    oracle, in child processes (the switches are read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **variant)
+    r = subprocess.run([sys.executable, "-c", _PYRAMID_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "PYRAMID OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

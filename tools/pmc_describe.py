@@ -13,7 +13,7 @@ DESCRIBE = ("k_extrema_flags", "k_count", "k_scan", "k_scatter", "k_refine", "k_
 
 
 def short(name):
-    for tok in DESCRIBE + ("k_upsample2x", "k_add_border", "k_gauss_strip", "k_gauss_fused", "k_gauss_mfma", "k_bin2x", "k_dog",
+    for tok in DESCRIBE + ("k_upsample2x", "k_add_border", "k_gauss_strip", "k_gauss_fused", "k_gauss_mfma", "k_gauss_tile", "k_bin2x", "k_dog",
                            "k_init_minmax"):
         if tok in name:
             return tok
