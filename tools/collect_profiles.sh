@@ -1,0 +1,23 @@
+# Developer helper: the rocprofv3 passes behind profiles/rNN_* (run on the GPU box from the repository root).
+# usage: bash tools/collect_profiles.sh <tag> <commit>      e.g. r02_v3 fad0457
+# Writes under gpurun_out/<tag>/: the kernel statistics + JSON line of the bench command, and the reductions of the
+# FETCH_SIZE / WRITE_SIZE / SQ_INSTS passes (pyramid traffic, describe PMC) and of an MFMA-busy pass.
+set -e
+TAG=$1
+COMMIT=$2
+export TMPDIR=/tmp
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-class-api --no-nview > $OUT/bench_line.json 2> $OUT/bench.err
+cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+export SSRLCV_SIFT_SERIAL=1
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_FETCH_SIZE --output-format csv -- python3 tools/bench_sift_stages.py --size 4096 --scene --stages 7 > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_WRITE_SIZE --output-format csv -- python3 tools/bench_sift_stages.py --size 4096 --scene --stages 7 > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d $OUT/pmc_SQ --output-format csv -- python3 tools/bench_sift_stages.py --size 4096 --scene --stages 7 > $OUT/pmc_sq.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE -d $OUT/pmc_MFMA --output-format csv -- python3 tools/bench_sift_stages.py --size 4096 --scene --stages 7 > $OUT/pmc_mfma.log 2>&1
+FEATURES=$(grep "stop=7" $OUT/pmc_sq.log | sed 's/.*n=//')
+python3 tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE 4 $COMMIT > $OUT/pyramid_traffic.json
+python3 tools/pmc_describe.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ 4 $FEATURES $COMMIT > $OUT/describe_pmc.json
+for k in "k_gauss_mfma2<32, 256" "k_gauss_mfma2<24, 256" "k_gauss_mfma2<16, 256" "k_gauss_mfma2<12, 256"; do python3 tools/pmcsum.py "$k" $OUT/pmc_MFMA; done > $OUT/mfma_busy.txt 2>&1 || true
+rm -rf $OUT/stats $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ $OUT/pmc_MFMA
+ls -la $OUT
