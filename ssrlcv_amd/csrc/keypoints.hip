@@ -706,8 +706,12 @@ struct DescConst {
   int32_t segment;      // blur segment of the key point = DoG level its window is sampled from
 };
 static_assert(sizeof(DescConst) == 32, "one s_load_dwordx8");
-__global__ __launch_bounds__(256) void k_desc_consts(const OctaveState* st, const ssrlcv_sskeypoint* kps, float pixelWidth,
-                                                     float lambda, DescConst* __restrict__ out) {
+// one launch for all octaves: blockIdx.y = octave
+__global__ __launch_bounds__(256) void k_desc_consts(const OctaveState* states, OctaveSet set, float lambda) {
+  const OctaveState* st = states + blockIdx.y;
+  const ssrlcv_sskeypoint* kps = set.kps[blockIdx.y];
+  const float pixelWidth = set.pixelWidth[blockIdx.y];
+  DescConst* __restrict__ out = (DescConst*)const_cast<void*>(set.consts[blockIdx.y]);
   const int n = st->hasExtrema ? st->n : 0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     DescConst d;
@@ -1224,8 +1228,16 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
       case 3: hipLaunchKernelGGL(k_thetas<3>, dim3(unitBlocks), dim3(64), 0, caller, states, thetaRanges, set, lambdaO, othr); break;
       default: hipLaunchKernelGGL(k_thetas<4>, dim3(unitBlocks), dim3(64), 0, caller, states, thetaRanges, set, lambdaO, othr); break;
     }
+    // The four expansions are independent three-kernel chains of ~30 us each (launch-bound on the short lists): octave 1's
+    // runs on one side stream, those of octaves 2 and 3 on the other, beside octave 0's on the caller's stream.
+    if (as) {
+      SSRLCV_HIP_TRY(hipEventRecord(as->expandFork, caller));
+      SSRLCV_HIP_TRY(hipStreamWaitEvent(as->chain, as->expandFork, 0));
+      SSRLCV_HIP_TRY(hipStreamWaitEvent(as->table, as->expandFork, 0));
+    }
     for (int o = 0; o < svp::kOctaves; ++o) {
       // thrust::remove of the -FLT_MAX / -1 slots + expandKeyPoints (:594-611): element space n x maxOrientations
+      const hipStream_t es = !as || o == 0 ? caller : (o == 1 ? as->chain : as->table);
       const svp::OctavePlan& oc = plan->oct[o];
       const uint32_t cap = oc.cap;
       const OctaveState* cst = states + o;
@@ -1249,12 +1261,18 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
       uint32_t* totals = nullptr;
       OctaveState* sto = states + o;
       auto post = [=] __device__(const uint32_t* tot) { book_orient(sto, tot, cap); };
-      hipError_t e = svc::partition<svp::kDog, 8>(cap * maxO, keyfn, emit, (uint32_t*)(ws + oc.off_part), &totals, caller,
+      hipError_t e = svc::partition<svp::kDog, 8>(cap * maxO, keyfn, emit, (uint32_t*)(ws + oc.off_part), &totals, es,
                                                   &states[o].n, maxO, post);
       if (e != hipSuccess) return (int)e;
       ssrlcv_sskeypoint* tmp = curBuf[o];
       curBuf[o] = othBuf[o];
       othBuf[o] = tmp;
+    }
+    if (as) {
+      SSRLCV_HIP_TRY(hipEventRecord(as->expandJoin[0], as->chain));
+      SSRLCV_HIP_TRY(hipEventRecord(as->expandJoin[1], as->table));
+      SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->expandJoin[0], 0));
+      SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->expandJoin[1], 0));
     }
   }
   for (int o = 0; o < svp::kOctaves; ++o)
@@ -1263,15 +1281,15 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
   hipLaunchKernelGGL(k_book_featbase, dim3(1), dim3(1), 0, caller, states, featBase, numFeatures, plan->maxFeatures);
   if (stop >= 7) {
     if (!features) return SSRLCV_ERR_INVALID_ARG;
-    uint32_t descBlocks = 0;
+    uint32_t descBlocks = 0, maxBlocks = 1;
     for (int o = 0; o < svp::kOctaves; ++o) {
       const svp::OctavePlan& oc = plan->oct[o];
       set.kps[o] = curBuf[o];
-      hipLaunchKernelGGL(k_desc_consts, dim3(list_blocks(oc.cap)), dim3(256), 0, caller, states + o,
-                         (const ssrlcv_sskeypoint*)curBuf[o], oc.pixelWidth, plan->params.descriptorContribWidth,
-                         (DescConst*)(ws + oc.off_descConst));
       descBlocks += list_blocks(oc.cap);
+      maxBlocks = list_blocks(oc.cap) > maxBlocks ? list_blocks(oc.cap) : maxBlocks;
     }
+    hipLaunchKernelGGL(k_desc_consts, dim3(maxBlocks, svp::kOctaves), dim3(256), 0, caller, states, set,
+                       plan->params.descriptorContribWidth);
     // one launch over every octave's key points, largest windows first (see RangeTable)
     hipLaunchKernelGGL(k_build_ranges, dim3(1), dim3(1), 0, caller, states, descRanges, 0);
     hipLaunchKernelGGL(k_descriptors, dim3(descBlocks * kWaveKernelOversubscription), dim3(256), 0, caller, descRanges, set,

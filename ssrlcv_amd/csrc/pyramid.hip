@@ -1771,6 +1771,8 @@ PlanAsync* plan_async(const ssrlcv_sift_plan* plan) {
         for (hipEvent_t& e : a->convDone) mk(e);
         for (hipEvent_t& e : a->dogDone) mk(e);
         for (hipEvent_t& e : a->polarDone) mk(e);
+        mk(a->expandFork);
+        for (hipEvent_t& e : a->expandJoin) mk(e);
         for (auto& lv : a->levelDone)
           for (hipEvent_t& e : lv) mk(e);
       }

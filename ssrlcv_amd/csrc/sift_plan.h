@@ -79,6 +79,7 @@ struct PlanAsync {
   hipStream_t chain, table;
   hipEvent_t fork;
   hipEvent_t join[kOctaves + 1], convDone[kOctaves], dogDone[kOctaves], polarDone[kOctaves];
+  hipEvent_t expandFork, expandJoin[2];      // describe: the orientation-expansion partitions of octaves 1..3 on the side streams
   hipEvent_t levelDone[kOctaves][kGauss];  // build_dog: gaussian level b of octave o complete (split DoG schedule)
 };
 
