@@ -828,8 +828,8 @@ __device__ __forceinline__ void bin2x_from_tile(const f32x4 v, bool valid, float
 // This edition keeps the products, their order and the LDS layout and removes the vector instructions:
 //  * radii are padded to even values (11 -> 12, 23 -> 24: zero taps, same k-step count), so k-step ks of the vertical
 //    pass reads four rows of ONE 16-row ring tile: tile and in-tile row are compile-time, the tile's slot is scalar;
-//  * every LDS address of a step is formed at the top of the step in ONE batch of v_add (scalar slot / stage offsets
-//    + static lane parts) and pinned; inside the loops there are only MFMAs, LDS and scalar instructions;
+//  * every LDS address of a step is formed at the END of the previous step in ONE batch of v_add (scalar slot / stage
+//    offsets + static lane parts) and pinned; inside the loops there are only MFMAs, LDS and scalar instructions;
 //  * rows are fetched through a buffer descriptor (row = scalar byte offset, lane part static; the mirror only on the
 //    steps that touch the image border), the four halo accesses share one exec region;
 //  * the result is stored through a scalar row base + static lane offset, unmasked on interior steps; min / max are one
@@ -1011,9 +1011,9 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma2(ConvArgs a) {
   // the vertical wave, placed in front of its loop, waited for the END of the horizontal wave's 80 MFMAs, s_setprio or
   // not), so each wave forms the NEXT step's LDS addresses in one batch at the end of its step, behind its last MFMA.
   unsigned aRow = 0, hRow[4] = {0, 0, 0, 0}, sRow = 0, gRow = 0;  // horizontal role: this step's LDS addresses
-  unsigned tb[NC];  // vertical role: LDS addresses (lane part included) of the ring tiles this step reads
+  unsigned rb[C::KS];  // vertical role: LDS address (lane part included) of the first operand of every k-step of this step
 #pragma unroll
-  for (int c = 0; c < NC; ++c) tb[c] = 0;
+  for (int ks = 0; ks < C::KS; ++ks) rb[ks] = 0;
   auto h_addresses = [&](int it, int tph /* (it - 1) mod NT */) {
     const unsigned par = (unsigned)(it & 1) * kStageBytes;  // uniform
     aRow = aLane + par;
@@ -1024,53 +1024,35 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma2(ConvArgs a) {
     gRow = gLane + (kStageBytes - par);
     asm volatile("" : "+v"(aRow), "+v"(hRow[0]), "+v"(hRow[1]), "+v"(hRow[2]), "+v"(hRow[3]), "+v"(sRow), "+v"(gRow));
   };
+  // k-step ks of a vertical pass takes rows (4 ks - D) .. + 3 relative to H tile it - 1, i.e. in-tile row `within` of ring
+  // tile c -- both compile-time; the tile's slot is scalar.  Every k-step gets its own address register here, in the batch:
+  // with one register per tile and the row as an immediate the compiler pairs the reads into ds_read2_b32, whose 8-bit
+  // offsets do not reach the row, and puts a v_add_u32 in front of every k-step -- the vector instruction among MFMAs
+  // this kernel exists to avoid.  (Hand-placed ds_read_b32 with 16-bit immediates and explicit s_waitcnt ran at the same
+  // speed, 0.233 ms at 65 taps, but a register copy the compiler may insert between such a read and its wait would copy
+  // stale data: dropped for the compiler-tracked form.)
   auto v_addresses = [&](int tph /* (it - 1) mod NT */) {
+    unsigned tb[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       int slot = tph + CMIN + c;  // uniform; ring tile c (CMIN .. 0, relative to H tile it - 1) sits in slot (tph + c) mod NT
       slot = slot < 0 ? slot + NT : slot;
-      tb[c] = vLane + (unsigned)slot * kTileBytes;
+      tb[c] = (unsigned)slot * kTileBytes;
     }
 #pragma unroll
-    for (int c = 0; c < NC; ++c) asm volatile("" : "+v"(tb[c]));
-  };
-  // Vertical-pass operand reads: k-step ks takes rows (4 ks - D) .. + 3 relative to H tile it - 1, i.e. in-tile row
-  // `within` of ring tile c -- both compile-time -- so the read is tile address + a 16-bit immediate.  Written as inline
-  // asm: left to the compiler, pairs of reads become ds_read2_b32, whose 8-bit offsets do not reach the row, and every
-  // k-step gets a v_add_u32 for its row -- the vector instruction among MFMAs this kernel exists to avoid.  The reads
-  // are therefore invisible to the compiler's s_waitcnt insertion: the loop waits explicitly (LDS returns in order).
-  float bv[3][TPW];
-  auto v_read = [&](int ks) {
-    const int rel = 4 * ks - D;
-    const int c = (rel >= 0 ? rel / 16 : -((-rel + 15) / 16));
-    const int within = rel - 16 * c;
-#pragma unroll
-    for (int t4 = 0; t4 < TPW; ++t4)
-      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bv[ks % 3][t4]) : "v"(tb[c - CMIN]), "n"((within * C::RSTR + t4 * 16) * 4));
-  };
-  // wait until at most `left` LDS reads are in flight; the operands of k-step ks pass through the statement, so that
-  // nothing that uses them can move in front of it
-  auto v_wait = [&](int ks, int left) {
-    if constexpr (TPW == 4) {
-      if (left == 8) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(bv[ks % 3][0]), "+v"(bv[ks % 3][1]), "+v"(bv[ks % 3][2]), "+v"(bv[ks % 3][3]));
-      else if (left == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bv[ks % 3][0]), "+v"(bv[ks % 3][1]), "+v"(bv[ks % 3][2]), "+v"(bv[ks % 3][3]));
-      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[ks % 3][0]), "+v"(bv[ks % 3][1]), "+v"(bv[ks % 3][2]), "+v"(bv[ks % 3][3]));
-    } else {
-      static_assert(TPW == 4 || TPW == 2, "tiles per wave");
-      if (left == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bv[ks % 3][0]), "+v"(bv[ks % 3][1]));
-      else if (left == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bv[ks % 3][0]), "+v"(bv[ks % 3][1]));
-      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[ks % 3][0]), "+v"(bv[ks % 3][1]));
+    for (int ks = 0; ks < C::KS; ++ks) {
+      const int rel = 4 * ks - D;  // compile-time: first row of the k-step, relative to H tile it - 1
+      const int c = (rel >= 0 ? rel / 16 : -((-rel + 15) / 16));
+      const int within = rel - 16 * c;
+      rb[ks] = vLane + tb[c - CMIN] + (unsigned)(within * C::RSTR) * 4u;
     }
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) asm volatile("" : "+v"(rb[ks]));
   };
-  static_assert((12 * C::RSTR + (TPW - 1) * 16) * 4 < 65536, "ds_read_b32 immediate");
-  static_assert(D >= 12, "the first two k-steps of a vertical pass read tiles that are complete one step earlier");
   if (role == 0) {
     h_addresses(0, NT - 1);
   } else {
     v_addresses(0);  // step 1 reads relative to H tile 0
-    v_read(0);       // (zeros so far: step 1's first rows lie above the strip)
-    v_read(1);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   __syncthreads();
   int tphase = NT - 1;  // ((it - 1) mod NT) for it = 0
@@ -1122,12 +1104,17 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma2(ConvArgs a) {
       if (it >= 1 && jbase + kMT > 0 && jbase < nrows) {  // uniform
 #pragma unroll
         for (int t4 = 0; t4 < TPW; ++t4) pend[t4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        // the operands of k-steps 0 and 1 were read before the barrier (complete tiles); k-step ks + 2 is requested
-        // before the MFMAs of ks, so at most 3 k-steps (12 reads) are in flight and the oldest 4 belong to ks
+        auto loadB = [&](int ks, float (&dst)[TPW]) {
+#pragma unroll
+          for (int t4 = 0; t4 < TPW; ++t4) dst[t4] = lds_ld(rb[ks] + (unsigned)(t4 * 16) * 4u);
+        };
+        // B operands are read two k-steps ahead of the MFMAs that use them
+        float bv[3][TPW];
+        loadB(0, bv[0]);
+        if (C::KS > 1) loadB(1, bv[1]);
 #pragma unroll
         for (int ks = 0; ks < C::KS; ++ks) {
-          if (ks + 2 < C::KS) v_read(ks + 2);
-          v_wait(ks, ks + 2 < C::KS ? 2 * TPW : ks + 1 < C::KS ? TPW : 0);
+          if (ks + 2 < C::KS) loadB(ks + 2, bv[(ks + 2) % 3]);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int t4 = 0; t4 < TPW; ++t4) pend[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[ks % 3][t4], tz[ks], pend[t4], 0, 0, 0);
@@ -1138,12 +1125,7 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma2(ConvArgs a) {
         store_pending();
       }
       LAB_STAMP(2);
-      if (it < steps) {
-        v_addresses(tnext);
-        v_read(0);  // next step's first operands: tiles that are complete already
-        v_read(1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the barrier waits for them anyway; explicit because the compiler does not see these reads)
-      }
+      if (it < steps) v_addresses(tnext);
       LAB_STAMP(3);
     }
     tphase = tnext;
