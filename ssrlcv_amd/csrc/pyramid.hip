@@ -2009,6 +2009,10 @@ void ssrlcv_sift_plan_destroy(ssrlcv_sift_plan* plan) {
     for (hipEvent_t e : a->convDone) (void)hipEventDestroy(e);
     for (hipEvent_t e : a->dogDone) (void)hipEventDestroy(e);
     for (hipEvent_t e : a->polarDone) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(a->expandFork);
+    for (hipEvent_t e : a->expandJoin) (void)hipEventDestroy(e);
+    for (auto& lv : a->levelDone)
+      for (hipEvent_t e : lv) (void)hipEventDestroy(e);
     delete a;
   }
   delete plan;
