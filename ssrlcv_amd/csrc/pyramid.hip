@@ -843,21 +843,6 @@ __device__ __forceinline__ float lds_ld(unsigned a) { return *(const lds_f32*)(s
 __device__ __forceinline__ void lds_st(unsigned a, float v) { *(lds_f32*)(size_t)a = v; }
 __device__ __forceinline__ void lds_st2(unsigned a, f32x2v v) { *(lds_f32x2*)(size_t)a = v; }
 
-// wave priority of the horizontal role: raised for its MFMA loop (see the schedule note in the kernel)
-#ifndef SSRLCV_MFMA2_PRIO
-#define SSRLCV_MFMA2_PRIO 1
-#endif
-#if SSRLCV_MFMA2_PRIO == 1
-#define MFMA2_PRIO_LOOP() __builtin_amdgcn_s_setprio(3)
-#define MFMA2_PRIO_SIDE() __builtin_amdgcn_s_setprio(0)
-#elif SSRLCV_MFMA2_PRIO == 2
-#define MFMA2_PRIO_LOOP() __builtin_amdgcn_s_setprio(0)
-#define MFMA2_PRIO_SIDE() __builtin_amdgcn_s_setprio(3)
-#else
-#define MFMA2_PRIO_SIDE() do { } while (0)
-#define MFMA2_PRIO_LOOP() do { } while (0)
-#endif
-
 template <int R, int TW>
 struct Mfma2Cfg : MfmaCfg<R, TW> {
   static constexpr int D = 2 * R;
@@ -1004,9 +989,10 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma2(ConvArgs a) {
     stage_write(sLane, gLane);
     if (steps > 1) fetch(1);
   }
-  // Schedule of a step.  Both waves of a SIMD start their MFMA loops right behind the barrier: the horizontal wave at
-  // high priority (its loop then runs at the full MFMA rate and its ring / stage / fetch work, which has no vector
-  // instruction, proceeds under the vertical wave's MFMAs), the vertical wave in the slots left over and alone afterwards.
+  // Schedule of a step.  Both waves of a SIMD start their MFMA loops right behind the barrier and share the matrix pipe
+  // (stamps: the horizontal wave's 80 MFMAs are through after ~3000 cycles, the vertical wave's after ~5500 = 160 slots:
+  // the pipe is saturated meanwhile); the horizontal wave's ring / stage / fetch work has no vector instruction and
+  // proceeds under the vertical wave's MFMAs.  (s_setprio on either role changed nothing.)
   // Vector instructions of one wave do not issue while the other streams MFMAs (s_memtime: a 20-add address batch of
   // the vertical wave, placed in front of its loop, waited for the END of the horizontal wave's 80 MFMAs, s_setprio or
   // not), so each wave forms the NEXT step's LDS addresses in one batch at the end of its step, behind its last MFMA.
@@ -1061,7 +1047,6 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma2(ConvArgs a) {
     const int tnext = tphase + 1 == NT ? 0 : tphase + 1;  // (it mod NT) = tphase of step it + 1
     if (role == 0) {
       if (it < steps) {
-        MFMA2_PRIO_LOOP();
         f32x4 acc[TPW];
 #pragma unroll
         for (int t4 = 0; t4 < TPW; ++t4) acc[t4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -1083,7 +1068,6 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma2(ConvArgs a) {
           for (int t4 = 0; t4 < TPW; ++t4) acc[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks % 3][t4], tz[ks], acc[t4], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
-        MFMA2_PRIO_SIDE();
         LAB_STAMP(1);
 #pragma unroll
         for (int t4 = 0; t4 < TPW; ++t4) {
