@@ -151,8 +151,9 @@ sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
 import numpy as np, torch
 from ssrlcv_amd import capi
 g = torch.Generator(device="cuda").manual_seed(3)
-img = torch.randint(0, 256, (4096, 4096), dtype=torch.uint8, device="cuda", generator=g)
-plan = capi.SiftPlan(4096, 4096)
+S = int(sys.argv[1])
+img = torch.randint(0, 256, (S, S), dtype=torch.uint8, device="cuda", generator=g)
+plan = capi.SiftPlan(S, S)
 plan.build_dog(img)
 out = []
 for o in range(4):
@@ -163,8 +164,9 @@ print("CHECKSUMS " + " | ".join(out))
 """
 
 
-def test_full_size_pyramid_is_the_same_on_every_kernel_path():
-    """At 4096^2 the pyramid takes paths no small test image reaches by default (256-column MFMA strips on the 8192^2 levels,
+@pytest.mark.parametrize("size", [4096, 8192])
+def test_full_size_pyramid_is_the_same_on_every_kernel_path(size):
+    """At 4096^2 and 8192^2 (BASELINE configs 2-3 and 4) the pyramid takes paths no small test image reaches by default (256-column MFMA strips on the 8192^2 levels,
     the split DoG launch on octaves of >= 2^24 pixels, the bin folded into a wide level-3 launch).  The oracle needs minutes
     there; instead every DoG level and its {min, max} must be bit-equal between the default build_dog and one restricted to
     the formulations the small-image parity tests pin to the oracle (VALU strips only, k_bin2x, one DoG launch with block
@@ -176,7 +178,7 @@ def test_full_size_pyramid_is_the_same_on_every_kernel_path():
     sums = []
     for variant in ({}, {"SSRLCV_GAUSS_VALU": "1", "SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_NO_BIN_FUSION": "1", "SSRLCV_DOG_CUTS": "",
                          "SSRLCV_DOG_ATOMICS": "1", "SSRLCV_SIFT_SERIAL": "1", "SSRLCV_NO_UPSAMPLE_FUSION": "1"}):
-        r = subprocess.run([sys.executable, "-c", _CHECKSUM_SCRIPT % {"root": root}], env=dict(os.environ, **variant),
+        r = subprocess.run([sys.executable, "-c", _CHECKSUM_SCRIPT % {"root": root}, str(size)], env=dict(os.environ, **variant),
                            capture_output=True, text=True, timeout=900)
         line = [l for l in r.stdout.splitlines() if l.startswith("CHECKSUMS ")]
         assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-4000:]
