@@ -184,3 +184,21 @@ def test_full_size_pyramid_is_the_same_on_every_kernel_path(size):
         assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-4000:]
         sums.append(line[0])
     assert sums[0] == sums[1]
+
+
+def test_config2_view_4096_every_feature_equals_the_oracle(capi, oracle_lib):
+    """BASELINE config[2] at its full size: one 4096 x 4096 view of the benchmark's scene generator through both
+    implementations -- every field of every feature (location, sigma, theta, the 128 descriptor bytes) bit-equal.  The
+    oracle takes about a minute here on the GPU box's host cores (OpenMP)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import scene
+    S = 4096
+    imgs, _, _, _ = scene.pinhole_views(1, S)
+    plan = capi.SiftPlan(S, S)
+    plan.extract(imgs[0])
+    got = plan.features_host(H.FEATURE)
+    ref = H.oracle_sift(oracle_lib, imgs[0].cpu().numpy())
+    assert len(got) > 200000
+    H.assert_features_equal(got, ref)
