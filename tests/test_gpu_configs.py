@@ -158,10 +158,12 @@ def _gloo_worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_equal_single_process(capi, tmp_path):
-    """The sharded flow with world size 2 (both ranks on device 0, gloo collectives staged through the host) against
-    world size 1 and the reference's 3-view fixture: same MatchSet on both ranks, same cloud; BA sums to float
-    accumulation accuracy (the all-reduce adds two partial sums)."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_on_one_gpu_equal_single_process(capi, tmp_path, world):
+    """The sharded flow with world size 2 and 4 (all ranks on device 0, gloo collectives staged through the host) against
+    world size 1 and the reference's 3-view fixture: same MatchSet on every rank, same cloud; BA sums to float
+    accumulation accuracy (the all-reduce adds the ranks' partial sums).  With 4 ranks and 3 views / 3 pairs the last rank
+    owns no image and no pair -- what ranks 4..7 see when the 4-view leg of bench.py runs on 8 GPUs."""
     import socket
     import torch.multiprocessing as mp
     from ssrlcv_amd import pipeline
@@ -169,13 +171,14 @@ def test_two_ranks_on_one_gpu_equal_single_process(capi, tmp_path):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    mp.spawn(_gloo_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    ranks = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
+    r0 = ranks[0]
     pix = [capi.to_dev(p).view(1024, 1024) for p in H.load_everest_pixels()]
     seed, _ = H.load_seed_features()
     v = H.load_view("Pipeline3View")
     one = pipeline.reconstruct(pix, v["cameras"], seed_features=seed, ba=True)
-    for r in (r0, r1):
+    for r in ranks:
         assert np.array_equal(r["mm"], one["matches"]) and np.array_equal(r["kp"], one["keypoints"])
         assert np.array_equal(r["pts"], one["points"].cpu().numpy())
         assert np.allclose(r["ba"], one["ba_sums"].cpu().numpy(), rtol=1e-4)
