@@ -365,9 +365,9 @@ def main():
                        "images_per_gpu": args.images, "features_per_image": nfeat, "parallelism": "image-pair shard"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "DoG pyramid stage = ssrlcv_hip_sift_build_dog (u8 upsample, 24 gaussian levels, 3 bin, "
-                                   "4 DoG launches per image); algorithmic bytes 362.25*W*H per image; events bracket the "
-                                   "stage on the launching stream",
+                         "kernel": "DoG pyramid stage = ssrlcv_hip_sift_build_dog (u8 upsample in the first level's loader, 24 "
+                                   "gaussian levels -- the level-3 launches also write the 2x2 bin --, 5 DoG launches per image); "
+                                   "algorithmic bytes 362.25*W*H per image; events bracket the stage on the launching stream",
                          "ms_per_image": pyr_ms},
             "describe": describe_roofline(desc_ms, int(np.mean(nfeat)), W),
         }
@@ -383,7 +383,7 @@ def main():
         if rank == 0:
             line["nview"] = nv
     if rank == 0:
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a single-GPU-run figure
             line["cpu_baseline"] = cpu_baseline(args.cpu_size)
         print(json.dumps(line))
     if dist is not None:
