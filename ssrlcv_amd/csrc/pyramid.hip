@@ -381,24 +381,35 @@ __global__ __launch_bounds__(kTX) void k_gauss_strip(ConvArgs a) {
   const int c0 = (x0 >> 1) + 2 * lane;                  // source column of outputs 4 lane, 4 lane + 1 (even: 2-byte aligned)
   const int c2 = c0 + 2 < uw ? c0 + 2 : uw - 1;
   const int hxm = hx >> 1, hxp = (hx & 1) ? (hxm + 1 < uw ? hxm + 1 : uw - 1) : hxm;
-  auto up_row = [&](int Y, float4& o, float& oh) {
+  // The u8 loads of a row and their conversion are two steps: the loads are issued behind the barrier and fly under the
+  // two passes, the integer sums and conversions run at the end of the step (converted at once, the wave waited for its
+  // byte loads in front of the horizontal pass: 55 % of its cycles in s_waitcnt, SQ_WAIT_ANY).
+  struct RawRow { uint32_t p0, p1, q0, q1, h00, h01, h10, h11; };
+  RawRow rawA = {0, 0, 0, 0, 0, 0, 0, 0}, rawB = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto up_load = [&](int Y, RawRow& r) {
     Y = mirror_row(Y);
     const int ym = Y >> 1, yp = (Y & 1) ? (ym + 1 < uh ? ym + 1 : uh - 1) : ym;
     const uint8_t* r0 = a.u8 + (size_t)ym * uw;
     const uint8_t* r1 = a.u8 + (size_t)yp * uw;
-    const uint32_t p0 = *reinterpret_cast<const uint16_t*>(r0 + c0), p1 = *reinterpret_cast<const uint16_t*>(r1 + c0);
-    const uint32_t a0 = (p0 & 255u) + (p1 & 255u), a1 = (p0 >> 8) + (p1 >> 8), a2 = (uint32_t)r0[c2] + (uint32_t)r1[c2];
+    r.p0 = *reinterpret_cast<const uint16_t*>(r0 + c0);
+    r.p1 = *reinterpret_cast<const uint16_t*>(r1 + c0);
+    r.q0 = r0[c2];
+    r.q1 = r1[c2];
+    if (halo) { r.h00 = r0[hxm]; r.h01 = r0[hxp]; r.h10 = r1[hxm]; r.h11 = r1[hxp]; }
+  };
+  auto up_convert = [&](const RawRow& r, float4& o, float& oh) {
+    const uint32_t a0 = (r.p0 & 255u) + (r.p1 & 255u), a1 = (r.p0 >> 8) + (r.p1 >> 8), a2 = r.q0 + r.q1;
     o.x = (float)(2 * a0) * 0.25f;
     o.y = (float)(a0 + a1) * 0.25f;
     o.z = (float)(2 * a1) * 0.25f;
     o.w = (float)(a1 + a2) * 0.25f;
-    if (halo) oh = (float)((uint32_t)r0[hxm] + (uint32_t)r0[hxp] + (uint32_t)r1[hxm] + (uint32_t)r1[hxp]) * 0.25f;
+    if (halo) oh = (float)(r.h00 + r.h01 + r.h10 + r.h11) * 0.25f;
   };
   auto fetch = [&](int s) {
     const int ybase = y0 - R + s * kNR + 2 * wave;
     if (UPS) {
-      up_row(ybase, preI0, preH0);
-      up_row(ybase + 1, preI1, preH1);
+      up_load(ybase, rawA);
+      up_load(ybase + 1, rawB);
       return;
     }
     const float* r0 = row_of(ybase);
@@ -410,7 +421,14 @@ __global__ __launch_bounds__(kTX) void k_gauss_strip(ConvArgs a) {
       preH1 = r1[hx];
     }
   };
+  auto convert = [&]() {
+    if (UPS) {
+      up_convert(rawA, preI0, preH0);
+      up_convert(rawB, preI1, preH1);
+    }
+  };
   fetch(0);
+  convert();
   const int gx = x0 + tid;
   for (int s = 0; s < steps; ++s) {
     s_in4[2 * wave][RP / 4 + lane] = preI0;
@@ -464,6 +482,7 @@ __global__ __launch_bounds__(kTX) void k_gauss_strip(ConvArgs a) {
         }
       }
     }
+    if (s + 1 < steps) convert();  // UPS: the bytes requested behind the barrier have arrived under the two passes
 #pragma unroll
     for (int k = 0; k < 2 * R; ++k) win[k] = win[k + kNR];
   }
