@@ -1756,6 +1756,7 @@ PlanAsync* plan_async(const ssrlcv_sift_plan* plan) {
         for (hipEvent_t& e : a->convDone) mk(e);
         for (hipEvent_t& e : a->dogDone) mk(e);
         for (hipEvent_t& e : a->polarDone) mk(e);
+        for (hipEvent_t& e : a->binDone) mk(e);
         mk(a->expandFork);
         for (hipEvent_t& e : a->expandJoin) mk(e);
         for (auto& lv : a->levelDone)
@@ -1954,8 +1955,8 @@ int ssrlcv_sift_plan_create(uint32_t w, uint32_t h, const ssrlcv_sift_params* pa
   p->off_in0 = take(P0 * 4);
   p->off_in1 = take(P0 / 4 * 4);
   p->off_in2 = take(P0 / 16 * 4);
-  for (int b = 0; b < svp::kGauss; ++b) p->off_gauss[b] = take(P0 * 4);
-  for (int b = 0; b < svp::kGauss; ++b) p->off_gauss1[b] = take(P0);  // P_1 = P_0 / 4 floats
+  for (int o = 0; o < svp::kOctaves; ++o)
+    for (int b = 0; b < svp::kGauss; ++b) p->off_gauss[o][b] = take((P0 >> (2 * o)) * 4);  // P_o = P_0 / 4^o floats
   p->off_minmax = take(sizeof(float) * 2 * (svp::kGauss + svp::kDog) * svp::kOctaves);
   p->off_state = take(sizeof(svp::OctaveState) * svp::kOctaves);
   uint32_t maxFeat = 0;
@@ -1996,7 +1997,7 @@ int ssrlcv_sift_plan_create(uint32_t w, uint32_t h, const ssrlcv_sift_params* pa
     }
   }
   p->off_extremaCounts = take(256);
-  p->off_dogPartial = take(sizeof(float) * 2 * svp::kDog * svp::kDogMaxWaves);
+  p->off_dogPartial = take(sizeof(float) * 2 * svp::kDog * svp::kDogMaxWaves * svp::kOctaves);  // one region per octave: their DoG kernels may run side by side
   p->total = off;
   p->maxFeatures = maxFeat;
   *out = p;
@@ -2012,6 +2013,7 @@ void ssrlcv_sift_plan_destroy(ssrlcv_sift_plan* plan) {
     for (hipEvent_t e : a->convDone) (void)hipEventDestroy(e);
     for (hipEvent_t e : a->dogDone) (void)hipEventDestroy(e);
     for (hipEvent_t e : a->polarDone) (void)hipEventDestroy(e);
+    for (hipEvent_t e : a->binDone) (void)hipEventDestroy(e);
     (void)hipEventDestroy(a->expandFork);
     for (hipEvent_t e : a->expandJoin) (void)hipEventDestroy(e);
     for (auto& lv : a->levelDone)
@@ -2036,7 +2038,7 @@ int ssrlcv_sift_plan_level(const ssrlcv_sift_plan* plan, void* workspace, int ki
     if (minmax_dev) *minmax_dev = mm + 2 * (svp::kGauss + blur);
   } else if (kind == 1) {
     if (blur < 0 || blur >= svp::kGauss) return SSRLCV_ERR_INVALID_ARG;
-    if (data) *data = (float*)(ws + ((octave & 1) ? plan->off_gauss1[blur] : plan->off_gauss[blur]));
+    if (data) *data = (float*)(ws + plan->off_gauss[octave][blur]);
     if (minmax_dev) *minmax_dev = mm + 2 * blur;
   } else {
     return SSRLCV_ERR_INVALID_ARG;
@@ -2093,7 +2095,8 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
   svp::PlanAsync* as = svp::plan_async(plan);
   hipStream_t sd = as ? as->table : st;
   static const DogSchedule sched;
-  float* dogPartial = sched.atomics ? nullptr : (float*)(ws + plan->off_dogPartial);
+  static const bool overlapOctaves = getenv("SSRLCV_NO_OCTAVE_OVERLAP") == nullptr;
+  static const int overlapFrom = getenv("SSRLCV_OCTAVE_OVERLAP_FROM") ? atoi(getenv("SSRLCV_OCTAVE_OVERLAP_FROM")) : 2;
   hipLaunchKernelGGL(k_init_minmax, dim3(1), dim3(64), 0, st, mmAll, pairs);
   // S1+S2: u8 -> f32 + one 2x upsample (startingOctave = -1)
   float* in = (float*)(ws + plan->off_in0);
@@ -2121,8 +2124,16 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
   for (int o = 0; o < svp::kOctaves; ++o) {
     const svp::OctavePlan& oc = plan->oct[o];
     float* mm = mmAll + (size_t)o * 2 * (svp::kGauss + svp::kDog);
-    const size_t* offGauss = (o & 1) ? plan->off_gauss1 : plan->off_gauss;
-    if (as && o >= 2) SSRLCV_HIP_TRY(hipStreamWaitEvent(st, as->dogDone[o - 2], 0));  // buffer set free again
+    const size_t* offGauss = plan->off_gauss[o];
+    // Octave 2 runs on a side stream: it only needs level 3 of octave 1 (its bin), so its latency-bound levels run beside
+    // levels 4-5 of octave 1; octave 3, back on the caller's stream behind octave 1, then runs beside levels 4-5 of
+    // octave 2.  (Octave 1 stays behind octave 0: levels 4-5 of octave 0 fill every CU's LDS.)
+    const hipStream_t so = (as && overlapOctaves && o >= overlapFrom && ((o - overlapFrom) & 1) == 0) ? as->chain : st;
+    // DoG kernels: octaves 0 and 1 on the DoG side stream (beside the next octave's convolutions); with the overlap the
+    // last two follow their own convolutions on those streams -- behind octave 1's in one in-order stream they were the tail
+    const hipStream_t sdo = (as && overlapOctaves && o >= 2) ? so : sd;  // (o >= 2 whatever the first overlapped octave)
+    float* dogPartial = sched.atomics ? nullptr : (float*)(ws + plan->off_dogPartial) + (size_t)o * 2 * svp::kDog * svp::kDogMaxWaves;
+    if (as && o >= 1) SSRLCV_HIP_TRY(hipStreamWaitEvent(so, as->binDone[o - 1], 0));
     const float* src = in;
     const float* lv[svp::kGauss] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     float* dogs[svp::kDog];
@@ -2145,7 +2156,7 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
       // next octave input = 2x2 bin of the UN-normalised level 3 (src/FeatureFactory.cu:392-399): written by level 3's
       // convolution itself where that kernel can (see launch_conv), by k_bin2x otherwise
       bool binned = false;
-      rc = launch_conv(src, dst, nullptr, oc.w, oc.h, oc.taps[b], oc.weights[b], mm + 2 * b, st,
+      rc = launch_conv(src, dst, nullptr, oc.w, oc.h, oc.taps[b], oc.weights[b], mm + 2 * b, so,
                        (fuseUpsample && o == 0 && b == 0) ? pixels : nullptr, dfp,
                        (b == 3 && o + 1 < svp::kOctaves) ? nextIn[o] : nullptr, &binned);
       if (rc) return rc;
@@ -2153,32 +2164,35 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
       src = dst;
       if (b == 3 && o + 1 < svp::kOctaves) {
         if (!binned) {
-          rc = ssrlcv_hip_bin2x(lv[3], oc.w, oc.h, nextIn[o], stream);
+          rc = ssrlcv_hip_bin2x(lv[3], oc.w, oc.h, nextIn[o], (ssrlcv_stream_t)so);
           if (rc) return rc;
         }
         in = nextIn[o];
+        if (as) SSRLCV_HIP_TRY(hipEventRecord(as->binDone[o], so));
       }
       // split schedule: the DoG levels whose operands are complete start on the side stream while the remaining (FMA-bound)
       // convolutions of this octave run -- with a small grid, so that they take the HBM bandwidth those leave idle
       // instead of crowding them out
       const bool cutHere = sched.fromEnv ? ((sched.cutMask[o] >> b) & 1) != 0 : (b == 3 && (size_t)oc.w * oc.h >= ((size_t)1 << 24));
       if (as && b < svp::kGauss - 1 && cutHere && b > firstDog) {
-        SSRLCV_HIP_TRY(hipEventRecord(as->levelDone[o][b], st));
-        SSRLCV_HIP_TRY(hipStreamWaitEvent(sd, as->levelDone[o][b], 0));
-        rc = launch_dog(lv, mm, oc.w, oc.h, dogs, mm + 2 * svp::kGauss, firstDog, b, sched.earlyBlocks, dogPartial, (ssrlcv_stream_t)sd);
+        SSRLCV_HIP_TRY(hipEventRecord(as->levelDone[o][b], so));
+        SSRLCV_HIP_TRY(hipStreamWaitEvent(sdo, as->levelDone[o][b], 0));
+        rc = launch_dog(lv, mm, oc.w, oc.h, dogs, mm + 2 * svp::kGauss, firstDog, b, sched.earlyBlocks, dogPartial, (ssrlcv_stream_t)sdo);
         if (rc) return rc;
         firstDog = b;
       }
     }
     if (as) {
-      SSRLCV_HIP_TRY(hipEventRecord(as->convDone[o], st));
-      SSRLCV_HIP_TRY(hipStreamWaitEvent(sd, as->convDone[o], 0));
+      SSRLCV_HIP_TRY(hipEventRecord(as->convDone[o], so));
+      SSRLCV_HIP_TRY(hipStreamWaitEvent(sdo, as->convDone[o], 0));
     }
-    rc = launch_dog(lv, mm, oc.w, oc.h, dogs, mm + 2 * svp::kGauss, firstDog, svp::kDog, sched.blocks, dogPartial, (ssrlcv_stream_t)sd);
+    rc = launch_dog(lv, mm, oc.w, oc.h, dogs, mm + 2 * svp::kGauss, firstDog, svp::kDog, sched.blocks, dogPartial, (ssrlcv_stream_t)sdo);
     if (rc) return rc;
-    if (as) SSRLCV_HIP_TRY(hipEventRecord(as->dogDone[o], sd));
+    if (as) SSRLCV_HIP_TRY(hipEventRecord(as->dogDone[o], sdo));
   }
-  if (as) SSRLCV_HIP_TRY(hipStreamWaitEvent(st, as->dogDone[svp::kOctaves - 1], 0));  // sd is in order: joins every DoG
+  if (as) {  // join: every stream a DoG kernel ran on (in-order streams: the last DoG of each covers the earlier ones)
+    for (int o = 0; o < svp::kOctaves; ++o) SSRLCV_HIP_TRY(hipStreamWaitEvent(st, as->dogDone[o], 0));
+  }
   return SSRLCV_OK;
 }
 

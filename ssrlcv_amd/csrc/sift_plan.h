@@ -79,6 +79,7 @@ struct PlanAsync {
   hipStream_t chain, table;
   hipEvent_t fork;
   hipEvent_t join[kOctaves + 1], convDone[kOctaves], dogDone[kOctaves], polarDone[kOctaves];
+  hipEvent_t binDone[kOctaves];              // build_dog: level 3 of octave o and its 2x2 bin are complete
   hipEvent_t expandFork, expandJoin[2];      // describe: the orientation-expansion partitions of octaves 1..3 on the side streams
   hipEvent_t levelDone[kOctaves][kGauss];  // build_dog: gaussian level b of octave o complete (split DoG schedule)
 };
@@ -96,8 +97,8 @@ struct ssrlcv_sift_plan {
   ssrlcv_sift_params params;
   svp::OctavePlan oct[svp::kOctaves];
   size_t off_in0, off_in1, off_in2;
-  size_t off_gauss[svp::kGauss];   // octaves 0, 2
-  size_t off_gauss1[svp::kGauss];  // octaves 1, 3
+  size_t off_gauss[svp::kOctaves][svp::kGauss];  // every octave has its own levels: octave o + 1 is convolved while
+                                                 // DoG(o) still reads octave o, octave o + 2 beside levels 4-5 of o + 1
   size_t off_minmax;   // floats: [oct][kGauss + kDog][2]
   size_t off_state;    // OctaveState[kOctaves]
   size_t off_extremaCounts;  // scratch for the pixel-domain partition
