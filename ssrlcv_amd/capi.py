@@ -197,6 +197,16 @@ def compact_matches(out_kind, matches_d, n, workspace):
     return cnt.value
 
 
+def matchset_from_matches(in_kind, matches_d, n, want_max=False):
+    """Device M7: (KeyPoint[2n] bytes, MultiMatch[n] bytes, max distance or None) from a validated DMatch / Match array."""
+    kp = dev_bytes(32 * n)
+    mm = dev_bytes(8 * n)
+    mx = torch.full((1,), -1.0, dtype=torch.float32, device="cuda") if want_max else None
+    check(LIB.ssrlcv_hip_matchset_from_matches(c_int(in_kind), ptr(matches_d), c_u32(n), ptr(kp), ptr(mm), ptr(mx),
+                                               stream_ptr()))
+    return kp, mm, (float(mx.item()) if want_max else None)
+
+
 # ------------------------------------------------------------------ SIFT kernel-level
 def gauss_kernel(sigma, pixel_width):
     w = np.zeros(129, np.float32)

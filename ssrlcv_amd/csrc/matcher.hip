@@ -637,6 +637,33 @@ int run_match(const ssrlcv_sift_feature* query, uint32_t nq, const ssrlcv_sift_f
 
 }  // namespace
 
+namespace {
+// M7: the 2-view MatchSet (src/Pipeline.cu:204-223).  One thread per match; ELEM = ssrlcv_match or ssrlcv_dmatch (the
+// end points sit at the same offsets).  Distances are >= 0, so the integer order of their bit patterns is the float order.
+template <typename ELEM>
+__global__ __launch_bounds__(256) void k_matchset(const ELEM* __restrict__ in, uint32_t n, ssrlcv_keypoint* __restrict__ kp,
+                                                  ssrlcv_multimatch* __restrict__ mm, float* __restrict__ maxDistance,
+                                                  bool wantMax) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  float d = 0.0f;
+  if (i < n) {
+    const ELEM m = in[i];
+    kp[2 * (size_t)i] = m.keyPoints[0];
+    kp[2 * (size_t)i + 1] = m.keyPoints[1];
+    ssrlcv_multimatch o;
+    o.numKeyPoints = 2u;
+    o.index = (int)(2 * i);
+    mm[i] = o;
+    if (wantMax) d = reinterpret_cast<const ssrlcv_dmatch*>(in)[i].distance;
+  }
+  if (!wantMax) return;  // uniform
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) d = fmaxf(d, __shfl_xor(d, o, 64));
+  if ((threadIdx.x & 63) == 0 && d > 0.0f) atomicMax(reinterpret_cast<int*>(maxDistance), __float_as_int(d));
+}
+
+}  // namespace
+
 extern "C" {
 
 size_t ssrlcv_hip_match_workspace_bytes(uint32_t numQuery, uint32_t numTarget) {
@@ -723,6 +750,26 @@ int ssrlcv_hip_compact_matches(int outKind, void* matches, uint32_t numMatches, 
   *count_host = host_tot[0];
   if (host_tot[0]) SSRLCV_HIP_TRY(hipMemcpyAsync(matches, tmp, (size_t)host_tot[0] * elem, hipMemcpyDeviceToDevice, st));
   SSRLCV_HIP_TRY(hipStreamSynchronize(st));
+  return SSRLCV_OK;
+}
+
+int ssrlcv_hip_matchset_from_matches(int inKind, const void* matches, uint32_t numMatches, ssrlcv_keypoint* keyPoints,
+                                     ssrlcv_multimatch* multiMatches, float* maxDistance, ssrlcv_stream_t stream) {
+  if (inKind != SSRLCV_OUT_DMATCH && inKind != SSRLCV_OUT_MATCH) return SSRLCV_ERR_INVALID_ARG;
+  if (maxDistance && inKind != SSRLCV_OUT_DMATCH) return SSRLCV_ERR_INVALID_ARG;
+  if (numMatches && (!matches || !keyPoints || !multiMatches)) return SSRLCV_ERR_INVALID_ARG;
+  if (numMatches > 0x3FFFFFFFu) return SSRLCV_ERR_INVALID_ARG;  // MultiMatch::index is an int
+  hipStream_t st = (hipStream_t)stream;
+  if (maxDistance) SSRLCV_HIP_TRY(hipMemsetAsync(maxDistance, 0, sizeof(float), st));
+  if (numMatches == 0) return SSRLCV_OK;
+  const dim3 grid((numMatches + 255) / 256);
+  if (inKind == SSRLCV_OUT_DMATCH)
+    hipLaunchKernelGGL(k_matchset<ssrlcv_dmatch>, grid, dim3(256), 0, st, (const ssrlcv_dmatch*)matches, numMatches, keyPoints,
+                       multiMatches, maxDistance, maxDistance != nullptr);
+  else
+    hipLaunchKernelGGL(k_matchset<ssrlcv_match>, grid, dim3(256), 0, st, (const ssrlcv_match*)matches, numMatches, keyPoints,
+                       multiMatches, maxDistance, false);
+  SSRLCV_LAUNCH_CHECK();
   return SSRLCV_OK;
 }
 

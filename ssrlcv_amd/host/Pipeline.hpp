@@ -1,15 +1,18 @@
-// ssrlcv_amd/host/Pipeline.hpp -- the stage glue of the reference (include/Pipeline.cuh:12-136, src/Pipeline.cu:16-384)
-// over the MI355X factories: the same stage structs, `fromCheckpoint` / `fromPreviousStage` hand-offs and `do*` entry
-// points, so a driver written against the reference (src/SFM.cu:131-230, test/Pipeline.cu) compiles unchanged.
+// ssrlcv_amd/host/Pipeline.hpp -- stage hand-off layer over the MI355X factories.
 //
-// Differences, all at the edges of the hot path (SURVEY.md section 8, rows marked out of scope):
-//  - image decoding is not part of this build: doFeatureGeneration(FeatureGenerationInput*, ...) reads `.cpimg` camera
-//    checkpoints plus `<id>_h.uty` pixel checkpoints when an image path names a directory entry of that form, and
-//    otherwise fails like the reference does on an unreadable image; the overload taking ready `Image`s is what the
-//    tests and the Python driver use;
-//  - doPoseEstimation runs the reference's flow (seed distances, double-constrained matches, LM refinement from the
-//    cameras' relative pose); PoseEstimator::estimatePoseRANSAC, commented out upstream, is not built;
-//  - MeshFactory::setPoints + savePoints("name") is the ASCII PLY dump, done with writePLY.
+// The reference drives its six stages through plain structs (include/Pipeline.cuh:12-136) that a driver fills either
+// from checkpoint files or from the previous stage's output (src/SFM.cu:131-230, test/Pipeline.cu).  The struct names,
+// their fields and the fromCheckpoint / fromPreviousStage / do* signatures are that interface and are kept; how a
+// stage is carried out is this build's own:
+//   * everything a stage reads from disk goes through one reader (stage::Store) that knows the reference's file naming
+//     (src/Pipeline.cu:3-10: "<dir>/<id>_<typeid>.uty", "<dir>/<id>_<typeid(Image)>.cpimg");
+//   * the 2-view MatchSet (src/Pipeline.cu:198-224) is assembled ON THE DEVICE from the validated
+//     DMatch list by ssrlcv_hip_matchset_from_matches, which also reduces the largest descriptor distance -- upstream
+//     copies the list to the host twice (once for a max loop, once sliced to Match) and fills both arrays in a loop;
+//   * the relative-pose arithmetic of the pose stage lives in two small functions that the tests can call.
+// Out of scope at this edge: image decoding (images arrive as `.cpimg` + `<id>_h.uty` pixel
+// checkpoints, or as ready Image objects), PoseEstimator::estimatePoseRANSAC (disabled upstream too), MeshFactory
+// (its setPoints + savePoints pair is the ASCII PLY dump: writePLY).
 #pragma once
 #include <sys/stat.h>
 #include <iomanip>
@@ -25,43 +28,141 @@
 #include "io_util.hpp"
 
 #ifndef GEO_ORBIT
-#define GEO_ORBIT 1  // Makefile default of the reference
+#define GEO_ORBIT 1  // the reference's Makefile default: earth-orbit epipolar constraint in the matcher
 #endif
 
 namespace ssrlcv {
 
 typedef ptr::value<Unity<Feature<SIFT_Descriptor>>> SiftFeatures;
 
-namespace detail {
-template <typename T>
-inline std::string checkpointPath(const std::string& directory, int id) {  // src/Pipeline.cu:3-6
-  return directory + "/" + std::to_string(id) + "_" + typeid(T).name() + ".uty";
-}
-inline std::string imageCheckpointPath(const std::string& directory, int id) {  // src/Pipeline.cu:8-10
-  return directory + "/" + std::to_string(id) + "_" + typeid(Image).name() + ".cpimg";
-}
-inline bool exists(const std::string& path) {
-  struct stat buf;
-  return stat(path.c_str(), &buf) == 0;
-}
-inline std::vector<ptr::value<Image>> imagesFromCheckpoint(const std::string& dir, int numImages) {
-  std::vector<ptr::value<Image>> images;
-  for (int i = 0; i < numImages; i++) images.push_back(ptr::value<Image>(imageCheckpointPath(dir, i), i, true));
-  return images;
-}
-inline void savePoints(const char* name, ptr::value<Unity<float3>> points, const std::string& dir) {
-  if (points != nullptr && exists(dir)) writePLY(name, points, dir);
-}
-}  // namespace detail
-
-// where the do* stages drop their PLY files (the reference hard-wires "out/"; skipped when the directory is absent)
+// PLY files of the cloud-producing stages land here ("out/" upstream); nothing is written when it does not exist
 inline std::string& pipelineOutputDir() {
-  static std::string dir = "out/";
-  return dir;
+  static std::string where = "out/";
+  return where;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// FEATURE GENERATION (include/Pipeline.cuh:16-28, src/Pipeline.cu:16-51)
+namespace stage {
+
+// A stage brackets its work with two marks of the same name in the reference's log; here the pair is one object.
+class Marks {
+  const char* name;
+ public:
+  explicit Marks(const char* n) : name(n) { logger.logState(name); }
+  ~Marks() { logger.logState(name); }
+  Marks(const Marks&) = delete;
+  Marks& operator=(const Marks&) = delete;
+};
+
+inline bool onDisk(const std::string& file) {
+  struct stat s;
+  return ::stat(file.c_str(), &s) == 0;
+}
+
+// One checkpoint directory in the reference's naming scheme.
+class Store {
+  std::string root;
+ public:
+  explicit Store(const std::string& directory) : root(directory + "/") {}
+  template <typename T> std::string unity(int id) const { return root + std::to_string(id) + "_" + typeid(T).name() + ".uty"; }
+  std::string image(int id) const { return root + std::to_string(id) + "_" + typeid(Image).name() + ".cpimg"; }
+
+  template <typename T> ptr::value<Unity<T>> load(int id) const { return ptr::value<Unity<T>>(unity<T>(id)); }
+  template <typename T> ptr::value<Unity<T>> loadIfPresent(int id) const {
+    const std::string file = unity<T>(id);
+    return onDisk(file) ? ptr::value<Unity<T>>(file) : ptr::value<Unity<T>>(nullptr);
+  }
+  std::vector<ptr::value<Image>> cameras(int count) const {
+    std::vector<ptr::value<Image>> v;
+    v.reserve((size_t)count);
+    for (int id = 0; id < count; ++id) v.emplace_back(image(id), id, true);
+    return v;
+  }
+  std::vector<SiftFeatures> features(int count) const {
+    std::vector<SiftFeatures> v;
+    v.reserve((size_t)count);
+    for (int id = 0; id < count; ++id) v.push_back(load<Feature<SIFT_Descriptor>>(id));
+    return v;
+  }
+  MatchSet matchSet(int id = 0) const {
+    MatchSet ms;
+    ms.keyPoints = load<KeyPoint>(id);
+    ms.matches = load<MultiMatch>(id);
+    return ms;
+  }
+};
+
+inline void dumpCloud(const char* name, const ptr::value<Unity<float3>>& cloud) {
+  const std::string& dir = pipelineOutputDir();
+  if (cloud != nullptr && onDisk(dir)) writePLY(name, cloud, dir);
+}
+
+inline void reportError(const std::string& label, float value) {
+  std::ostringstream line;
+  line << label << std::fixed << std::setprecision(12) << value;
+  logger.info << line.str();
+}
+
+// Pose of camera `b` seen from camera `a`: position = (a - b) turned back through a's z, y, x rotations, angles = the
+// axis rotations of Ra^T Rb (the starting point the reference hands to its LM refinement, src/Pipeline.cu:103-119).
+inline Pose relativePose(const Image::Camera& a, const Image::Camera& b) {
+  float3 t = a.cam_pos - b.cam_pos;
+  const float3 axes[3] = {{0, 0, 1}, {0, 1, 0}, {1, 0, 0}};
+  const float turn[3] = {-a.cam_rot.z, -a.cam_rot.y, -a.cam_rot.x};
+  for (int k = 0; k < 3; ++k) t = rotatePointArbitrary(t, axes[k], turn[k]);
+  float Ra[3][3], RaT[3][3], Rb[3][3], Rab[3][3];
+  getRotationMatrix(a.cam_rot, Ra);
+  transpose(Ra, RaT);
+  getRotationMatrix(b.cam_rot, Rb);
+  multiply(RaT, Rb, Rab);
+  const float3 angles = getAxisRotations(Rab);
+  Pose p;
+  p.roll = angles.x;
+  p.pitch = angles.y;
+  p.yaw = angles.z;
+  p.x = t.x;
+  p.y = t.y;
+  p.z = t.z;
+  return p;
+}
+
+// The inverse step: put camera `b` where `pose` (relative to `a`, position in units of 1000) says it is (:127-136).
+inline void applyRelativePose(const Image::Camera& a, const Pose& pose, Image::Camera& b) {
+  const float3 step = {1000 * pose.x, 1000 * pose.y, 1000 * pose.z};
+  b.cam_pos = a.cam_pos + rotatePoint(step, a.cam_rot);
+  float Rrel[3][3], Ra[3][3], Rb[3][3];
+  getRotationMatrix({pose.roll, pose.pitch, pose.yaw}, Rrel);
+  getRotationMatrix(a.cam_rot, Ra);
+  multiply(Ra, Rrel, Rb);
+  b.cam_rot = getAxisRotations(Rb);
+}
+
+// M7 on the device.  `pairs` holds validated DMatches (any memory state); the result is left on the host, where the
+// reference builds it and where its bundle generator expects it (src/PointCloudFactory.cu:840-846).
+inline MatchSet pairwiseMatchSet(const ptr::value<Unity<DMatch>>& pairs, float* largestDistance) {
+  const unsigned long n = pairs->size();
+  const MemoryState before = pairs->getMemoryState();
+  if (before == cpu) pairs->setMemoryState(gpu);
+  else if (before == both && pairs->getFore() == cpu) pairs->transferMemoryTo(gpu);
+  MatchSet ms;
+  ms.keyPoints = ptr::value<Unity<KeyPoint>>(nullptr, 2 * n, gpu);
+  ms.matches = ptr::value<Unity<MultiMatch>>(nullptr, n, gpu);
+  ptr::device<float> peak(1);
+  HipSafeCall(ssrlcv_hip_matchset_from_matches(SSRLCV_OUT_DMATCH, pairs->device.get(), (uint32_t)n,
+                                               reinterpret_cast<ssrlcv_keypoint*>(ms.keyPoints->device.get()),
+                                               reinterpret_cast<ssrlcv_multimatch*>(ms.matches->device.get()), peak.get(),
+                                               nullptr));
+  HipCheckError();
+  HipSafeCall(ssrlcv_hip_memcpy(largestDistance, peak.get(), sizeof(float), 1));
+  ms.keyPoints->setMemoryState(cpu);
+  ms.matches->setMemoryState(cpu);
+  if (before == cpu) pairs->setMemoryState(cpu);
+  return ms;
+}
+
+}  // namespace stage
+
+// =====================================================================================================================
+// Stage 1: features (include/Pipeline.cuh:16-28)
 struct FeatureGenerationInput {
   const std::string seedPath;
   const std::vector<std::string> imagePaths;
@@ -74,64 +175,68 @@ struct FeatureGenerationOutput {
   std::vector<ptr::value<Image>> images;
 };
 
-// the reference's loop body for images that are already in memory (pixels in image->pixels, camera filled in)
+// Images already in memory (pixels + camera).  Camera positions become relative to the first camera, whose ECEF
+// position every image keeps as its offset (src/Pipeline.cu:36-39); features are left readable on the host.
 inline void doFeatureGeneration(ptr::value<Image> seed, std::vector<ptr::value<Image>> images, FeatureGenerationOutput* out) {
-  SIFT_FeatureFactory featureFactory = SIFT_FeatureFactory(1.5f, 6.0f);
-  logger.logState("SEED");
-  if (seed != nullptr) out->seedFeatures = featureFactory.generateFeatures(seed, false, 2, 0.8);
-  logger.logState("SEED");
-  logger.logState("FEATURES");
-  float3 offset = {0.0f, 0.0f, 0.0f};
-  for (size_t i = 0; i < images.size(); i++) {
-    ptr::value<Image> image = images[i];
-    if (i == 0) offset = image->camera.cam_pos;
-    image->camera.ecef_offset = offset;
-    image->camera.cam_pos = image->camera.cam_pos - offset;
-    SiftFeatures features = featureFactory.generateFeatures(image, false, 2, 0.8);
-    features->transferMemoryTo(cpu);
-    out->images.push_back(image);
-    out->allFeatures.push_back(features);
+  SIFT_FeatureFactory sift(1.5f, 6.0f);  // orientation / descriptor contribution widths of the reference pipeline
+  const unsigned maxOrientations = 2;
+  const float peakRatio = 0.8f;
+  {
+    stage::Marks marks("SEED");
+    if (seed != nullptr) out->seedFeatures = sift.generateFeatures(seed, false, maxOrientations, peakRatio);
   }
-  logger.logState("FEATURES");
+  stage::Marks marks("FEATURES");
+  if (images.empty()) return;
+  const float3 origin = images.front()->camera.cam_pos;
+  out->images.reserve(images.size());
+  out->allFeatures.reserve(images.size());
+  for (ptr::value<Image>& view : images) {
+    view->camera.ecef_offset = origin;
+    view->camera.cam_pos = view->camera.cam_pos - origin;
+    SiftFeatures found = sift.generateFeatures(view, false, maxOrientations, peakRatio);
+    found->transferMemoryTo(cpu);
+    out->allFeatures.push_back(found);
+    out->images.push_back(view);
+  }
 }
 
-// path flavour: every path must be a `<dir>/<id>_<typeid(Image)>.cpimg` checkpoint with `<dir>/<id>_h.uty` pixels beside it
+// Path flavour.  This build has no image decoders: a path must name a camera checkpoint `<dir>/<id>_<Image>.cpimg`
+// with the pixels beside it as `<dir>/<id>_h.uty`.
 inline void doFeatureGeneration(FeatureGenerationInput* in, FeatureGenerationOutput* out) {
-  auto load = [](const std::string& path, int id) {
-    ptr::value<Image> image(path, id, true);
-    std::string pix = path.substr(0, path.find_last_of('/') + 1) + std::to_string(id) + "_h.uty";
-    if (!detail::exists(pix)) {
-      logger.err << "image decoding is not part of this build and no pixel checkpoint " + pix + " exists";
-      exit(-1);
+  auto open = [](const std::string& cameraFile, int id) {
+    const std::string dir = cameraFile.substr(0, cameraFile.find_last_of('/') + 1);
+    const std::string pixelFile = dir + std::to_string(id) + "_h.uty";
+    if (!stage::onDisk(pixelFile)) {
+      logger.err << "no pixel checkpoint " + pixelFile + " (this build reads .cpimg + _h.uty pairs, it decodes no image formats)";
+      std::exit(-1);
     }
-    image->pixels = ptr::value<Unity<unsigned char>>(pix);
-    return image;
+    ptr::value<Image> view(cameraFile, id, true);
+    view->pixels = ptr::value<Unity<unsigned char>>(pixelFile);
+    return view;
   };
-  ptr::value<Image> seed = nullptr;
-  if (in->seedPath.size() > 0) seed = load(in->seedPath, -1);
-  std::vector<ptr::value<Image>> images;
-  for (int i = 0; i < in->numImages; i++) images.push_back(load(in->imagePaths[i], i));
-  doFeatureGeneration(seed, images, out);
+  std::vector<ptr::value<Image>> views;
+  for (int id = 0; id < in->numImages; ++id) views.push_back(open(in->imagePaths[(size_t)id], id));
+  ptr::value<Image> seed = in->seedPath.empty() ? ptr::value<Image>(nullptr) : open(in->seedPath, -1);
+  doFeatureGeneration(seed, views, out);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// POSE ESTIMATION (include/Pipeline.cuh:34-50, src/Pipeline.cu:57-140)
+// =====================================================================================================================
+// Stage 2: pose (include/Pipeline.cuh:34-50)
 struct PoseEstimationInput {
   SiftFeatures seedFeatures;
   std::vector<SiftFeatures> allFeatures;
   std::vector<ptr::value<Image>> images;
 
   void fromCheckpoint(std::string featureGenDir, int numImages) {
-    std::string seedCpPath = detail::checkpointPath<Feature<SIFT_Descriptor>>(featureGenDir, -1);
-    if (detail::exists(seedCpPath)) seedFeatures = SiftFeatures(seedCpPath);
-    images = detail::imagesFromCheckpoint(featureGenDir, numImages);
-    for (int i = 0; i < numImages; i++)
-      allFeatures.push_back(SiftFeatures(detail::checkpointPath<Feature<SIFT_Descriptor>>(featureGenDir, i)));
+    const stage::Store store(featureGenDir);
+    seedFeatures = store.loadIfPresent<Feature<SIFT_Descriptor>>(-1);
+    images = store.cameras(numImages);
+    allFeatures = store.features(numImages);
   }
   void fromPreviousStage(FeatureGenerationOutput* featureGenOutput) {
-    this->seedFeatures = featureGenOutput->seedFeatures;
-    this->allFeatures = featureGenOutput->allFeatures;
-    this->images = featureGenOutput->images;
+    seedFeatures = featureGenOutput->seedFeatures;
+    allFeatures = featureGenOutput->allFeatures;
+    images = featureGenOutput->images;
   }
 };
 
@@ -139,79 +244,59 @@ struct PoseEstimationOutput {
   ptr::value<Unity<float>> seedDistances = nullptr;
 };
 
+// Two views only, like upstream: loose double-constrained matches (epsilon 100 px, delta 3 km, absolute threshold 10^2)
+// feed the Levenberg-Marquardt refinement, which starts at the cameras' own relative pose; the second camera is then
+// moved to the refined pose.
 inline void doPoseEstimation(PoseEstimationInput* in, PoseEstimationOutput* out) {
-  logger.info << "Starting pose estimation...";
-  logger.logState("POSE");
-  MatchFactory<SIFT_Descriptor> matchFactory = MatchFactory<SIFT_Descriptor>(0.6f, 10.0f * 10.0f);
-  if (in->seedFeatures != nullptr) matchFactory.setSeedFeatures(in->seedFeatures);
-  out->seedDistances = (in->seedFeatures != nullptr) ? matchFactory.getSeedDistances(in->allFeatures[0]) : nullptr;
-  logger.logState("matching images");
-  ptr::value<Unity<Match>> matches = matchFactory.generateMatchesDoubleConstrained(
-      in->images[0], in->allFeatures[0], in->images[1], in->allFeatures[1], 100, 3, out->seedDistances);
-  logger.logState("done matching images");
-  matches->transferMemoryTo(cpu);
-  PoseEstimator estim(in->images.at(0), in->images.at(1), matches);
-  // starting pose = the cameras' relative pose (the RANSAC estimate is commented out upstream, src/Pipeline.cu:101)
-  Pose pose;
-  float3 pos = in->images.at(0)->camera.cam_pos - in->images.at(1)->camera.cam_pos;
-  pos = rotatePointArbitrary(pos, {0, 0, 1}, -in->images.at(0)->camera.cam_rot.z);
-  pos = rotatePointArbitrary(pos, {0, 1, 0}, -in->images.at(0)->camera.cam_rot.y);
-  pos = rotatePointArbitrary(pos, {1, 0, 0}, -in->images.at(0)->camera.cam_rot.x);
-  pose.x = pos.x;
-  pose.y = pos.y;
-  pose.z = pos.z;
-  float C0[3][3], C0t[3][3], C1[3][3], relative[3][3];
-  getRotationMatrix(in->images.at(0)->camera.cam_rot, C0);
-  transpose(C0, C0t);
-  getRotationMatrix(in->images.at(1)->camera.cam_rot, C1);
-  multiply(C0t, C1, relative);
-  float3 rot = getAxisRotations(relative);
-  pose.roll = rot.x;
-  pose.pitch = rot.y;
-  pose.yaw = rot.z;
-  logger.info.printf("Original pose: %f %f %f", pose.roll, pose.pitch, pose.yaw);
-  estim.LM_optimize(&pose);
-  // write the refined pose back into the second camera (src/Pipeline.cu:127-136)
-  float R1[3][3], R2[3][3], R[3][3];
-  in->images.at(1)->camera.cam_pos =
-      in->images.at(0)->camera.cam_pos + rotatePoint({1000 * pose.x, 1000 * pose.y, 1000 * pose.z}, in->images.at(0)->camera.cam_rot);
-  getRotationMatrix({pose.roll, pose.pitch, pose.yaw}, R1);
-  getRotationMatrix(in->images.at(0)->camera.cam_rot, R2);
-  multiply(R2, R1, R);
-  in->images.at(1)->camera.cam_rot = getAxisRotations(R);
-  logger.info.printf("Rotation: %f %f %f", in->images.at(1)->camera.cam_rot.x, in->images.at(1)->camera.cam_rot.y, in->images.at(1)->camera.cam_rot.z);
-  logger.info.printf("Position: %f %f %f", in->images.at(1)->camera.cam_pos.x, in->images.at(1)->camera.cam_pos.y, in->images.at(1)->camera.cam_pos.z);
-  logger.logState("POSE");
+  stage::Marks marks("POSE");
+  ptr::value<Image> first = in->images.at(0), second = in->images.at(1);
+  MatchFactory<SIFT_Descriptor> matcher(0.6f, 10.0f * 10.0f);
+  const bool seeded = in->seedFeatures != nullptr;
+  if (seeded) {
+    matcher.setSeedFeatures(in->seedFeatures);
+    out->seedDistances = matcher.getSeedDistances(in->allFeatures[0]);
+  } else {
+    out->seedDistances = nullptr;
+  }
+  ptr::value<Unity<Match>> tiePoints = matcher.generateMatchesDoubleConstrained(first, in->allFeatures[0], second, in->allFeatures[1],
+                                                                               100, 3, out->seedDistances);
+  tiePoints->transferMemoryTo(cpu);
+  logger.info.printf("pose stage: %lu tie points", tiePoints->size());
+  PoseEstimator refiner(first, second, tiePoints);
+  Pose pose = stage::relativePose(first->camera, second->camera);
+  logger.info.printf("pose stage: start angles %f %f %f", pose.roll, pose.pitch, pose.yaw);
+  refiner.LM_optimize(&pose);
+  stage::applyRelativePose(first->camera, pose, second->camera);
+  const Image::Camera& moved = second->camera;
+  logger.info.printf("pose stage: camera 1 now at (%f %f %f), rotation (%f %f %f)", moved.cam_pos.x, moved.cam_pos.y,
+                     moved.cam_pos.z, moved.cam_rot.x, moved.cam_rot.y, moved.cam_rot.z);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// FEATURE MATCHING (include/Pipeline.cuh:56-74, src/Pipeline.cu:146-241)
+// =====================================================================================================================
+// Stage 3: matching (include/Pipeline.cuh:56-74)
 struct FeatureMatchingInput {
   SiftFeatures seedFeatures;
   std::vector<SiftFeatures> allFeatures;
   std::vector<ptr::value<Image>> images;
   ptr::value<Unity<float>> seedDistances;
-  float epsilon;  // pixel buffer around 2D epipolar line
-  float delta;    // kilometer buffer above and below line segment in 3D space
+  float epsilon;  // pixels either side of the projected epipolar segment
+  float delta;    // kilometres added above / below the earth shells that bound the segment
 
   void fromCheckpoint(std::string featureGenDirectory, std::string poseDirectory, int numImages, float epsilon, float delta) {
-    std::string seedCpPath = detail::checkpointPath<Feature<SIFT_Descriptor>>(featureGenDirectory, -1);
-    if (detail::exists(seedCpPath)) seedFeatures = SiftFeatures(seedCpPath);
-    images = detail::imagesFromCheckpoint(featureGenDirectory, numImages);
-    for (int i = 0; i < numImages; i++)
-      allFeatures.push_back(SiftFeatures(detail::checkpointPath<Feature<SIFT_Descriptor>>(featureGenDirectory, i)));
+    const stage::Store store(featureGenDirectory);
+    seedFeatures = store.loadIfPresent<Feature<SIFT_Descriptor>>(-1);
+    images = store.cameras(numImages);
+    allFeatures = store.features(numImages);
+    // seed distances are a product of the (2-view only) pose stage
+    if (numImages == 2) seedDistances = stage::Store(poseDirectory).loadIfPresent<float>(0);
     this->epsilon = epsilon;
     this->delta = delta;
-    if (numImages == 2) {  // pose estimation only exists for 2 views
-      std::string seedDistPath = detail::checkpointPath<float>(poseDirectory, 0);
-      if (detail::exists(seedDistPath)) seedDistances = ptr::value<Unity<float>>(seedDistPath);
-    }
   }
   void fromPreviousStage(PoseEstimationInput* poseInput, PoseEstimationOutput* poseOutput, float epsilon, float delta) {
-    this->seedFeatures = poseInput->seedFeatures;
-    this->allFeatures = poseInput->allFeatures;
-    this->images = poseInput->images;
-    this->seedDistances = poseOutput->seedDistances;
+    seedFeatures = poseInput->seedFeatures;
+    allFeatures = poseInput->allFeatures;
+    images = poseInput->images;
+    seedDistances = poseOutput->seedDistances;
     this->epsilon = epsilon;
     this->delta = delta;
   }
@@ -221,64 +306,46 @@ struct FeatureMatchingOutput {
   MatchSet matchSet;
 };
 
+// Ratio threshold 0.6 against the seed image, absolute threshold 200^2 (src/Pipeline.cu:175).  Two views: one matcher
+// call, MatchSet assembled on the device.  More: every pair i < j + the consistency merge (generateMatchesExhaustive).
 inline void doFeatureMatching(FeatureMatchingInput* in, FeatureMatchingOutput* out) {
-  logger.info << "Starting matching...";
-  MatchFactory<SIFT_Descriptor> matchFactory = MatchFactory<SIFT_Descriptor>(0.6f, 200.0f * 200.0f);
-  logger.logState("MATCHING");
-  if (in->seedFeatures != nullptr) matchFactory.setSeedFeatures(in->seedFeatures);
-  if (in->seedDistances == nullptr)
-    in->seedDistances = (in->seedFeatures != nullptr) ? matchFactory.getSeedDistances(in->allFeatures[0]) : nullptr;
-  if (in->images.size() == 2) {
-#if GEO_ORBIT == 1
-    ptr::value<Unity<DMatch>> distanceMatches = matchFactory.generateDistanceMatchesDoubleConstrained(
-        in->images[0], in->allFeatures[0], in->images[1], in->allFeatures[1], in->epsilon, in->delta, in->seedDistances);
-#else
-    ptr::value<Unity<DMatch>> distanceMatches = matchFactory.generateDistanceMatches(
-        in->images[0], in->allFeatures[0], in->images[1], in->allFeatures[1], in->seedDistances);
-#endif
-    distanceMatches->transferMemoryTo(cpu);
-    float maxDist = 0.0f;
-    DMatch* dhost = distanceMatches->host.get();
-    for (unsigned long i = 0; i < distanceMatches->size(); ++i)
-      if (maxDist < dhost[i].distance) maxDist = dhost[i].distance;
-    logger.info.printf("max euclidean distance between features = %f", maxDist);
-    if (distanceMatches->getMemoryState() != gpu) distanceMatches->setMemoryState(gpu);
-    ptr::value<Unity<Match>> matches = matchFactory.getRawMatches(distanceMatches);
-    // the 2-view MatchSet is the match list laid out pairwise (src/Pipeline.cu:204-223)
-    out->matchSet.keyPoints = ptr::value<Unity<KeyPoint>>(nullptr, matches->size() * 2, cpu);
-    out->matchSet.matches = ptr::value<Unity<MultiMatch>>(nullptr, matches->size(), cpu);
-    matches->setMemoryState(cpu);
-    KeyPoint* okhost = out->matchSet.keyPoints->host.get();
-    Match* mhost = matches->host.get();
-    MultiMatch* omhost = out->matchSet.matches->host.get();
-    for (unsigned long i = 0; i < out->matchSet.matches->size(); i++) {
-      okhost[i * 2] = mhost[i].keyPoints[0];
-      okhost[i * 2 + 1] = mhost[i].keyPoints[1];
-      omhost[i] = {2, (int)(i * 2)};
-    }
-    logger.info << "Total Matches: " + std::to_string(matches->size());
-  } else {
-    out->matchSet = matchFactory.generateMatchesExhaustive(in->images, in->allFeatures, in->epsilon, in->delta);
-    out->matchSet.matches->setMemoryState(cpu);
-    out->matchSet.keyPoints->setMemoryState(cpu);
+  stage::Marks marks("MATCHING");
+  MatchFactory<SIFT_Descriptor> matcher(0.6f, 200.0f * 200.0f);
+  if (in->seedFeatures != nullptr) {
+    matcher.setSeedFeatures(in->seedFeatures);
+    if (in->seedDistances == nullptr) in->seedDistances = matcher.getSeedDistances(in->allFeatures[0]);
   }
-  logger.logState("MATCHING");
+  if (in->images.size() != 2) {
+    out->matchSet = matcher.generateMatchesExhaustive(in->images, in->allFeatures, in->epsilon, in->delta);
+    out->matchSet.keyPoints->setMemoryState(cpu);
+    out->matchSet.matches->setMemoryState(cpu);
+    return;
+  }
+  ptr::value<Unity<DMatch>> pairs =
+#if GEO_ORBIT == 1
+      matcher.generateDistanceMatchesDoubleConstrained(in->images[0], in->allFeatures[0], in->images[1], in->allFeatures[1],
+                                                       in->epsilon, in->delta, in->seedDistances);
+#else
+      matcher.generateDistanceMatches(in->images[0], in->allFeatures[0], in->images[1], in->allFeatures[1], in->seedDistances);
+#endif
+  float worst = 0.0f;
+  out->matchSet = stage::pairwiseMatchSet(pairs, &worst);
+  logger.info.printf("2-view matching: %lu matches, largest descriptor distance %f", out->matchSet.matches->size(), worst);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// TRIANGULATION (include/Pipeline.cuh:80-92, src/Pipeline.cu:247-278)
+// =====================================================================================================================
+// Stage 4: triangulation (include/Pipeline.cuh:80-92)
 struct TriangulationInput {
   MatchSet matchSet;
   std::vector<ptr::value<Image>> images;
 
   void fromCheckpoint(std::string featureGenDir, std::string featureMatchDir, int numImages) {
-    images = detail::imagesFromCheckpoint(featureGenDir, numImages);
-    matchSet.keyPoints = ptr::value<Unity<KeyPoint>>(detail::checkpointPath<KeyPoint>(featureMatchDir, 0));
-    matchSet.matches = ptr::value<Unity<MultiMatch>>(detail::checkpointPath<MultiMatch>(featureMatchDir, 0));
+    images = stage::Store(featureGenDir).cameras(numImages);
+    matchSet = stage::Store(featureMatchDir).matchSet();
   }
   void fromPreviousStage(FeatureMatchingInput* featureMatchingInput, FeatureMatchingOutput* featureMatchingOutput) {
-    this->images = featureMatchingInput->images;
-    this->matchSet = featureMatchingOutput->matchSet;
+    images = featureMatchingInput->images;
+    matchSet = featureMatchingOutput->matchSet;
   }
 };
 
@@ -286,34 +353,38 @@ struct TriangulationOutput {
   ptr::value<Unity<float3>> points;
 };
 
+namespace stage {
+// bundles -> cloud with the triangulator the view count selects; `error` is the linear (2-view) or angular (N-view) sum
+inline ptr::value<Unity<float3>> triangulate(PointCloudFactory& factory, MatchSet* matchSet,
+                                             const std::vector<ptr::value<Image>>& views, float* error) {
+  BundleSet rays = factory.generateBundles(matchSet, views);
+  if (views.size() == 2) return factory.twoViewTriangulate(rays, error);
+  return factory.nViewTriangulate(rays, error);
+}
+}  // namespace stage
+
 inline void doTriangulation(TriangulationInput* in, TriangulationOutput* out) {
-  PointCloudFactory pointCloudFactory = PointCloudFactory();
-  logger.logState("TRIANGULATE");
-  float error;  // linear for 2-view, angular for N-view
-  BundleSet bundleSet = pointCloudFactory.generateBundles(&in->matchSet, in->images);
-  out->points = (in->images.size() == 2) ? pointCloudFactory.twoViewTriangulate(bundleSet, &error)
-                                         : pointCloudFactory.nViewTriangulate(bundleSet, &error);
-  std::stringstream ss;
-  ss << "\tUnfiltered Error: " << std::fixed << std::setprecision(12) << error;
-  logger.info << ss.str();
-  detail::savePoints("ssrlcv-initial", out->points, pipelineOutputDir());
-  logger.logState("TRIANGULATE");
+  stage::Marks marks("TRIANGULATE");
+  PointCloudFactory factory;
+  float error = 0.0f;
+  out->points = stage::triangulate(factory, &in->matchSet, in->images, &error);
+  stage::reportError("triangulation error before filtering: ", error);
+  stage::dumpCloud("ssrlcv-initial", out->points);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// FILTERING (include/Pipeline.cuh:98-110, src/Pipeline.cu:284-352)
+// =====================================================================================================================
+// Stage 5: filtering (include/Pipeline.cuh:98-110)
 struct FilteringInput {
   MatchSet matchSet;
   std::vector<ptr::value<Image>> images;
 
   void fromCheckpoint(std::string featureGenDir, std::string featureMatchDir, int numImages) {
-    images = detail::imagesFromCheckpoint(featureGenDir, numImages);
-    matchSet.keyPoints = ptr::value<Unity<KeyPoint>>(detail::checkpointPath<KeyPoint>(featureMatchDir, 0));
-    matchSet.matches = ptr::value<Unity<MultiMatch>>(detail::checkpointPath<MultiMatch>(featureMatchDir, 0));
+    images = stage::Store(featureGenDir).cameras(numImages);
+    matchSet = stage::Store(featureMatchDir).matchSet();
   }
   void fromPreviousStage(TriangulationInput* triangulationInput) {
-    this->images = triangulationInput->images;
-    this->matchSet = triangulationInput->matchSet;
+    images = triangulationInput->images;
+    matchSet = triangulationInput->matchSet;
   }
 };
 
@@ -321,44 +392,34 @@ struct FilteringOutput {
   ptr::value<Unity<float3>> points;
 };
 
+// Two views: drop matches whose rays miss each other by more than 100 km, then everything beyond 3 sigma of a 10 %
+// sample; N views: the statistical filter alone (src/Pipeline.cu:297-343).  The filters rewrite in->matchSet; the
+// cloud is triangulated again from what is left.
 inline void doFiltering(FilteringInput* in, FilteringOutput* out) {
-  PointCloudFactory pointCloudFactory;
-  logger.logState("FILTER");
-  std::stringstream ss;
-  if (in->images.size() == 2) {
-    float linearError;
-    pointCloudFactory.linearCutoffFilter(&in->matchSet, in->images, 100.0);  // removes linear errors over 100 km
-    float sigma_filter = 3.0;
-    pointCloudFactory.deterministicStatisticalFilter(&in->matchSet, in->images, sigma_filter, 0.1);  // 10 % sample, 3 sigma
-    BundleSet bundleSet = pointCloudFactory.generateBundles(&in->matchSet, in->images);
-    out->points = pointCloudFactory.twoViewTriangulate(bundleSet, &linearError);
-    ss << "Filtered " << sigma_filter << " Linear Error: " << std::fixed << std::setprecision(12) << linearError;
-  } else {
-    float angularError;
-    pointCloudFactory.deterministicStatisticalFilter(&in->matchSet, in->images, 3.0, 0.1);
-    BundleSet bundleSet = pointCloudFactory.generateBundles(&in->matchSet, in->images);
-    out->points = pointCloudFactory.nViewTriangulate(bundleSet, &angularError);
-    ss << "Filtered " << 0.1 << " Linear Error: " << std::fixed << std::setprecision(12) << angularError;
-  }
-  logger.info << ss.str();
-  detail::savePoints("ssrlcv-filtered", out->points, pipelineOutputDir());
-  logger.logState("FILTER");
+  stage::Marks marks("FILTER");
+  PointCloudFactory factory;
+  const float sigmas = 3.0f, sampleFraction = 0.1f;
+  if (in->images.size() == 2) factory.linearCutoffFilter(&in->matchSet, in->images, 100.0);
+  factory.deterministicStatisticalFilter(&in->matchSet, in->images, sigmas, sampleFraction);
+  float error = 0.0f;
+  out->points = stage::triangulate(factory, &in->matchSet, in->images, &error);
+  stage::reportError("triangulation error after the " + std::to_string((int)sigmas) + "-sigma filter: ", error);
+  stage::dumpCloud("ssrlcv-filtered", out->points);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// BUNDLE ADJUSTMENT (include/Pipeline.cuh:116-134, src/Pipeline.cu:358-384)
+// =====================================================================================================================
+// Stage 6: bundle adjustment (include/Pipeline.cuh:116-134)
 struct BundleAdjustInput {
   MatchSet matchSet;
   std::vector<ptr::value<Image>> images;
 
   void fromCheckpoint(std::string featureGenDir, std::string filteringDir, int numImages) {
-    images = detail::imagesFromCheckpoint(featureGenDir, numImages);
-    matchSet.keyPoints = ptr::value<Unity<KeyPoint>>(detail::checkpointPath<KeyPoint>(filteringDir, 0));
-    matchSet.matches = ptr::value<Unity<MultiMatch>>(detail::checkpointPath<MultiMatch>(filteringDir, 0));
+    images = stage::Store(featureGenDir).cameras(numImages);
+    matchSet = stage::Store(filteringDir).matchSet();
   }
   void fromPreviousStage(FilteringInput* filteringInput) {
-    this->images = filteringInput->images;
-    this->matchSet = filteringInput->matchSet;
+    images = filteringInput->images;
+    matchSet = filteringInput->matchSet;
   }
 };
 
@@ -366,13 +427,14 @@ struct BundleAdjustOutput {
   ptr::value<Unity<float3>> points;
 };
 
+// Ten iterations requested, two views only (upstream has no N-view bundle adjustment: the call returns without a cloud).
 inline void doBundleAdjust(BundleAdjustInput* in, BundleAdjustOutput* out) {
-  if (in->images.size() != 2) return;  // not implemented for N-view in the reference either
-  PointCloudFactory pointCloudFactory;
-  logger.logState("BA");
-  out->points = pointCloudFactory.BundleAdjustTwoView(&in->matchSet, in->images, 10, "");
-  detail::savePoints("ssrlcv-BA-final", out->points, pipelineOutputDir());
-  logger.logState("BA");
+  if (in->images.size() != 2) return;
+  stage::Marks marks("BA");
+  PointCloudFactory factory;
+  const unsigned iterations = 10;
+  out->points = factory.BundleAdjustTwoView(&in->matchSet, in->images, iterations, "");
+  stage::dumpCloud("ssrlcv-BA-final", out->points);
 }
 
 }  // namespace ssrlcv

@@ -240,3 +240,29 @@ def test_everest_fixture_matches_reproduced_on_gpu(capi, oracle_lib, everest_ora
     assert n == 13534
     assert np.array_equal(dm["kp0_loc"], kp["loc"][0::2]) and np.array_equal(dm["kp1_loc"], kp["loc"][1::2])
     assert np.array_equal(dm["kp0_parent"], kp["parentId"][0::2])
+    # M7 on the device (src/Pipeline.cu:198-224): the validated list laid out pairwise is the reference's golden MatchSet
+    kp_d, mm_d, peak = capi.matchset_from_matches(capi.OUT_DMATCH, out_d, n, want_max=True)
+    gkp, gmm = capi.to_host(kp_d, H.KEYPOINT, 2 * n), capi.to_host(mm_d, H.MULTIMATCH, n)
+    assert np.array_equal(gkp["loc"], kp["loc"]) and np.array_equal(gkp["parentId"], kp["parentId"])
+    assert np.array_equal(gmm["numKeyPoints"], v["mm0"]["numKeyPoints"]) and np.array_equal(gmm["index"], v["mm0"]["index"])
+    assert peak == float(dm["distance"].max())
+
+
+@pytest.mark.parametrize("n", [0, 1, 257, 5000])
+def test_matchset_from_matches_both_input_kinds(capi, n):
+    rng = np.random.default_rng(n)
+    for kind, dt in ((capi.OUT_DMATCH, H.DMATCH), (capi.OUT_MATCH, H.MATCH)):
+        m = np.zeros(n, dt)
+        m["kp0_parent"], m["kp1_parent"] = 2, 5
+        m["kp0_loc"] = rng.uniform(0, 4096, (n, 2)).astype(np.float32)
+        m["kp1_loc"] = rng.uniform(0, 4096, (n, 2)).astype(np.float32)
+        if kind == capi.OUT_DMATCH:
+            m["distance"] = rng.integers(0, 40000, n).astype(np.float32)
+        want_max = kind == capi.OUT_DMATCH
+        kp_d, mm_d, peak = capi.matchset_from_matches(kind, capi.to_dev(m) if n else None, n, want_max=want_max)
+        kp, mm = capi.to_host(kp_d, H.KEYPOINT, 2 * n), capi.to_host(mm_d, H.MULTIMATCH, n)
+        assert np.array_equal(kp["loc"][0::2], m["kp0_loc"]) and np.array_equal(kp["loc"][1::2], m["kp1_loc"])
+        assert np.array_equal(kp["parentId"][0::2], m["kp0_parent"]) and np.array_equal(kp["parentId"][1::2], m["kp1_parent"])
+        assert np.all(mm["numKeyPoints"] == 2) and np.array_equal(mm["index"], 2 * np.arange(n))
+        if want_max:
+            assert peak == (float(m["distance"].max()) if n else 0.0)

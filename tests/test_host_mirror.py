@@ -101,20 +101,18 @@ def test_reference_stage_flow_through_class_api(tmp_path, views):
     pts, state, _ = read_uty(os.path.join(d, "100_6float3.uty"), np.dtype(("<f4", (3,))))
     assert state == 1  # triangulators return the cloud on the cpu
     ref_kp, ref_mm = gv["kp0"], gv["mm0"]
-    # descriptor bytes can differ from the CUDA build by 1 LSB (libm), flipping a handful of borderline ratio tests
-    assert abs(len(mm) - len(ref_mm)) <= 0.01 * len(ref_mm), (len(mm), len(ref_mm))
-    def groups(kparr, mmarr):
-        out = set()
-        for n, idx in zip(mmarr["numKeyPoints"], mmarr["index"]):
-            out.add(tuple((int(k["parentId"]), float(k["loc"][0]), float(k["loc"][1])) for k in kparr[idx: idx + n]))
-        return out
-    got, ref = groups(kp, mm), groups(ref_kp, ref_mm)
-    assert len(got & ref) >= 0.985 * len(ref), (len(got & ref), len(ref))
+    # The class API (SIFT_FeatureFactory -> MatchFactory -> doFeatureMatching) must land on the reference's golden
+    # MatchSet entry for entry: 13 534 pairs (2 views) / 21 177 multi-matches over 51 442 key points (3 views).
+    print("class API, %d views: %d matches (golden %d), %d key points (golden %d)"
+          % (views, len(mm), len(ref_mm), len(kp), len(ref_kp)))
+    assert len(mm) == len(ref_mm) == (13534 if views == 2 else 21177)
+    assert np.array_equal(mm["numKeyPoints"], ref_mm["numKeyPoints"]) and np.array_equal(mm["index"], ref_mm["index"])
+    assert np.array_equal(kp["parentId"], ref_kp["parentId"]) and np.array_equal(kp["loc"], ref_kp["loc"])
     assert len(pts) == len(mm) and np.isfinite(pts).all()
-    if len(mm) == len(ref_mm) and np.array_equal(kp["loc"], ref_kp["loc"]):
-        diff = pts - gv["points0"]
-        rms = float(np.sqrt((diff.astype(np.float64) ** 2).sum(1).mean()))
-        assert rms <= (1e-4 if views == 2 else 2.5e-3)
+    diff = pts - gv["points0"]
+    rms = float(np.sqrt((diff.astype(np.float64) ** 2).sum(1).mean()))
+    print("class API, %d views: cloud rms vs golden %.3e km" % (views, rms))
+    assert rms <= (1e-4 if views == 2 else 2.5e-3)  # float tolerance north_star states (N-view: S is near-singular)
     if views == 2:
         adj, _, _ = read_uty(os.path.join(d, "101_6float3.uty"), np.dtype(("<f4", (3,))))
         # BundleAdjustTwoView is an identity on the cloud upstream (2_6float3.uty == 1_6float3.uty)
