@@ -37,6 +37,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+import helpers as _H  # noqa: E402  (test-side helpers: POD dtypes and the loader of the CPU oracle the cpu_baseline leg times)
+
+OMP_THREADS = _H.limit_openmp()  # the OpenMP team = the CPUs this process is granted (cgroup quota), set before torch loads
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (~2.5 PF)
@@ -162,9 +165,9 @@ def cpu_baseline(size, runs=3):
         f = H.oracle_sift(lib, img)
         times.append(time.perf_counter() - t0)
     dt = float(np.median(times))
-    return {"value": size * size / dt / 1e6, "unit": "Mpix/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": size * size / dt / 1e6, "unit": "Mpix/s", "cores": OMP_THREADS, "kind": "port",
             "sample": "oracle_sift_generate on one %dx%d view of the benchmark's scene generator (%d features; median of %d "
-                      "runs after a warm-up: %s s; OpenMP on all host cores); the reference itself has no CPU compute path"
+                      "runs after a warm-up: %s s; OpenMP team = the host CPUs granted to this process); the reference itself has no CPU compute path"
                       % (size, size, len(f), runs, ", ".join("%.2f" % t for t in times))}
 
 

@@ -242,11 +242,12 @@ inline hipError_t partition(uint32_t n, MaskFn maskfn, EmitFn emit, uint32_t* wo
 // 16-byte words and squeezes bit k of every byte into a 64-bit mask per key (16 x {shift, and, multiply, extract}):
 // per-key counts are popcounts, output slots an exclusive wave prefix over the lanes plus the rank of the bit inside
 // the lane's mask -- the same key-major, input-ordered output as the generic kernels, from 4 loads and ~250
-// instructions per 4096 elements.  Requirements: n % 64 == 0, `flags` 16-byte aligned.
+// instructions per 4096 elements.  Requirements: n % 64 == 0, `flags` 16-byte aligned, shift + NKEYS <= 8.
 constexpr int kFlagRun = 4096;  // elements per wave
 
+// shift: key k is bit shift + k of the flag byte
 template <int NKEYS>
-__device__ __forceinline__ void flag_masks(const uint8_t* __restrict__ flags, uint32_t base, uint32_t n, unsigned lane,
+__device__ __forceinline__ void flag_masks(const uint8_t* __restrict__ flags, uint32_t base, uint32_t n, unsigned lane, int shift,
                                            unsigned long long (&m)[NKEYS]) {
 #pragma unroll
   for (int k = 0; k < NKEYS; ++k) m[k] = 0ull;
@@ -265,7 +266,7 @@ __device__ __forceinline__ void flag_masks(const uint8_t* __restrict__ flags, ui
 #pragma unroll
     for (int d = 0; d < 16; ++d) {
       // bit k of the four bytes -> bits 21..24 of the product (1 + 2^7 + 2^14 + 2^21: every target bit gets one term)
-      const uint32_t nib = ((((w[d] >> k) & 0x01010101u) * 0x00204081u) >> 21) & 0xFu;
+      const uint32_t nib = ((((w[d] >> (k + shift)) & 0x01010101u) * 0x00204081u) >> 21) & 0xFu;
       if (d < 8) lo |= nib << (4 * d);
       else hi |= nib << (4 * (d - 8));
     }
@@ -274,12 +275,12 @@ __device__ __forceinline__ void flag_masks(const uint8_t* __restrict__ flags, ui
 }
 
 template <int NKEYS>
-__global__ __launch_bounds__(kThreads) void k_count_flags(uint32_t n, uint32_t numRuns, const uint8_t* __restrict__ flags,
+__global__ __launch_bounds__(kThreads) void k_count_flags(uint32_t n, uint32_t numRuns, const uint8_t* __restrict__ flags, int shift,
                                                           uint32_t* __restrict__ counts) {
   const unsigned lane = threadIdx.x & 63;
   const uint32_t run = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   unsigned long long m[NKEYS];
-  flag_masks<NKEYS>(flags, run * (uint32_t)kFlagRun, n, lane, m);
+  flag_masks<NKEYS>(flags, run * (uint32_t)kFlagRun, n, lane, shift, m);
   uint32_t mine = 0;
 #pragma unroll
   for (int k = 0; k < NKEYS; ++k) {
@@ -292,14 +293,14 @@ __global__ __launch_bounds__(kThreads) void k_count_flags(uint32_t n, uint32_t n
 }
 
 template <int NKEYS, typename EmitFn, typename PostFn>
-__global__ __launch_bounds__(kThreads) void k_scatter_flags(uint32_t n, uint32_t numRuns, const uint8_t* __restrict__ flags,
+__global__ __launch_bounds__(kThreads) void k_scatter_flags(uint32_t n, uint32_t numRuns, const uint8_t* __restrict__ flags, int shift,
                                                             EmitFn emit, const uint32_t* __restrict__ offsets, uint32_t* totals,
                                                             PostFn post) {
   const unsigned lane = threadIdx.x & 63;
   const uint32_t run = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const uint32_t base = run * (uint32_t)kFlagRun;
   unsigned long long m[NKEYS];
-  flag_masks<NKEYS>(flags, base, n, lane, m);
+  flag_masks<NKEYS>(flags, base, n, lane, shift, m);
 #pragma unroll
   for (int k = 0; k < NKEYS; ++k) {
     const uint32_t c = (uint32_t)__popcll(m[k]);
@@ -324,10 +325,10 @@ __global__ __launch_bounds__(kThreads) void k_scatter_flags(uint32_t n, uint32_t
 
 // partition() for byte flags; falls back to the generic kernels when the fast path's requirements do not hold.
 template <int NKEYS, typename EmitFn, typename PostFn = NoPost>
-inline hipError_t partition_flags(uint32_t n, const uint8_t* flags, EmitFn emit, uint32_t* workspace, uint32_t** totals_out,
+inline hipError_t partition_flags(uint32_t n, const uint8_t* flags, int shift, EmitFn emit, uint32_t* workspace, uint32_t** totals_out,
                                   hipStream_t stream, PostFn post = PostFn()) {
   if (n % 64u != 0u || (reinterpret_cast<size_t>(flags) & 15u) != 0u) {
-    auto maskfn = [=] __device__(uint32_t i) -> uint32_t { return (uint32_t)flags[i]; };
+    auto maskfn = [=] __device__(uint32_t i) -> uint32_t { return ((uint32_t)flags[i] >> shift) & ((1u << NKEYS) - 1u); };
     return partition<NKEYS, kFlagRun / 64>(n, maskfn, emit, workspace, totals_out, stream, nullptr, 1u, post);
   }
   const uint32_t runs0 = (n + kFlagRun - 1) / kFlagRun;
@@ -342,12 +343,12 @@ inline hipError_t partition_flags(uint32_t n, const uint8_t* flags, EmitFn emit,
     hipLaunchKernelGGL((k_post_only<PostFn>), dim3(1), dim3(1), 0, stream, totals, post);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL((k_count_flags<NKEYS>), dim3(nb), dim3(kThreads), 0, stream, n, runs, flags, counts);
+  hipLaunchKernelGGL((k_count_flags<NKEYS>), dim3(nb), dim3(kThreads), 0, stream, n, runs, flags, shift, counts);
   if ((size_t)NKEYS * runs > 16384)
     hipLaunchKernelGGL((k_scan<NKEYS, 1024>), dim3(1), dim3(1024), 0, stream, runs, counts, totals, 0u, (const int*)nullptr, 1u, (uint32_t)kFlagRun, n);
   else
     hipLaunchKernelGGL((k_scan<NKEYS, 256>), dim3(1), dim3(256), 0, stream, runs, counts, totals, 0u, (const int*)nullptr, 1u, (uint32_t)kFlagRun, n);
-  hipLaunchKernelGGL((k_scatter_flags<NKEYS, EmitFn, PostFn>), dim3(nb), dim3(kThreads), 0, stream, n, runs, flags, emit, counts,
+  hipLaunchKernelGGL((k_scatter_flags<NKEYS, EmitFn, PostFn>), dim3(nb), dim3(kThreads), 0, stream, n, runs, flags, shift, emit, counts,
                      totals, post);
   return hipGetLastError();
 }

@@ -7,10 +7,14 @@
 // the reference's host-side index arithmetic literally, including the blur re-scan of refineExtremaLocation
 // (src/FeatureFactory.cu:251-259) whose untouched entries keep the values discardExtrema left behind.
 //
-// The second normalisation of the DoG levels (findKeyPoints, src/FeatureFactory.cu:472) is never materialised: every
-// consumer samples the raw level and applies (v - min) / (max - min) on the fly -- the same two float operations the
-// in-place normalize kernel performs, so the sampled values are bit-identical while 40 bytes/pixel of traffic vanish.
-// Gradients (calculatePixelGradients, src/Image.cu:1583-1598) are likewise evaluated at the sample sites only.
+// Neither normalisation of the reference is materialised, and neither are the DoG levels: the workspace holds the six
+// un-normalised Gaussian levels of every octave with their {min, max}, and the {min, max} of the five DoG levels
+// (ssrlcv_hip_sift_build_dog reduces them in the pass that also finds the extrema).  A consumer that needs the
+// twice-normalised DoG value of a pixel (findKeyPoints normalises the DoG levels again, src/FeatureFactory.cu:472)
+// evaluates ((N(level b+1) - N(level b)) - min_b) / (max_b - min_b) with N(x) = (x - min) / (max - min): the float
+// operations of normalize (src/Image.cu:1560-1565) and subtractImages (:842-845) in their order, so the values are the
+// reference's bit for bit while 20 + 40 bytes per pixel of DoG traffic never exist.
+// Gradients (calculatePixelGradients, src/Image.cu:1583-1598) are evaluated once per pixel into the polar tables.
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <math.h>
@@ -23,72 +27,37 @@ using svp::OctaveState;
 
 namespace {
 
-struct LevelSet {  // one octave's raw DoG levels + their min/max
-  const float* dog[svp::kDog];
-  const float* minmax;  // 5 x {min,max}
-  const float2* polar;  // {|grad|, atan2(gy,gx)} of the normalised levels 1..3, level-major; nullptr = not built
+struct LevelSet {  // one octave's scale space
+  const float* lvl[svp::kGauss];  // un-normalised Gaussian levels
+  const float* lvlMinMax;         // 6 x {min, max} of them
+  const float* minmax;            // 5 x {min, max} of the raw DoG levels
+  const float2* polar;            // {|grad|, atan2(gy,gx)} of the normalised DoG levels 1..3, level-major
   int w, h;
 };
 
-// (v - min) / (max - min) of normalize (src/Image.cu:1560-1565); sv::div_by returns the IEEE quotient and the compiler
-// shares the divisor's reciprocal between the samples of one level
-__device__ __forceinline__ float norm_sample(const float* __restrict__ lvl, float mn, float mx, size_t a) {
-  return sv::div_by(lvl[a] - mn, sv::make_divisor(mx - mn));
-}
-
-// ---- S8: extrema ---------------------------------------------------------------------------------------------------
-// findExtrema (src/FeatureFactory.cu:847-882): a pixel of level b (1..3) is kept when it equals the max or the min of
-// its 3x3x3 neighbourhood (non-strict); bit (b-1) of flags[p].  The 27-value max / min is separable: a thread walks
-// kExtRows rows of one column, forms the 3-wide row max / min of all five levels once per row (v_max3 / v_min3), keeps
-// three rows of them in registers and combines rows, then levels -- 19 loads and ~35 VALU per pixel instead of 45 and
-// ~80 for the direct form.  max and min are exact, so the grouping does not change any flag.
-constexpr int kExtRows = 8;
-__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
-__device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
-__global__ __launch_bounds__(256) void k_extrema_flags(LevelSet L, uint8_t* __restrict__ flags, float minAbs) {
-  const int x = blockIdx.x * 256 + threadIdx.x;
-  const int y0 = blockIdx.y * kExtRows;
-  if (x >= L.w) return;
-  const int xm = x > 0 ? x - 1 : 0, xp = x < L.w - 1 ? x + 1 : L.w - 1;  // border pixels never flag: clamping is harmless
-  const bool xin = x > 0 && x < L.w - 1;
-  float hmx[svp::kDog][3], hmn[svp::kDog][3], ctr[3][3];  // [level][row slot]; ctr: levels 1..3
-#pragma unroll
-  for (int step = 0; step < kExtRows + 2; ++step) {
-    const int r = step % 3;  // slot of the row loaded in this step (fully unrolled: static)
-    int yy = y0 + step - 1;
-    yy = yy < 0 ? 0 : (yy > L.h - 1 ? L.h - 1 : yy);
-#pragma unroll
-    for (int l = 0; l < svp::kDog; ++l) {
-      const float* p = L.dog[l] + (size_t)yy * L.w;
-      const float a0 = p[xm], a1 = p[x], a2 = p[xp];
-      hmx[l][r] = max3f(a0, a1, a2);
-      hmn[l][r] = min3f(a0, a1, a2);
-      if (l >= 1 && l <= 3) ctr[l - 1][r] = a1;
-    }
-    if (step >= 2) {
-      const int y = y0 + step - 2;         // the middle one of the three rows held
-      const int mid = (step - 1) % 3;
-      if (y < L.h) {
-        float vmx[svp::kDog], vmn[svp::kDog];
-#pragma unroll
-        for (int l = 0; l < svp::kDog; ++l) {
-          vmx[l] = max3f(hmx[l][0], hmx[l][1], hmx[l][2]);
-          vmn[l] = min3f(hmn[l][0], hmn[l][1], hmn[l][2]);
-        }
-        uint8_t f = 0;
-#pragma unroll
-        for (int bl = 1; bl <= 3; ++bl) {
-          const float hi = max3f(vmx[bl - 1], vmx[bl], vmx[bl + 1]);
-          const float lo = min3f(vmn[bl - 1], vmn[bl], vmn[bl + 1]);
-          const float c = ctr[bl - 1][mid];
-          // minAbs > 0 folds the first removeNoise (flagNoise: |intensity| < threshold is discarded) into the search
-          if ((hi == c || lo == c) && !(fabsf(c) < minAbs)) f |= (uint8_t)(1u << (bl - 1));
-        }
-        if (!(xin && y > 0 && y < L.h - 1)) f = 0;
-        flags[(size_t)y * L.w + x] = f;
-      }
-    }
+// DoG level b of an octave as its consumers see it: the two Gaussian levels it is the difference of and the constants
+// of the three normalisations.  sv::div_by returns the IEEE quotient through a shared reciprocal (device_math.h).
+struct DogView {
+  const float* lo;
+  const float* hi;
+  float mnLo, mnHi, mnDog;
+  sv::Divisor rgLo, rgHi, rgDog;
+  __device__ __forceinline__ float raw(size_t a) const {  // subtractImages of the two normalised levels: k_dog's arithmetic
+    return sv::div_by(hi[a] - mnHi, rgHi) - sv::div_by(lo[a] - mnLo, rgLo);
   }
+  __device__ __forceinline__ float norm(size_t a) const { return sv::div_by(raw(a) - mnDog, rgDog); }
+};
+__device__ __forceinline__ DogView dog_view(const LevelSet& L, int b) {
+  DogView v;
+  v.lo = L.lvl[b];
+  v.hi = L.lvl[b + 1];
+  v.mnLo = L.lvlMinMax[2 * b];
+  v.rgLo = sv::make_divisor(L.lvlMinMax[2 * b + 1] - v.mnLo);
+  v.mnHi = L.lvlMinMax[2 * b + 2];
+  v.rgHi = sv::make_divisor(L.lvlMinMax[2 * b + 3] - v.mnHi);
+  v.mnDog = L.minmax[2 * b];
+  v.rgDog = sv::make_divisor(L.minmax[2 * b + 1] - v.mnDog);
+  return v;
 }
 
 // ---- bookkeeping (one thread: the last block of the partition that precedes it, see compact.h last_block_post) ----------
@@ -188,13 +157,11 @@ __global__ __launch_bounds__(256) void k_flag_noise(const OctaveState* st, ssrlc
 __global__ __launch_bounds__(256) void k_flag_edges(const OctaveState* st, ssrlcv_sskeypoint* kps, LevelSet L, float thr) {
   int n = st->hasExtrema ? st->n : 0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    int seg = segment_of(st, i);
-    const float* px = L.dog[seg];
-    float mn = L.minmax[2 * seg], mx = L.minmax[2 * seg + 1];
+    const DogView D = dog_view(L, segment_of(st, i));
     ssrlcv_sskeypoint kp = kps[i];
     int lx = (int)roundf(kp.loc.x), ly = (int)roundf(kp.loc.y);
     int W = L.w;
-#define NS(yy, xx) norm_sample(px, mn, mx, (size_t)(yy) * W + (xx))
+#define NS(yy, xx) D.norm((size_t)(yy) * W + (xx))
     float h00 = -2.0f * NS(ly, lx);
     float h11 = h00 + NS(ly + 1, lx) + NS(ly - 1, lx);
     h00 += NS(ly, lx + 1) + NS(ly, lx - 1);
@@ -217,12 +184,10 @@ __global__ __launch_bounds__(256) void k_flag_noise_edges_window(const OctaveSta
     ssrlcv_sskeypoint kp = kps[i];
     bool drop = fabsf(kp.intensity) < noiseThr;
     {
-      int seg = segment_of(st, i);
-      const float* px = L.dog[seg];
-      float mn = L.minmax[2 * seg], mx = L.minmax[2 * seg + 1];
+      const DogView D = dog_view(L, segment_of(st, i));
       int lx = (int)roundf(kp.loc.x), ly = (int)roundf(kp.loc.y);
       int W = L.w;
-#define NS(yy, xx) norm_sample(px, mn, mx, (size_t)(yy) * W + (xx))
+#define NS(yy, xx) D.norm((size_t)(yy) * W + (xx))
       float h00 = -2.0f * NS(ly, lx);
       float h11 = h00 + NS(ly + 1, lx) + NS(ly - 1, lx);
       h00 += NS(ly, lx + 1) + NS(ly, lx - 1);
@@ -252,15 +217,10 @@ __global__ __launch_bounds__(256) void k_refine(const OctaveState* st, ssrlcv_ss
     float grad[3], temp[3], offset[3] = {0.0f, 0.0f, 0.0f};
     int bl = kp.blur;
     for (int attempt = 0; attempt < 5; ++attempt) {
-      const float* pl = L.dog[bl - 1];
-      const float* pm = L.dog[bl];
-      const float* pu = L.dog[bl + 1];
-      float lmn = L.minmax[2 * (bl - 1)], lmx = L.minmax[2 * (bl - 1) + 1];
-      float mmn = L.minmax[2 * bl], mmx = L.minmax[2 * bl + 1];
-      float umn = L.minmax[2 * (bl + 1)], umx = L.minmax[2 * (bl + 1) + 1];
-#define PM(yy, xx) norm_sample(pm, mmn, mmx, (size_t)(yy) * W + (xx))
-#define PL(yy, xx) norm_sample(pl, lmn, lmx, (size_t)(yy) * W + (xx))
-#define PU(yy, xx) norm_sample(pu, umn, umx, (size_t)(yy) * W + (xx))
+      const DogView Dl = dog_view(L, bl - 1), Dm = dog_view(L, bl), Du = dog_view(L, bl + 1);
+#define PM(yy, xx) Dm.norm((size_t)(yy) * W + (xx))
+#define PL(yy, xx) Dl.norm((size_t)(yy) * W + (xx))
+#define PU(yy, xx) Du.norm((size_t)(yy) * W + (xx))
       grad[0] = PM(ly, lx + 1) - PM(ly, lx - 1);
       grad[1] = PM(ly + 1, lx) - PM(ly - 1, lx);
       grad[2] = PU(ly, lx) - PL(ly, lx);
@@ -329,64 +289,96 @@ __global__ __launch_bounds__(256) void k_refine(const OctaveState* st, ssrlcv_ss
 
 // Gradient magnitude / direction of every pixel of the normalised DoG levels 1..3, computed once per image: the
 // orientation and descriptor windows of neighbouring key points overlap ~10x, and 4 gathers + 4 divisions + sqrtf +
-// atan2f per sample was two thirds of their instruction count.  The operations are those of normalize +
-// calculatePixelGradients, so values are bit-identical to the per-sample path; a block owns a 256 x 16 tile and every thread a column run of it, so a pixel is normalised once
-// (18 divisions per 16 pixels instead of 64: the kernel is VALU bound), vertical neighbours are the thread's own
-// registers, horizontal ones come through LDS, and the border rule of calculatePixelGradients (src/Image.cu:1583-1598:
-// a border pixel takes the stencil of its inner neighbour) is a choice of indices, not per-pixel address arithmetic.
+// atan2f per sample was two thirds of their instruction count.  The operations are those of normalize + subtractImages +
+// normalize + calculatePixelGradients, so values are bit-identical to the per-sample path.  A block owns a 256 x 16 tile
+// and every thread a column run of it; it walks the three DoG levels of the tile in turn, keeping the normalised column of
+// the upper Gaussian level in registers as the lower operand of the next DoG level, so the four Gaussian levels 1..4 are
+// read once (16 B per pixel; the DoG levels are never in memory) and every Gaussian pixel is normalised once.  Vertical
+// neighbours are the thread's own registers, horizontal ones come through LDS, and the border rule of
+// calculatePixelGradients (src/Image.cu:1583-1598: a border pixel takes the stencil of its inner neighbour) is a choice
+// of indices, not per-pixel address arithmetic.
 constexpr int kPolRows = 16;
 __global__ __launch_bounds__(256) void k_polar(LevelSet L, float2* __restrict__ out) {
   __shared__ float s_n[kPolRows][256 + 2];  // column c of the tile at [.][c + 1]; [.][0] / [.][257] = columns x0 - 1 / x0 + 256
   const int W = L.w, H = L.h;
-  const int x0 = blockIdx.x * 256, y0 = blockIdx.y * kPolRows, lvl = blockIdx.z + 1;
+  const int x0 = blockIdx.x * 256, y0 = blockIdx.y * kPolRows;
   const int t = threadIdx.x, x = x0 + t;
-  const float* __restrict__ px = L.dog[lvl];
-  const float mn = L.minmax[2 * lvl];
-  const sv::Divisor range = sv::make_divisor(L.minmax[2 * lvl + 1] - mn);
   // own column, rows y0 - 1 .. y0 + 16; rows / columns clamped into the image are loaded but never used (see below)
   const int xc = x < W ? x : W - 1;
-  float v[kPolRows + 2];
+  // halo role: thread t < 32 also carries one pixel of column x0 - 1 (even t) or x0 + 256 (odd t), row y0 + t / 2
+  const bool haloRole = t < 2 * kPolRows;
+  const int hside = t & 1;
+  int hx = hside ? x0 + 256 : x0 - 1;
+  hx = hx < 0 ? 0 : (hx > W - 1 ? W - 1 : hx);
+  int hy = y0 + (t >> 1);
+  hy = hy > H - 1 ? H - 1 : hy;
+  size_t rowOff[kPolRows + 2];
 #pragma unroll
   for (int j = 0; j < kPolRows + 2; ++j) {
     int yy = y0 - 1 + j;
     yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
-    v[j] = sv::div_by(px[(size_t)yy * W + xc] - mn, range);
+    rowOff[j] = (size_t)yy * W + xc;
   }
+  const size_t haloOff = (size_t)hy * W + hx;
+  // normalised column of Gaussian level 1 (the lower operand of DoG level 1)
+  float nlo[kPolRows + 2], nloH = 0.0f;
+  {
+    const float mn = L.lvlMinMax[2];
+    const sv::Divisor rg = sv::make_divisor(L.lvlMinMax[3] - mn);
+    const float* __restrict__ g = L.lvl[1];
 #pragma unroll
-  for (int i = 0; i < kPolRows; ++i) s_n[i][t + 1] = v[i + 1];
-  if (t < 2 * kPolRows) {
-    const int i = t >> 1, side = t & 1;
-    int hx = side ? x0 + 256 : x0 - 1;
-    hx = hx < 0 ? 0 : (hx > W - 1 ? W - 1 : hx);
-    int yy = y0 + i;
-    yy = yy > H - 1 ? H - 1 : yy;
-    s_n[i][side ? 257 : 0] = sv::div_by(px[(size_t)yy * W + hx] - mn, range);
+    for (int j = 0; j < kPolRows + 2; ++j) nlo[j] = sv::div_by(g[rowOff[j]] - mn, rg);
+    if (haloRole) nloH = sv::div_by(g[haloOff] - mn, rg);
   }
-  __syncthreads();
-  float2* __restrict__ lvlOut = out + (size_t)blockIdx.z * svp::polar_level_stride(W, H);
-  if (blockIdx.x == 0 && blockIdx.y == 0) {  // the zero entries around the table (see svp::polar_level_stride)
-    if (t == 0) lvlOut[0] = make_float2(0.0f, 0.0f);
-    for (int i = t; i < W + 1; i += 256) lvlOut[1 + (size_t)W * H + i] = make_float2(0.0f, 0.0f);
-  }
-  if (x >= W) return;
   // LDS columns of the two horizontal taps: x - 1 / x + 1, at the image border x / x + 2 resp. x - 2 / x
   const int cl = x == 0 ? 1 : (x == W - 1 ? t - 1 : t);
   const int cr = x == 0 ? 3 : (x == W - 1 ? t + 1 : t + 2);
-  float2* __restrict__ o = lvlOut + 1 + (size_t)y0 * W + x;
+#pragma unroll 1
+  for (int lvl = 1; lvl <= 3; ++lvl) {
+    const float mn = L.lvlMinMax[2 * (lvl + 1)];
+    const sv::Divisor rg = sv::make_divisor(L.lvlMinMax[2 * (lvl + 1) + 1] - mn);
+    const float dmn = L.minmax[2 * lvl];
+    const sv::Divisor drg = sv::make_divisor(L.minmax[2 * lvl + 1] - dmn);
+    const float* __restrict__ g = L.lvl[lvl + 1];
+    float v[kPolRows + 2];
 #pragma unroll
-  for (int i = 0; i < kPolRows; ++i) {
-    const int y = y0 + i;
-    if (y >= H) break;
-    float2 g;
-    g.x = s_n[i][cr] - s_n[i][cl];
-    // rows y + 1 / y - 1 are v[i + 2] / v[i]; at the border rows y + 2 / y resp. y / y - 2
-    const float up = y == 0 ? v[i + 3 < kPolRows + 2 ? i + 3 : kPolRows + 1] : (y == H - 1 ? v[i + 1] : v[i + 2]);
-    const float dn = y == 0 ? v[i + 1] : (y == H - 1 ? v[i > 0 ? i - 1 : 0] : v[i]);
-    g.y = up - dn;
-    float2 r;
-    r.x = sqrtf((g.x * g.x) + (g.y * g.y));
-    r.y = sv_atan2f(g.y, g.x);
-    o[(size_t)i * W] = r;
+    for (int j = 0; j < kPolRows + 2; ++j) {
+      const float nhi = sv::div_by(g[rowOff[j]] - mn, rg);
+      v[j] = sv::div_by((nhi - nlo[j]) - dmn, drg);  // the twice-normalised DoG value
+      nlo[j] = nhi;
+    }
+    if (lvl > 1) __syncthreads();  // the previous level's horizontal taps have been read
+#pragma unroll
+    for (int i = 0; i < kPolRows; ++i) s_n[i][t + 1] = v[i + 1];
+    if (haloRole) {
+      const float nhi = sv::div_by(g[haloOff] - mn, rg);
+      s_n[t >> 1][hside ? 257 : 0] = sv::div_by((nhi - nloH) - dmn, drg);
+      nloH = nhi;
+    }
+    __syncthreads();
+    float2* __restrict__ lvlOut = out + (size_t)(lvl - 1) * svp::polar_level_stride(W, H);
+    if (blockIdx.x == 0 && blockIdx.y == 0) {  // the zero entries around the table (see svp::polar_level_stride)
+      if (t == 0) lvlOut[0] = make_float2(0.0f, 0.0f);
+      for (int i = t; i < W + 1; i += 256) lvlOut[1 + (size_t)W * H + i] = make_float2(0.0f, 0.0f);
+    }
+    if (x < W) {
+      float2* __restrict__ o = lvlOut + 1 + (size_t)y0 * W + x;
+#pragma unroll
+      for (int i = 0; i < kPolRows; ++i) {
+        const int y = y0 + i;
+        if (y >= H) break;
+        float2 g2;
+        g2.x = s_n[i][cr] - s_n[i][cl];
+        // rows y + 1 / y - 1 are v[i + 2] / v[i]; at the border rows y + 2 / y resp. y / y - 2
+        const float up = y == 0 ? v[i + 3 < kPolRows + 2 ? i + 3 : kPolRows + 1] : (y == H - 1 ? v[i + 1] : v[i + 2]);
+        const float dn = y == 0 ? v[i + 1] : (y == H - 1 ? v[i > 0 ? i - 1 : 0] : v[i]);
+        g2.y = up - dn;
+        float2 r;
+        r.x = sqrtf((g2.x * g2.x) + (g2.y * g2.y));
+        r.y = sv_atan2f(g2.y, g2.x);
+        o[(size_t)i * W] = r;
+      }
+    }
   }
 }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -996,8 +988,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8), amdg
 LevelSet make_levels(const ssrlcv_sift_plan* plan, char* ws, int o) {
   LevelSet L;
   const svp::OctavePlan& oc = plan->oct[o];
-  for (int b = 0; b < svp::kDog; ++b) L.dog[b] = (const float*)(ws + oc.off_dog[b]);
-  L.minmax = (const float*)(ws + plan->off_minmax) + (size_t)o * 2 * (svp::kGauss + svp::kDog) + 2 * svp::kGauss;
+  for (int b = 0; b < svp::kGauss; ++b) L.lvl[b] = (const float*)(ws + plan->off_gauss[o][b]);
+  L.lvlMinMax = (const float*)(ws + plan->off_minmax) + (size_t)o * 2 * (svp::kGauss + svp::kDog);
+  L.minmax = L.lvlMinMax + 2 * svp::kGauss;
   L.polar = (const float2*)(ws + oc.off_polar);
   L.w = (int)oc.w;
   L.h = (int)oc.h;
@@ -1065,8 +1058,8 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
   if (!plan || !workspace || !numFeatures) return SSRLCV_ERR_INVALID_ARG;
   char* ws = (char*)workspace;
   OctaveState* states = (OctaveState*)(ws + plan->off_state);
-  const float noiseThreshold = 0.01f;  // src/SIFT_FeatureFactory.cu:58
-  const float edgeThreshold = 12.1f;   // :59
+  const float noiseThreshold = svp::kNoiseThreshold;  // src/SIFT_FeatureFactory.cu:58
+  const float edgeThreshold = svp::kEdgeThreshold;    // :59
   const int stop = plan->stopStage;
   const uint32_t maxO = plan->params.maxOrientations;
   // The four octaves' chains are independent until the feature offsets are summed, and each is a long run of small
@@ -1082,7 +1075,7 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
     if (stop >= 6) {
       for (int o = 0; o < svp::kOctaves; ++o) {
         const svp::OctavePlan& oc = plan->oct[o];
-        hipLaunchKernelGGL(k_polar, dim3((oc.w + 255) / 256, (oc.h + kPolRows - 1) / kPolRows, 3), dim3(256), 0, as->table,
+        hipLaunchKernelGGL(k_polar, dim3((oc.w + 255) / 256, (oc.h + kPolRows - 1) / kPolRows), dim3(256), 0, as->table,
                            make_levels(plan, ws, o), (float2*)(ws + oc.off_polar));
         SSRLCV_HIP_TRY(hipEventRecord(as->polarDone[o], as->table));
       }
@@ -1106,21 +1099,18 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
     const int nswaps = 2 * (stop >= 2) + (fused ? 1 : (stop >= 3) + (stop >= 4)) + (stop >= 6);
     hipLaunchKernelGGL(k_state_reset, dim3(1), dim3(1), 0, s, st);
     // --- searchForExtrema (src/FeatureFactory.cu:86-159) ---
-    // removeNoise(noiseThreshold * 0.8) (src/FeatureFactory.cu:484) follows the search directly and tests the raw DoG
-    // value fillExtrema stores as the intensity, so when the run goes past it the test is made where the extremum is
-    // found: the survivors, their order and extremaBlurIndices are those of search + discard, without the first list
-    // (1.33 M entries per 4096^2 image, 0.1 % of them noise) being written, flagged and compacted again.
-    const float firstNoise = stop >= 1 ? (float)(noiseThreshold * 0.8) : 0.0f;
-    hipLaunchKernelGGL(k_extrema_flags, dim3((oc.w + 255) / 256, (oc.h + kExtRows - 1) / kExtRows), dim3(256), 0, s, L, flags,
-                       firstNoise);
+    // findExtrema itself ran inside ssrlcv_hip_sift_build_dog (k_dogx: the DoG values exist only there); what is left is
+    // the compaction of the flag bytes into the list.  removeNoise(noiseThreshold * 0.8) (src/FeatureFactory.cu:484)
+    // follows the search directly and tests the raw DoG value fillExtrema stores as the intensity, so the flag byte
+    // carries a second set of bits for the extrema that pass it: when the run goes past that stage the list is built
+    // from those -- the survivors, their order and extremaBlurIndices are those of search + discard, without the first
+    // list (1.33 M entries per 4096^2 image, 0.1 % of them noise) being written, flagged and compacted again.
     {
       const uint32_t P = oc.w * oc.h;
       const int W = (int)oc.w;
       const int octaveId = o;
       const float s1 = oc.sigma[1], s2 = oc.sigma[2], s3 = oc.sigma[3];
-      const float* d1 = L.dog[1];
-      const float* d2 = L.dog[2];
-      const float* d3 = L.dog[3];
+      const LevelSet Lc = L;
       ssrlcv_sskeypoint* first = (nswaps & 1) ? B : A;
       auto emit = [=] __device__(uint32_t p, int b, uint32_t d) {
         if (d >= cap) return;
@@ -1129,14 +1119,14 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
         kp.blur = (int)b + 1;
         kp.loc.x = (float)(p % W);
         kp.loc.y = (float)(p / W);
-        kp.intensity = (b == 0 ? d1 : b == 1 ? d2 : d3)[p];
+        kp.intensity = dog_view(Lc, b + 1).raw(p);
         kp.sigma = b == 0 ? s1 : b == 1 ? s2 : s3;
         kp.theta = -1.0f;
         kp.discard = 0;
         first[d] = kp;
       };
       uint32_t* totals = nullptr;
-      hipError_t e = svc::partition_flags<3>(P, flags, emit, words, &totals, s);
+      hipError_t e = svc::partition_flags<3>(P, flags, stop >= 1 ? svp::kNoiseFlagShift : 0, emit, words, &totals, s);
       if (e != hipSuccess) return (int)e;
       // (a kernel of its own here: the pixel-domain scatter has thousands of blocks, and counting them down with one
       // same-address atomic each costs more than this launch)
@@ -1216,7 +1206,7 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
     if (!as) {
       for (int o = 0; o < svp::kOctaves; ++o) {
         const svp::OctavePlan& oc = plan->oct[o];
-        hipLaunchKernelGGL(k_polar, dim3((oc.w + 255) / 256, (oc.h + kPolRows - 1) / kPolRows, 3), dim3(256), 0, caller,
+        hipLaunchKernelGGL(k_polar, dim3((oc.w + 255) / 256, (oc.h + kPolRows - 1) / kPolRows), dim3(256), 0, caller,
                            set.L[o], (float2*)(ws + oc.off_polar));
       }
     }

@@ -34,6 +34,16 @@ __device__ __forceinline__ int sym_coord(int i, int l) {
   return (i > l - 1) ? ll - 1 - i : i;
 }
 
+// Mirror of the one-tile kernel: coordinates beyond the last pixel a valid output needs only meet zero weights, so they are
+// clamped first and one reflection is enough for sides of at least 2R (every level of a 4096^2 image); smaller levels
+// take the reference's modulo (sides down to 16 pixels: below that upstream itself reads out of bounds, see plan_create).
+__device__ __forceinline__ int mirror_into(int i, int l, int R) {
+  if (l < 64) return sym_coord(i, l);
+  i = i > l - 1 + R ? l - 1 + R : i;
+  i = i < 0 ? -1 - i : i;
+  return i > l - 1 ? 2 * l - 1 - i : i;
+}
+
 // float atomics on {min,max} via the integer-ordering trick (same idea as atomicMinFloat/atomicMaxFloat,
 // src/FeatureFactory.cu:769-780)
 __device__ __forceinline__ void atomic_min_f(float* addr, float v) {
@@ -181,12 +191,6 @@ struct ConvArgs {
   uint32_t rowsPerBlock;
   uint32_t x0base;  // first column of the launch's first strip (k_gauss_fused on the partial last strip)
   const uint8_t* u8;  // k_gauss_strip<R, true>: the u8 image (w/2 x h/2) whose 2x bilinear upsample is the input
-  // k_gauss_mfma<R, TW, true>: while it streams its input (gaussian level b+1) the loader also emits DoG level b =
-  // normalised(level b+1) - normalised(level b): both levels are complete, so their min / max are final
-  const float* dogPrev;       // level b (nullptr: no DoG emission)
-  float* dogOut;              // DoG level b
-  const float* dogLvlMinMax;  // {min_b, max_b, min_b+1, max_b+1}
-  float* dogMinMax;           // {min, max} of DoG level b (atomics)
   // k_gauss_mfma2 / k_gauss_tile: also emit the 2x2 bin of the output (S5, the next octave's input) from the accumulators
   float* binOut;  // (w/2) x (h/2), nullptr: no bin
   float wgt[33];  // taps are symmetric (w[k] == w[2R-k] bit for bit): only k = 0..R travel, in SGPRs
@@ -497,11 +501,11 @@ __global__ __launch_bounds__(kTX) void k_gauss_strip(ConvArgs a) {
 // band fills 65/80 of a 16-wide tile at R = 32.
 //   horizontal: D[16 rows][16 cols] = In[16 rows][16+2R cols] x T      A from the LDS row stage, B = per-lane constants
 //   vertical  : D^T[16 cols][16 rows] = H^T[16 cols][16+2R rows] x T             A from the LDS ring of H rows, B = constants
-// A block owns a 256-column strip and marches down 16 rows per step.  It has 8 waves in two roles, one wave of each
-// per SIMD: four waves stage the input rows and run the horizontal pass of step `it` (4 of the 16 column tiles each),
-// the other four run the vertical pass of step `it - 1` from the ring of H rows and store the result.  With a single role
-// per SIMD the matrix pipe sat idle 53 % of the time behind staging, address arithmetic, stores and barriers (PMC:
-// SQ_VALU_MFMA_BUSY_CYCLES); with two, each wave's non-MFMA work runs under the other wave's MFMAs.
+// A block owns a 256- or 128-column strip and marches down 16 rows per step.  It has 8 waves in two roles, one wave of
+// each per SIMD: four waves stage the input rows and run the horizontal pass of step `it` (their share of the column
+// tiles), the other four run the vertical pass of step `it - 1` from the ring of H rows and store the result.
+// (The first edition of this kernel, with per-element staging and the address arithmetic inside the MFMA loops, is in
+// the history up to round 2; k_gauss_mfma2 below replaced it, partial last strips go to the VALU kernel.)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMT = 16;            // rows per marching step of the MFMA kernel
@@ -526,297 +530,6 @@ struct MfmaCfg {
   static constexpr int STG = (TOT + 255) / 256;   // staged elements per horizontal-role thread (256 of them)
   static constexpr size_t ldsBytes = sizeof(float) * ((size_t)2 * kMT * SW + (size_t)RINGROWS * RSTR);
 };
-
-// ROWS = true: every strip of the launch is full (W % TW == 0) and the rows are 16-byte aligned (W % 4 == 0, aligned
-// base): the horizontal-role waves then stage WHOLE ROWS -- wave w4 owns rows 4 w4 .. 4 w4 + 3 of the 16-row tile, the
-// row index is wave-uniform (mirrored in SGPRs), a lane loads one float4 of the strip's interior and one halo float --
-// 8 loads and 12 LDS writes per thread and step instead of the 23 + 23 of the element-wise staging below (whose
-// per-element mirror / address arithmetic was ~115 VALU instructions per step).  Same values land in the same LDS
-// slots, so the passes and their results are unchanged.
-template <int R, int TW, bool ROWS>
-__global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma(ConvArgs a) {
-  using C = MfmaCfg<R, TW>;
-  constexpr int TPW = C::TPW;
-  extern __shared__ __attribute__((aligned(16))) float s_mem[];
-  float* s_ring = s_mem + 2 * kMT * C::SW;     // [RINGROWS][RSTR]; the two row stages [kMT][SW] sit in front
-  const int W = (int)a.w, H = (int)a.h;
-  const int x0 = blockIdx.x * TW;
-  const int y0 = blockIdx.y * (int)a.rowsPerBlock;
-  int nrows = (int)a.rowsPerBlock;
-  if (y0 + nrows > H) nrows = H - y0;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // One wave of each role per SIMD, whichever way the hardware deals the 8 waves of a workgroup onto the 4 SIMDs
-  // (w % 4 or w / 2): roles differ within the pairs (w, w + 4) and (2k, 2k + 1).  Measured: with both roles on the same
-  // SIMD pair nothing overlapped (time = staging skeleton + MFMA time).
-  const int role = (wave ^ (wave >> 2)) & 1, w4 = wave >> 1, htid = w4 * 64 + lane;
-  const int li = lane & 15, lk = lane >> 4;
-
-  // per-lane Toeplitz constants: tz[s] = w[4s + lk - li] (0 outside 0..2R); w is symmetric, R+1 taps in the kernarg
-  float tz[C::KS];
-#pragma unroll
-  for (int s = 0; s < C::KS; ++s) {
-    int t = 4 * s + lk - li;
-    int ti = t <= R ? t : 2 * R - t;
-    tz[s] = (t >= 0 && t <= 2 * R) ? a.wgt[ti < 0 ? 0 : ti] : 0.0f;
-  }
-  // The per-lane index turns the a.wgt reads into global loads.  Pin their completion here: otherwise the compiler's
-  // s_waitcnt pass, which only knows "tz may still be in flight" at the loop header, waits inside the MFMA loops with a
-  // vmcnt that also drains the row prefetch issued one iteration earlier (vmcnt is in order) -- measured: the matrix
-  // pipe idle 46 % of the time behind HBM latency.
-#pragma unroll
-  for (int s = 0; s < C::KS; ++s) asm volatile("" : "+v"(tz[s]));
-  // zero the ring and the stages once: band zeros multiply whatever sits there, it must be finite
-  for (int i = tid; i < (int)(C::ldsBytes / sizeof(float)); i += kMfmaThreads) s_mem[i] = 0.0f;
-
-  // ---- horizontal role: staging state.  Element e of this thread is float e*256 + htid of the [kMT][SW] tile; its
-  // column never changes.  Coordinates are clamped/mirrored into the image, so every load is unconditional: padding
-  // columns and the elements past the tile (dropped at the LDS store) re-read a valid pixel, their weight is 0.
-  constexpr int NSTG = ROWS ? 1 : C::STG;
-  int gxs[NSTG], rws[NSTG];
-  float pre[NSTG];
-  // row-wise staging state (ROWS): halo lane h < RP owns stage column h (image column x0 - RP + h), lanes RP ..
-  // NH - 1 the columns right of the strip; the overshoot columns past x0 + TW + R carry weight 0 and re-read a valid pixel
-  constexpr int NH = 2 * C::RP + (C::KP - C::K);
-  static_assert(NH <= 64, "one halo float per lane");
-  f32x4 preI[4];
-  float preHl[4];
-  const bool haloLane = lane < NH;
-  const int hcol = lane < C::RP ? lane : TW + lane;  // right halo starts at stage column RP + TW
-  int hgx = lane < C::RP ? x0 - C::RP + lane : x0 + TW + (lane - C::RP);
-  hgx = hgx > W - 1 + R ? W - 1 + R : hgx;
-  hgx = hgx < 0 ? -1 - hgx : hgx;
-  hgx = hgx > W - 1 ? 2 * W - 1 - hgx : hgx;
-  const bool interiorLane = 4 * lane < TW;
-  // DoG emission (ROWS only): the rows of this block's own output range pass through the loader exactly once
-  const bool emitDog = ROWS && a.dogOut != nullptr;
-  f32x4 prevI[4];
-  int emitRow[4] = {-1, -1, -1, -1};
-  float dmn = FLT_MAX, dmx = -FLT_MAX;
-  float lmn0 = 0.0f, lmn1 = 0.0f;
-  sv::Divisor rng0 = {1.0f, 1.0f}, rng1 = {1.0f, 1.0f};
-  if (emitDog && role == 0) {
-    lmn0 = a.dogLvlMinMax[0];
-    rng0 = sv::make_divisor(a.dogLvlMinMax[1] - lmn0);
-    lmn1 = a.dogLvlMinMax[2];
-    rng1 = sv::make_divisor(a.dogLvlMinMax[3] - lmn1);
-  }
-  if (role == 0 && !ROWS) {
-#pragma unroll
-    for (int e = 0; e < NSTG; ++e) {
-      int idx = e * 256 + htid;
-      idx = idx < C::TOT ? idx : C::TOT - 1;
-      int r = idx / C::SW, c = idx - r * C::SW;
-      int x = x0 - C::RP + c;
-      x = x > W - 1 + R ? W - 1 + R : x;
-      x = x < 0 ? -1 - x : x;                 // sym_coord for -l <= i < 0
-      x = x > W - 1 ? 2 * W - 1 - x : x;      // sym_coord for l <= i < 2l
-      gxs[e] = x;
-      rws[e] = r;
-    }
-  }
-  auto fetch = [&](int s) {
-    if (ROWS) {
-      const int ybase = y0 - R + s * kMT + 4 * __builtin_amdgcn_readfirstlane(w4);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        int y = ybase + k;  // wave-uniform
-        y = y > H - 1 + R ? H - 1 + R : y;
-        y = y < 0 ? -1 - y : y;
-        y = y > H - 1 ? 2 * H - 1 - y : y;
-        const float* row = a.in + (size_t)y * W;
-        if (interiorLane) preI[k] = *reinterpret_cast<const f32x4*>(row + x0 + 4 * lane);
-        if (haloLane) preHl[k] = row[hgx];
-        if (emitDog) {
-          const int yr = ybase + k;  // un-mirrored: a row of this block's own range is inside the image
-          emitRow[k] = (yr >= y0 && yr < y0 + nrows) ? yr : -1;
-          if (emitRow[k] >= 0 && interiorLane)
-            prevI[k] = *reinterpret_cast<const f32x4*>(a.dogPrev + (size_t)yr * W + x0 + 4 * lane);
-        }
-      }
-      return;
-    }
-    const int ybase = y0 - R + s * kMT;
-#pragma unroll
-    for (int e = 0; e < NSTG; ++e) {
-      int y = ybase + rws[e];
-      y = y > H - 1 + R ? H - 1 + R : y;
-      y = y < 0 ? -1 - y : y;
-      y = y > H - 1 ? 2 * H - 1 - y : y;
-      pre[e] = a.in[(size_t)y * W + gxs[e]];
-    }
-  };
-  auto stage_write = [&](int buf) {
-    float* s_in = s_mem + buf * kMT * C::SW;
-    if (ROWS) {
-      typedef float f32x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float* srow = s_in + (4 * w4 + k) * C::SW;  // SW is even and RP a multiple of 4: 8-byte aligned pairs
-        if (interiorLane) {
-          *reinterpret_cast<f32x2*>(srow + C::RP + 4 * lane) = f32x2{preI[k][0], preI[k][1]};
-          *reinterpret_cast<f32x2*>(srow + C::RP + 4 * lane + 2) = f32x2{preI[k][2], preI[k][3]};
-        }
-        if (haloLane) srow[hcol] = preHl[k];
-        if (emitDog && emitRow[k] >= 0 && interiorLane) {
-          // the arithmetic of k_dog: both levels normalised with the shared-reciprocal IEEE quotient, then subtracted
-          f32x4 d;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float cur = sv::div_by(preI[k][c] - lmn1, rng1);
-            const float prv = sv::div_by(prevI[k][c] - lmn0, rng0);
-            d[c] = cur - prv;
-            dmn = fminf(dmn, d[c]);
-            dmx = fmaxf(dmx, d[c]);
-          }
-          __builtin_nontemporal_store(d, reinterpret_cast<f32x4*>(a.dogOut + (size_t)emitRow[k] * W + x0 + 4 * lane));
-        }
-      }
-      return;
-    }
-#pragma unroll
-    for (int e = 0; e < NSTG; ++e)
-      if ((e + 1) * 256 <= C::TOT || e * 256 + htid < C::TOT) s_in[e * 256 + htid] = pre[e];
-  };
-  float mn = FLT_MAX, mx = -FLT_MAX;
-  // vertical role: the accumulators of the last vertical pass, stored one iteration later
-  constexpr int kNoPending = -(1 << 30);
-  f32x4 pend[TPW];
-  int pendJ = kNoPending;
-  // The vertical product is evaluated transposed, D^T[x][y] = sum_k H^T[x][k] * T[k][y] (same LDS reads, the ring rows
-  // as the A operand): a lane then holds four consecutive x of output row jbase + li -- one 16-byte store per tile
-  // instead of four 4-byte ones (measured 0.03-0.04 ms per 8192^2 level).
-  const bool vec4 = (W & 3) == 0 && (reinterpret_cast<size_t>(a.out) & 15) == 0;
-  auto store_pending = [&]() {
-    const int jbase = pendJ;
-    const int j = jbase + li;
-    const bool rowOk = j >= 0 && j < nrows;
-#pragma unroll
-    for (int t4 = 0; t4 < TPW; ++t4) {
-      const int gx = x0 + (w4 * TPW + t4) * 16 + lk * 4;
-      float* o = a.out + ((long)(y0 + j) * W + gx);
-      const f32x4 v = pend[t4];
-      if (rowOk && vec4 && gx + 3 < W) {
-        *reinterpret_cast<f32x4*>(o) = v;  // rows start 16-byte aligned when W % 4 == 0 (gx is a multiple of 4)
-        mn = fminf(fminf(mn, v[0]), fminf(v[1], fminf(v[2], v[3])));
-        mx = fmaxf(fmaxf(mx, v[0]), fmaxf(v[1], fmaxf(v[2], v[3])));
-      } else if (rowOk) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (gx + r < W) { o[r] = v[r]; mn = fminf(mn, v[r]); mx = fmaxf(mx, v[r]); }
-      }
-    }
-    pendJ = kNoPending;
-  };
-  const int steps = (nrows + 2 * R + kMT - 1) / kMT;
-  if (role == 0) fetch(0);
-  __syncthreads();  // zero fill complete
-  if (role == 0) {
-    stage_write(0);
-    if (steps > 1) fetch(1);
-  }
-  __syncthreads();
-  for (int it = 0; it <= steps; ++it) {
-    LAB_STAMP(0);
-    if (role == 0) {
-      if (it < steps) {
-        // ---- horizontal pass: H rows 16 it .. 16 it + 15 of this strip into the ring.  The wave's four column tiles
-        // are four independent accumulation chains; the A operands of k-step ks+1 are read under the MFMAs of ks.
-        const float* arow = s_mem + (it & 1) * kMT * C::SW + li * C::SW + (w4 * TPW) * 16 + (C::RP - R) + lk;
-        f32x4 acc[TPW];
-#pragma unroll
-        for (int t4 = 0; t4 < TPW; ++t4) acc[t4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        float av[3][TPW];  // A operands are read two k-steps ahead of the MFMAs that use them
-#pragma unroll
-        for (int t4 = 0; t4 < TPW; ++t4) av[0][t4] = arow[t4 * 16];
-        if (C::KS > 1) {
-#pragma unroll
-          for (int t4 = 0; t4 < TPW; ++t4) av[1][t4] = arow[t4 * 16 + 4];
-        }
-#pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks) {
-          if (ks + 2 < C::KS) {
-#pragma unroll
-            for (int t4 = 0; t4 < TPW; ++t4) av[(ks + 2) % 3][t4] = arow[t4 * 16 + 4 * (ks + 2)];
-          }
-          __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of this k-step's MFMAs
-#pragma unroll
-          for (int t4 = 0; t4 < TPW; ++t4) acc[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks % 3][t4], tz[ks], acc[t4], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        LAB_STAMP(1);
-        // D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
-        const int slot0 = (it * kMT) % C::RINGROWS;
-#pragma unroll
-        for (int t4 = 0; t4 < TPW; ++t4) {
-          float* dst = s_ring + (size_t)(slot0 + lk * 4) * C::RSTR + (w4 * TPW + t4) * 16 + li;
-          dst[0] = acc[t4][0];
-          dst[C::RSTR] = acc[t4][1];
-          dst[2 * C::RSTR] = acc[t4][2];
-          dst[3 * C::RSTR] = acc[t4][3];
-        }
-        LAB_STAMP(2);
-        // next step's rows into the other stage (last read one iteration ago), the step after that into registers
-        if (it + 1 < steps) {
-          stage_write((it + 1) & 1);
-          LAB_STAMP(3);
-          if (it + 2 < steps) fetch(it + 2);
-        }
-        LAB_STAMP(4);
-      }
-    } else {
-      // ---- vertical role.  The result of the previous iteration is stored first: its VALU / store work then runs
-      // while the horizontal waves occupy the matrix pipe, and this wave's MFMAs run while they stage the next rows
-      // (with both roles doing MFMAs first and bookkeeping second, neither overlapped anything).
-      if (pendJ != kNoPending) store_pending();
-      LAB_STAMP(1);
-      // vertical pass of step it - 1: output rows j = jbase + ii, ii = 0..15; B row kk is H row jbase + kk
-      const int jbase = (it - 1) * kMT - 2 * R;
-      if (it >= 1 && jbase + kMT > 0 && jbase < nrows) {
-        // ring offsets of the H rows jbase + kk of every k-step, computed up front: left inside the loop, the
-        // add / compare / select / multiply chain sat between the MFMAs of one k-step and the LDS reads of the next
-        // and stretched a k-step from 128 to 272 cycles (measured, vertical role alone).  One wrap at most
-        // (K <= RINGROWS); padded k-steps re-read a valid row, their weight is 0.
-        const int base = ((jbase % C::RINGROWS) + C::RINGROWS) % C::RINGROWS;  // wave-uniform
-        const float* colp = s_ring + (w4 * TPW) * 16 + li;
-        int boff[C::KS];
-#pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks) {
-          int kk = 4 * ks + lk;
-          kk = kk > C::K - 1 ? C::K - 1 : kk;
-          int slot = base + kk;
-          slot = slot >= C::RINGROWS ? slot - C::RINGROWS : slot;
-          boff[ks] = slot * C::RSTR;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        auto loadB = [&](int ks, float (&dst)[TPW]) {
-          const float* brow = colp + boff[ks];
-#pragma unroll
-          for (int t4 = 0; t4 < TPW; ++t4) dst[t4] = brow[t4 * 16];
-        };
-#pragma unroll
-        for (int t4 = 0; t4 < TPW; ++t4) pend[t4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        // B operands are read two k-steps ahead of the MFMAs that use them
-        float bv[3][TPW];
-        loadB(0, bv[0]);
-        if (C::KS > 1) loadB(1, bv[1]);
-#pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks) {
-          if (ks + 2 < C::KS) loadB(ks + 2, bv[(ks + 2) % 3]);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int t4 = 0; t4 < TPW; ++t4) pend[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[ks % 3][t4], tz[ks], pend[t4], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        pendJ = jbase;
-      }
-      LAB_STAMP(2);
-    }
-    __syncthreads();
-  }
-  if (role == 1 && pendJ != kNoPending) store_pending();
-  if (a.minmax) block_minmax_commit(mn, mx, a.minmax, s_mem);
-  if (emitDog) block_minmax_commit(dmn, dmx, a.dogMinMax, s_mem);
-}
 
 // S5 folded into a vertical-pass epilogue: lane (li, lk) holds four consecutive x of output row y (= row li of a 16-row
 // tile that starts on an even row); the row below sits in lane li ^ 1 of the same quad (DPP quad_perm [1,0,3,2]).  Even
@@ -1187,21 +900,14 @@ __global__ __launch_bounds__(kTileThreads) void k_gauss_tile(ConvArgs a) {
   int gx[C::NC];
 #pragma unroll
   for (int i = 0; i < C::NC; ++i) {
-    int x = x0 - C::RP + i * 64 + lane;
-    x = x > W - 1 + R ? W - 1 + R : x;
-    x = x < 0 ? -1 - x : x;
-    x = x > W - 1 ? 2 * W - 1 - x : x;
-    gx[i] = x;
+    gx[i] = mirror_into(x0 - C::RP + i * 64 + lane, W, R);
   }
   {
     float v[C::RPW][C::NC];
     const int r0 = wave * C::RPW;
 #pragma unroll
     for (int k = 0; k < C::RPW; ++k) {
-      int y = y0 - R + r0 + k;  // wave-uniform
-      y = y > H - 1 + R ? H - 1 + R : y;
-      y = y < 0 ? -1 - y : y;
-      y = y > H - 1 ? 2 * H - 1 - y : y;
+      const int y = mirror_into(y0 - R + r0 + k, H, R);  // wave-uniform
       const float* row = a.in + (size_t)y * W;
 #pragma unroll
       for (int i = 0; i < C::NC; ++i) v[k][i] = row[gx[i]];
@@ -1480,43 +1186,317 @@ __global__ __launch_bounds__(256) void k_dog_finalize(const float* __restrict__ 
   }
 }
 
+// ---- S6 + S7 + S8 without the DoG levels: the fused pass of ssrlcv_hip_sift_build_dog --------------------------------------
+// The reference writes five DoG levels per octave (subtractImages), reads them back to find their min / max, then reads
+// them three more times (extrema, gradients, refinement).  The pipeline keeps the six Gaussian levels instead and never
+// writes a DoG level: this pass streams the Gaussian levels once, forms DoG[b] = N(level b+1) - N(level b) in registers
+// (the arithmetic of k_dog, so the same values), reduces the DoG levels' {min, max} (the second normalisation of
+// findKeyPoints needs them, src/FeatureFactory.cu:472) and runs findExtrema (src/FeatureFactory.cu:847-882) on the values
+// while they are there: a pixel of DoG level b = 1..3 is flagged when it equals the max or the min of its 3x3x3
+// neighbourhood (non-strict).  Every later consumer (refinement, edge test, gradient tables) evaluates the DoG values it
+// samples from the two Gaussian levels again.  Per octave pixel: 24 B read + 1 B written, against 24 + 20 of k_dog and
+// another 20 + 1 of a separate extrema pass.
+//
+// A wave owns a strip of 62 * NPX columns and marches down `rowsPerWave` rows of it (plus one halo row above and below);
+// a lane holds NPX consecutive pixels, lanes 0 and 63 the strip's halo columns (strips overlap by two lanes: 3 % more
+// loads and arithmetic, against ~15 % for evaluating the halo columns in two masked lanes -- the pass is VALU bound -- and
+// the strip starts stay 4 NPX-byte aligned).  The 27-value max / min is separable and evaluated in the order columns (the
+// neighbours' pixels come by DPP wave shifts) -> levels -> rows, so the state carried from row to row is the
+// level-combined 3-wide max / min of the two previous rows (3 levels x 2 x NPX registers each) and the centre values of
+// the previous row.  max and min are exact: the grouping changes no flag.
+// flags[p]: bit k = extremum of DoG level k + 1; bit kNoiseFlagShift + k = the same and |value| >= minAbs (the first
+// removeNoise, which tests the raw DoG value).
+// One launch covers the DoG levels first .. last - 1: flags for the levels first + 1 .. last - 2, {min, max} for
+// mmFirst .. last - 1.  orFlags: the flag byte already holds the bits of an earlier launch of the split schedule.
+// (These four are template parameters: as wave-uniform kernel arguments they cut the row loop into fifty basic blocks
+// that the scheduler could not move loads across.)
+struct DogxArgs {
+  const float* lvl[svp::kGauss];
+  const float* lvlMinMax;  // 6 x {min, max}
+  uint8_t* flags;
+  float* partial;          // float[2 * kDog][kDogMaxWaves]: per-wave {min, max} partials, reduced by k_dog_finalize
+  int w, h;
+  int strips;              // ceil(w / (62 * NPX))
+  int rowsPerWave;
+  float minAbs;
+};
+
+__device__ __forceinline__ float dpp_from_lane_below(float v) {  // lane i <- lane i - 1 (wave_shr:1); lane 0 keeps its own
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_from_lane_above(float v) {  // lane i <- lane i + 1 (wave_shl:1); lane 63 keeps its own
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+__device__ __forceinline__ float dmin3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
+
+template <int NPX, int first, int last, int mmFirst, bool orFlags>
+__global__ __launch_bounds__(256) void k_dogx(DogxArgs a) {
+  typedef float vec __attribute__((ext_vector_type(NPX)));
+  const int lane = threadIdx.x & 63;
+  const int gwave = blockIdx.x * 4 + (threadIdx.x >> 6);  // adjacent waves = adjacent strips of the same rows
+  const int strip = gwave % a.strips, seg = gwave / a.strips;
+  const int W = a.w, H = a.h;
+  const int r0 = seg * a.rowsPerWave;
+  if (r0 >= H) return;  // wave-uniform
+  const int r1 = r0 + a.rowsPerWave < H ? r0 + a.rowsPerWave : H;
+  const int x = (strip * 62 + lane - 1) * NPX;     // first column of this lane (lane 0 of strip 0: -NPX)
+  const bool mine = lane >= 1 && lane <= 62 && x < W;  // W is a multiple of NPX: a lane is inside or outside as a whole
+  // lanes outside the image re-read the nearest pixels: they only ever neighbour border pixels, which do not flag, and
+  // what they add to the {min, max} are values of real pixels
+  const int xl = x < 0 ? 0 : (x < W ? x : W - NPX);
+  float lmn[svp::kGauss];
+  sv::Divisor rg[svp::kGauss];
+#pragma unroll
+  for (int b = 0; b < svp::kGauss; ++b) {
+    lmn[b] = 0.0f;
+    rg[b] = sv::Divisor{1.0f, 1.0f};
+    if (b >= first && b <= last) {
+      lmn[b] = a.lvlMinMax[2 * b];
+      rg[b] = sv::make_divisor(a.lvlMinMax[2 * b + 1] - lmn[b]);
+    }
+  }
+  float dmn[svp::kDog], dmx[svp::kDog];
+#pragma unroll
+  for (int b = 0; b < svp::kDog; ++b) { dmn[b] = FLT_MAX; dmx[b] = -FLT_MAX; }
+  // carried state: level-combined 3-wide max / min of rows y - 2 and y - 1, centre values of row y - 1 (levels 1..3)
+  float gmxA[3][NPX], gmnA[3][NPX], gmxB[3][NPX], gmnB[3][NPX], ctrB[3][NPX];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) { gmxA[k][i] = gmnA[k][i] = gmxB[k][i] = gmnB[k][i] = ctrB[k][i] = 0.0f; }
+  vec nxt[svp::kGauss];
+  auto fetch = [&](int y) {
+    y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);  // rows -1 and H only neighbour border rows, which do not flag
+    const size_t row = (size_t)y * W + xl;
+#pragma unroll
+    for (int b = first; b <= last; ++b) nxt[b] = __builtin_nontemporal_load(reinterpret_cast<const vec*>(a.lvl[b] + row));
+  };
+  fetch(r0 - 1);
+  for (int y = r0 - 1; y <= r1; ++y) {
+    vec cur[svp::kGauss];
+#pragma unroll
+    for (int b = first; b <= last; ++b) cur[b] = nxt[b];
+    if (y < r1) fetch(y + 1);
+    // normalised levels and DoG values of this row
+    float d[svp::kDog][NPX];
+    {
+      float prev[NPX];
+#pragma unroll
+      for (int b = first; b <= last; ++b) {
+        float n[NPX];
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) n[i] = sv::div_by(cur[b][i] - lmn[b], rg[b]);
+        if (b > first) {
+#pragma unroll
+          for (int i = 0; i < NPX; ++i) d[b - 1][i] = n[i] - prev[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) prev[i] = n[i];
+      }
+    }
+    // 3-wide max / min per level; the level's {min, max} ride on them (pixel i's triple covers i - 1 .. i + 1; the halo
+    // rows and columns a wave sees beyond its own are pixels of the image too)
+    float hmx[svp::kDog][NPX], hmn[svp::kDog][NPX];
+#pragma unroll
+    for (int b = first; b < last; ++b) {
+      const float left = dpp_from_lane_below(d[b][NPX - 1]);
+      const float right = dpp_from_lane_above(d[b][0]);
+#pragma unroll
+      for (int i = 0; i < NPX; ++i) {
+        const float l = i == 0 ? left : d[b][i - 1], r = i == NPX - 1 ? right : d[b][i + 1];
+        hmx[b][i] = dmax3(l, d[b][i], r);
+        hmn[b][i] = dmin3(l, d[b][i], r);
+      }
+      if (b >= mmFirst) {
+        if (NPX == 4) {
+          dmx[b] = dmax3(dmx[b], hmx[b][1], d[b][3]);
+          dmn[b] = dmin3(dmn[b], hmn[b][1], d[b][3]);
+        } else if (NPX == 2) {
+          dmx[b] = dmax3(dmx[b], d[b][0], d[b][1]);
+          dmn[b] = dmin3(dmn[b], d[b][0], d[b][1]);
+        } else {
+          dmx[b] = __builtin_fmaxf(dmx[b], d[b][0]);
+          dmn[b] = __builtin_fminf(dmn[b], d[b][0]);
+        }
+      }
+    }
+    // ... then across the levels k, k + 1, k + 2 (DoG level k + 1 and its two neighbours)
+    float gmx[3][NPX], gmn[3][NPX];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+      for (int i = 0; i < NPX; ++i) gmx[k][i] = gmn[k][i] = 0.0f;
+      if (k < first || k + 2 >= last) continue;
+#pragma unroll
+      for (int i = 0; i < NPX; ++i) {
+        gmx[k][i] = dmax3(hmx[k][i], hmx[k + 1][i], hmx[k + 2][i]);
+        gmn[k][i] = dmin3(hmn[k][i], hmn[k + 1][i], hmn[k + 2][i]);
+      }
+    }
+    // flags of row y - 1 (its three rows y - 2, y - 1, y are complete)
+    const int yo = y - 1;
+    if (yo >= r0 && yo < r1 && mine) {  // (uniform but for `mine`)
+      const bool rowIn = yo > 0 && yo < H - 1;
+      unsigned packed = 0;
+#pragma unroll
+      for (int i = 0; i < NPX; ++i) {
+        const bool in = rowIn && (x + i) > 0 && (x + i) < W - 1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          if (k < first || k + 2 >= last) continue;
+          const float hi = dmax3(gmxA[k][i], gmxB[k][i], gmx[k][i]);
+          const float lo = dmin3(gmnA[k][i], gmnB[k][i], gmn[k][i]);
+          const float c = ctrB[k][i];
+          const bool ext = in && (hi == c || lo == c);
+          const bool loud = ext && !(__builtin_fabsf(c) < a.minAbs);
+          packed |= (ext ? 1u << (8 * i + k) : 0u) | (loud ? 1u << (8 * i + svp::kNoiseFlagShift + k) : 0u);
+        }
+      }
+      uint8_t* fp = a.flags + (size_t)yo * W + x;
+      if (NPX == 4) {
+        unsigned* p4 = reinterpret_cast<unsigned*>(fp);
+        *p4 = orFlags ? (*p4 | packed) : packed;
+      } else if (NPX == 2) {
+        unsigned short* p2 = reinterpret_cast<unsigned short*>(fp);
+        *p2 = (unsigned short)(orFlags ? (*p2 | packed) : packed);
+      } else {
+        *fp = (uint8_t)(orFlags ? (*fp | packed) : packed);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (k < first || k + 2 >= last) continue;
+#pragma unroll
+      for (int i = 0; i < NPX; ++i) {
+        gmxA[k][i] = gmxB[k][i]; gmnA[k][i] = gmnB[k][i];
+        gmxB[k][i] = gmx[k][i]; gmnB[k][i] = gmn[k][i];
+        ctrB[k][i] = d[k + 1][i];
+      }
+    }
+  }
+  // per-wave {min, max} partials (k_dog_finalize reduces them: no atomics)
+#pragma unroll
+  for (int b = mmFirst; b < last; ++b) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      dmn[b] = fminf(dmn[b], __shfl_xor(dmn[b], o, 64));
+      dmx[b] = fmaxf(dmx[b], __shfl_xor(dmx[b], o, 64));
+    }
+    if (lane == 0) {
+      a.partial[(size_t)(2 * b) * svp::kDogMaxWaves + gwave] = dmn[b];
+      a.partial[(size_t)(2 * b + 1) * svp::kDogMaxWaves + gwave] = dmx[b];
+    }
+  }
+}
+
+// launches k_dogx + k_dog_finalize for the DoG levels first .. last - 1 of one octave (see k_dogx)
+int launch_dogx(const float* const levels[svp::kGauss], const float* levelMinMax, uint32_t w, uint32_t h, uint8_t* flags,
+                float* dogMinMax, float* partial, int first, int last, int mmFirst, bool orFlags, float minAbs,
+                unsigned targetWaves, hipStream_t st) {
+  if (first < 0 || last > svp::kDog || last - first < 1 || mmFirst < first || mmFirst >= last) return SSRLCV_ERR_INVALID_ARG;
+  DogxArgs a;
+  for (int b = 0; b < svp::kGauss; ++b) a.lvl[b] = levels[b];
+  a.lvlMinMax = levelMinMax;
+  a.flags = flags;
+  a.partial = partial;
+  a.w = (int)w;
+  a.h = (int)h;
+  a.minAbs = minAbs;
+  static const int forceNpx = getenv("SSRLCV_DOGX_NPX") ? atoi(getenv("SSRLCV_DOGX_NPX")) : 0;
+  bool aligned16 = (w & 3) == 0, aligned8 = (w & 1) == 0;
+  for (int b = first; b <= last; ++b) {
+    aligned16 = aligned16 && (reinterpret_cast<size_t>(levels[b]) & 15) == 0;
+    aligned8 = aligned8 && (reinterpret_cast<size_t>(levels[b]) & 7) == 0;
+  }
+  aligned16 = aligned16 && (reinterpret_cast<size_t>(flags) & 3) == 0;
+  aligned8 = aligned8 && (reinterpret_cast<size_t>(flags) & 1) == 0;
+  // pixels per lane: 4 where the rows are 16-byte aligned (2.15 vector instructions per pixel against 2.7 with 2; 1.89 against
+  // 1.96 ms per 4096^2 build_dog); SSRLCV_DOGX_NPX=1 / 2 force fewer
+  int npx = aligned16 ? 4 : aligned8 ? 2 : 1;
+  if (forceNpx == 2 && aligned8) npx = 2;
+  if (forceNpx == 1) npx = 1;
+  a.strips = (int)((w + 62 * npx - 1) / (62 * npx));
+  if (targetWaves > svp::kDogMaxWaves) targetWaves = svp::kDogMaxWaves;
+  // rows per wave: about targetWaves waves in the launch, at least 16 rows (2 halo rows per segment)
+  unsigned segs = targetWaves / (unsigned)a.strips;
+  if (segs < 1) segs = 1;
+  unsigned rows = (h + segs - 1) / segs;
+  if (rows < 16) rows = 16;
+  a.rowsPerWave = (int)rows;
+  segs = (h + rows - 1) / rows;
+  const unsigned waves = segs * (unsigned)a.strips;
+  if (waves > svp::kDogMaxWaves) return SSRLCV_ERR_UNSUPPORTED;
+  const dim3 grid((waves + 3) / 4);
+  // waves of the last block beyond `waves` return at once (r0 >= H) without touching their partial slot: finalize reads
+  // `waves` slots only
+#define SSRLCV_LAUNCH_DOGX(F, L, M, O)                                                               \
+  do {                                                                                              \
+    if (npx == 4) hipLaunchKernelGGL((k_dogx<4, F, L, M, O>), grid, dim3(256), 0, st, a);           \
+    else if (npx == 2) hipLaunchKernelGGL((k_dogx<2, F, L, M, O>), grid, dim3(256), 0, st, a);      \
+    else hipLaunchKernelGGL((k_dogx<1, F, L, M, O>), grid, dim3(256), 0, st, a);                    \
+  } while (0)
+  if (first == 0 && last == 5 && mmFirst == 0 && !orFlags) SSRLCV_LAUNCH_DOGX(0, 5, 0, false);
+  else if (first == 0 && last == 3 && mmFirst == 0 && !orFlags) SSRLCV_LAUNCH_DOGX(0, 3, 0, false);
+  else if (first == 1 && last == 5 && mmFirst == 3 && orFlags) SSRLCV_LAUNCH_DOGX(1, 5, 3, true);
+  else return SSRLCV_ERR_INVALID_ARG;  // the three launches build_dog's schedule is made of
+#undef SSRLCV_LAUNCH_DOGX
+  hipLaunchKernelGGL(k_dog_finalize, dim3((unsigned)(last - mmFirst)), dim3(256), 0, st, partial, waves, mmFirst, dogMinMax);
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
+}
+
 // u8src (nullable): the convolution's input is the 2x upsample of this u8 image (w/2 x h/2) and `in` is not read; only
 // honoured where upsample_fusable() says so (row-staged VALU kernel on full, aligned strips)
 bool upsample_fusable(uint32_t w, uint32_t h, int taps) {
   static const bool off = getenv("SSRLCV_NO_UPSAMPLE_FUSION") != nullptr || getenv("SSRLCV_GAUSS_MFMA") != nullptr;
   return !off && taps / 2 <= 8 && w % kTX == 0 && (w & 3) == 0 && (h & 1) == 0;
 }
-// DoG emission by a convolution's loader (k_gauss_mfma<.., true>): possible where that kernel runs on full, aligned strips
-struct DogFuse {
-  const float* prev;       // gaussian level b (the convolution's input is level b+1)
-  float* out;              // DoG level b
-  const float* lvlMinMax;  // {min_b, max_b, min_b+1, max_b+1}
-  float* dogMinMax;        // {min, max} of DoG level b
-};
-bool dog_fusable(const float* in, uint32_t w, uint32_t h, int taps) {
-  // Off by default: measured on MI355X (4096^2 image) the stage went from 2.36 to 2.58 ms with it -- the loader's
-  // 15 VALU instructions per pixel compete with the f32 MFMAs for the same issue slots (they do not overlap on this
-  // part) and the two extra streams push the convolutions towards the HBM bound, which costs more than the four DoG
-  // levels the streaming kernel no longer has to produce (0.71 -> 0.19 ms).  SSRLCV_DOG_FUSION=1 enables it (same results).
-  static const bool on = getenv("SSRLCV_DOG_FUSION") != nullptr && getenv("SSRLCV_GAUSS_VALU") == nullptr &&
-                         getenv("SSRLCV_GAUSS_ELEMENTWISE") == nullptr;
-  if (!on) return false;
-  const int R = taps / 2;
-  if (R < 9 || R > 32) return false;  // the MFMA formulation serves R >= 11 (templated radii 11, 16, 23, 32)
-  static const bool forceWide = getenv("SSRLCV_GAUSS_WIDE") != nullptr, forceNarrow = getenv("SSRLCV_GAUSS_NARROW") != nullptr;
-  const bool wide = R > 23 || forceWide || (!forceNarrow && (size_t)w * h >= ((size_t)1 << 25));
-  const uint32_t tw = wide ? 256 : 128;
-  return (w & 3) == 0 && (reinterpret_cast<size_t>(in) & 15) == 0 && w % tw == 0;
+
+// VALU formulation: full 256-column strips with 16-byte aligned rows take the row-staged kernel, a partial last strip (or
+// everything, when the rows are not aligned) the generic one.  firstColumn > 0: only the strips from that column on (the
+// remainder of a launch whose full strips went to the MFMA kernel).
+void launch_valu(ConvArgs a, int RT, uint32_t firstColumn, hipStream_t st) {
+  const uint32_t w = a.w, h = a.h;
+  // rows per block: aim for >= 1024 blocks, never below 64 rows (halo recompute = 2R / rows).  Sizing the launch to
+  // whole rounds of resident blocks (768 slots) was tried and measured no different on MI355X.
+  const uint32_t bx = (w - firstColumn + kTX - 1) / kTX;
+  uint32_t rows = h;
+  while (rows > 64 && ((w + kTX - 1) / kTX) * ((h + rows - 1) / rows) < 1024) rows = (rows + 1) / 2;
+  rows = (rows + kNR - 1) / kNR * kNR;
+  a.rowsPerBlock = rows;
+  const uint32_t by = (h + rows - 1) / rows;
+  const bool aligned = firstColumn == 0 && (w & 3) == 0 && (a.u8 || (reinterpret_cast<size_t>(a.in) & 15) == 0);
+  const uint32_t nFull = aligned ? w / kTX : 0;
+#define SSRLCV_LAUNCH_VALU(RR)                                                                                 \
+  do {                                                                                                          \
+    if (nFull && a.u8) hipLaunchKernelGGL((k_gauss_strip<RR, true>), dim3(nFull, by), dim3(kTX), 0, st, a);     \
+    else if (nFull) hipLaunchKernelGGL((k_gauss_strip<RR, false>), dim3(nFull, by), dim3(kTX), 0, st, a);       \
+    if (nFull < bx) {                                                                                           \
+      a.x0base = firstColumn + nFull * kTX;                                                                     \
+      hipLaunchKernelGGL(k_gauss_fused<RR>, dim3(bx - nFull, by), dim3(kTX), 0, st, a);                         \
+    }                                                                                                           \
+  } while (0)
+  switch (RT) {
+    case 6: SSRLCV_LAUNCH_VALU(6); break;
+    case 8: SSRLCV_LAUNCH_VALU(8); break;
+    case 11: SSRLCV_LAUNCH_VALU(11); break;
+    case 16: SSRLCV_LAUNCH_VALU(16); break;
+    case 23: SSRLCV_LAUNCH_VALU(23); break;
+    default: SSRLCV_LAUNCH_VALU(32); break;
+  }
+#undef SSRLCV_LAUNCH_VALU
 }
+
 // binOut (nullable): where the 2x2 bin of the result may be written by the convolution itself; *binned tells whether it was
-// (only k_gauss_mfma2 / k_gauss_tile do it, for even sizes with W % 4 == 0) -- otherwise the caller runs k_bin2x
+// (only k_gauss_mfma2 / k_gauss_tile do it, for even sizes with W % 4 == 0 and no partial strip) -- otherwise the caller
+// runs k_bin2x
 int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h, int taps, const float* weights_host,
-                float* minmax, hipStream_t st, const uint8_t* u8src = nullptr, const DogFuse* dog = nullptr,
-                float* binOut = nullptr, bool* binned = nullptr) {
+                float* minmax, hipStream_t st, const uint8_t* u8src = nullptr, float* binOut = nullptr,
+                bool* binned = nullptr) {
   if (taps < 1 || (taps & 1) == 0 || taps > svp::kMaxTaps) return SSRLCV_ERR_INVALID_ARG;
   int R = taps / 2;
   if (R > 32) return SSRLCV_ERR_UNSUPPORTED;  // the pipeline's sigma ladder never exceeds 65 taps
-  if (w < 64 || h < 64) return SSRLCV_ERR_UNSUPPORTED;  // fused kernel mirrors without modulo: needs size >= 2R
   ConvArgs a;
   a.in = in;
   a.out = out;
@@ -1524,6 +1504,7 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
   a.w = w;
   a.h = h;
   a.x0base = 0;
+  a.rowsPerBlock = h;
   a.binOut = nullptr;
   if (binned) *binned = false;
   static const bool noBinFold = getenv("SSRLCV_NO_BIN_FUSION") != nullptr;
@@ -1533,33 +1514,14 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
 #endif
   a.u8 = u8src;
   if (u8src && !upsample_fusable(w, h, taps)) return SSRLCV_ERR_INVALID_ARG;
-  a.dogPrev = nullptr;
-  a.dogOut = nullptr;
-  a.dogLvlMinMax = nullptr;
-  a.dogMinMax = nullptr;
-  if (dog) {
-    if (!dog_fusable(in, w, h, taps)) return SSRLCV_ERR_INVALID_ARG;
-    a.dogPrev = dog->prev;
-    a.dogOut = dog->out;
-    a.dogLvlMinMax = dog->lvlMinMax;
-    a.dogMinMax = dog->dogMinMax;
-  }
   memset(a.wgt, 0, sizeof a.wgt);
-  // pad the tap set symmetrically into the smallest templated radius: extra taps carry weight 0 and would change
-  // the fmaf chain (0*x + s is exact, so the result is identical) -- only exact radii are dispatched below anyway.
+  // pad the tap set symmetrically into the smallest templated radius: extra taps carry weight 0 and do not change the
+  // fmaf chain (0*x + s is exact, so the result is identical)
   int RT = R <= 6 ? 6 : R <= 8 ? 8 : R <= 11 ? 11 : R <= 16 ? 16 : R <= 23 ? 23 : 32;
   for (int k = 0; k <= R; ++k) {
     if (weights_host[k] != weights_host[taps - 1 - k]) return SSRLCV_ERR_UNSUPPORTED;  // symmetric taps only
     a.wgt[(RT - R) + k] = weights_host[k];
   }
-  // rows per block: aim for >= 1024 blocks, never below 64 rows (halo recompute = 2R / rows).  Sizing the launch to
-  // whole rounds of resident blocks (768 slots) was tried and measured no different on MI355X.
-  uint32_t bx = (w + kTX - 1) / kTX;
-  uint32_t rows = h;
-  while (rows > 64 && bx * ((h + rows - 1) / rows) < 1024) rows = (rows + 1) / 2;
-  rows = (rows + kNR - 1) / kNR * kNR;
-  a.rowsPerBlock = rows;
-  dim3 grid(bx, (h + rows - 1) / rows);
   // Two bit-identical formulations.  Measured per 16384^2 level on MI355X (ms, taps 13/17/23/33/47/65): VALU marching
   // kernel (row-staged strips) 0.464/0.517/0.690/0.654/1.120/1.102, f32-MFMA banded Toeplitz -/-/0.613/0.669/0.770/0.875
   // -- the band wastes (16 + 2R - taps) / (16 + 2R) of the matrix pipe, more than half at R = 6, and the VALU kernel is
@@ -1571,9 +1533,12 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
   // small levels (<= 1024^2): the tile kernel (no marching).  Measured inside build_dog on a 4096^2 image (octave 3 =
   // 1024^2, octave 2 = 2048^2): marching kernels everywhere 2.079 ms, tile kernel for octave 3 2.065, for octaves 2 and
   // 3 2.133 (a 2048^2 level is 1024 tiles, four rounds of one-per-CU blocks).  SSRLCV_GAUSS_TILE_MAXPX=<pixels> moves
-  // the threshold (0 = never).
+  // the threshold (0 = never).  Levels with a side below 64 pixels always go here: it is the one kernel that mirrors with
+  // the reference's modulo (the marching kernels reflect once, which needs a side of at least 2R).
   static const size_t tileMaxPx = getenv("SSRLCV_GAUSS_TILE_MAXPX") ? (size_t)atoll(getenv("SSRLCV_GAUSS_TILE_MAXPX")) : ((size_t)1 << 20);
-  if (!u8src && !dog && !forceValu && (size_t)w * h <= tileMaxPx) {
+  const bool tiny = w < 64 || h < 64;
+  if (tiny || (!u8src && !forceValu && (size_t)w * h <= tileMaxPx)) {
+    if (u8src) return SSRLCV_ERR_INVALID_ARG;
     if (canBin) { a.binOut = binOut; if (binned) *binned = true; }
 #define SSRLCV_LAUNCH_TILE(RR)                                                                                     \
   do {                                                                                                              \
@@ -1597,78 +1562,31 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
     SSRLCV_LAUNCH_CHECK();
     return SSRLCV_OK;
   }
-  if (!useMfma) {
-    // full strips with 16-byte aligned rows take the row-staged kernel, a partial last strip (or everything, when the
-    // rows are not aligned) the generic one
-    const bool aligned = (w & 3) == 0 && (u8src || (reinterpret_cast<size_t>(in) & 15) == 0);
-    const uint32_t nFull = aligned ? w / kTX : 0;
-#define SSRLCV_LAUNCH_VALU(RR)                                                                              \
-  do {                                                                                                       \
-    if (nFull && u8src) hipLaunchKernelGGL((k_gauss_strip<RR, true>), dim3(nFull, grid.y), dim3(kTX), 0, st, a); \
-    else if (nFull) hipLaunchKernelGGL((k_gauss_strip<RR, false>), dim3(nFull, grid.y), dim3(kTX), 0, st, a); \
-    if (nFull < bx) {                                                                                        \
-      a.x0base = nFull * kTX;                                                                                \
-      hipLaunchKernelGGL(k_gauss_fused<RR>, dim3(bx - nFull, grid.y), dim3(kTX), 0, st, a);                  \
-    }                                                                                                        \
-  } while (0)
-    switch (RT) {
-      case 6: SSRLCV_LAUNCH_VALU(6); break;
-      case 8: SSRLCV_LAUNCH_VALU(8); break;
-      case 11: SSRLCV_LAUNCH_VALU(11); break;
-      case 16: SSRLCV_LAUNCH_VALU(16); break;
-      case 23: SSRLCV_LAUNCH_VALU(23); break;
-      default: SSRLCV_LAUNCH_VALU(32); break;
-    }
-#undef SSRLCV_LAUNCH_VALU
-  } else {
-    // one or two blocks are resident per CU (LDS): size the strips so that the launch is about one round of them;
-    // 16-row steps, at least 4 steps of payload per 2R halo
-#define SSRLCV_LAUNCH_MFMA(RR, TW)                                                                                \
-  do {                                                                                                              \
-    static int blocksPerCu = 0, cus = 0;                                                                            \
-    if (!blocksPerCu) {                                                                                             \
-      SSRLCV_HIP_TRY(hipFuncSetAttribute((const void*)k_gauss_mfma<RR, TW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                         (int)MfmaCfg<RR, TW>::ldsBytes));                                          \
-      SSRLCV_HIP_TRY(hipFuncSetAttribute((const void*)k_gauss_mfma<RR, TW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                         (int)MfmaCfg<RR, TW>::ldsBytes));                                          \
-      int dev = 0, occ = 0;                                                                                         \
-      SSRLCV_HIP_TRY(hipGetDevice(&dev));                                                                           \
-      SSRLCV_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));                      \
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_gauss_mfma<RR, TW, true>, kMfmaThreads,  \
-                                                       MfmaCfg<RR, TW>::ldsBytes) != hipSuccess || occ < 1)         \
-        occ = 1;                                                                                                    \
-      blocksPerCu = occ;                                                                                            \
-    }                                                                                                               \
-    const uint32_t bxm = (w + (TW) - 1) / (TW);                                                                     \
-    uint32_t by = ((uint32_t)(blocksPerCu * cus) + bxm - 1) / bxm;                                                  \
-    rows = (h + by - 1) / by;                                                                                       \
-    rows = rows < 64 ? 64 : rows;                                                                                   \
-    rows = (rows + kMT - 1) / kMT * kMT;                                                                            \
-    a.rowsPerBlock = rows;                                                                                          \
-    grid = dim3(bxm, (h + rows - 1) / rows);                                                                        \
-    const size_t ldsB = MfmaCfg<RR, TW>::ldsBytes;                                                                  \
-    if (rowStaging && w % (TW) == 0)                                                                                \
-      hipLaunchKernelGGL((k_gauss_mfma<RR, TW, true>), grid, dim3(kMfmaThreads), ldsB, st, a);                      \
-    else                                                                                                            \
-      hipLaunchKernelGGL((k_gauss_mfma<RR, TW, false>), grid, dim3(kMfmaThreads), ldsB, st, a);                     \
-  } while (0)
-    // 128-column strips let two blocks (8 waves each) share a CU's 160 KB of LDS (R <= 23).  Alone on the chip they are
-    // slower than the 256-column ones (more halo, two accumulation chains per wave instead of four: 0.632 / 0.834 / 0.801
-    // against 0.608 / 0.673 / 0.771 ms per 16384^2 level at 23 / 33 / 47 taps), but octaves >= 1 run beside the DoG kernel
-    // of the previous octave, whose resident blocks keep the big ones off the CUs: the narrow strips are used for the
-    // smaller levels (build_dog 2.57 -> 2.48 ms per 4096^2 image).  SSRLCV_GAUSS_WIDE=1 / SSRLCV_GAUSS_NARROW=1 force one.
-    static const bool forceWide = getenv("SSRLCV_GAUSS_WIDE") != nullptr, forceNarrow = getenv("SSRLCV_GAUSS_NARROW") != nullptr;
-    static const bool noRowStaging = getenv("SSRLCV_GAUSS_ELEMENTWISE") != nullptr;
-    const bool rowStaging = !noRowStaging && (w & 3) == 0 && (reinterpret_cast<size_t>(in) & 15) == 0;
-    const bool wide = forceWide || (!forceNarrow && (size_t)w * h >= ((size_t)1 << 25));
-    // second edition (k_gauss_mfma2): full aligned strips only, radii padded to even values
-    static const bool noMfma2 = getenv("SSRLCV_GAUSS_MFMA1") != nullptr;
-    if (!noMfma2 && !dog && rowStaging && (reinterpret_cast<size_t>(out) & 15) == 0 && (uint64_t)w * h * 4 < ((uint64_t)1 << 32) &&
-        w % (wide || R > 24 ? 256u : 128u) == 0) {
-      const int R2 = R <= 6 ? 6 : R <= 8 ? 8 : R <= 12 ? 12 : R <= 16 ? 16 : R <= 24 ? 24 : 32;
-      if (canBin) { a.binOut = binOut; if (binned) *binned = true; }
-      memset(a.wgt, 0, sizeof a.wgt);
-      for (int k = 0; k <= R; ++k) a.wgt[(R2 - R) + k] = weights_host[k];
+  // the MFMA kernel serves full strips of 16-byte aligned rows; what is left of the width goes to the VALU kernel
+  // 128-column strips let two blocks (8 waves each) share a CU's 160 KB of LDS (R <= 24).  Alone on the chip they are
+  // slower than the 256-column ones (more halo, two accumulation chains per wave instead of four: 0.632 / 0.834 / 0.801
+  // against 0.608 / 0.673 / 0.771 ms per 16384^2 level at 23 / 33 / 47 taps), but octaves >= 1 run beside the DoG pass
+  // of the previous octave, whose resident blocks keep the big ones off the CUs: the narrow strips are used for the
+  // smaller levels (build_dog 2.57 -> 2.48 ms per 4096^2 image).  SSRLCV_GAUSS_WIDE=1 / SSRLCV_GAUSS_NARROW=1 force one.
+  static const bool forceWide = getenv("SSRLCV_GAUSS_WIDE") != nullptr, forceNarrow = getenv("SSRLCV_GAUSS_NARROW") != nullptr;
+  const bool wide = R > 24 || forceWide || (!forceNarrow && (size_t)w * h >= ((size_t)1 << 25));
+  const uint32_t tw = wide ? 256u : 128u;
+  const bool mfmaOk = useMfma && (w & 3) == 0 && (reinterpret_cast<size_t>(in) & 15) == 0 && (reinterpret_cast<size_t>(out) & 15) == 0 &&
+                      (uint64_t)w * h * 4 < ((uint64_t)1 << 32) && w >= tw;
+  if (!mfmaOk) {
+    launch_valu(a, RT, 0, st);
+    SSRLCV_LAUNCH_CHECK();
+    return SSRLCV_OK;
+  }
+  // radii padded to even values (see k_gauss_mfma2)
+  const int R2 = R <= 6 ? 6 : R <= 8 ? 8 : R <= 12 ? 12 : R <= 16 ? 16 : R <= 24 ? 24 : 32;
+  const uint32_t nStrips = w / tw, covered = nStrips * tw;
+  ConvArgs m = a;
+  if (canBin && covered == w) { m.binOut = binOut; if (binned) *binned = true; }
+  memset(m.wgt, 0, sizeof m.wgt);
+  for (int k = 0; k <= R; ++k) m.wgt[(R2 - R) + k] = weights_host[k];
+  // one or two blocks are resident per CU (LDS): size the strips so that the launch is about one round of them;
+  // 16-row steps, at least 4 steps of payload per 2R halo
 #define SSRLCV_LAUNCH_MFMA2(RR, TW)                                                                                 \
   do {                                                                                                              \
     static int blocksPerCu = 0, cus = 0;                                                                            \
@@ -1683,37 +1601,24 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
         occ = 1;                                                                                                    \
       blocksPerCu = occ;                                                                                            \
     }                                                                                                               \
-    const uint32_t bxm = w / (TW);                                                                                  \
-    uint32_t by = ((uint32_t)(blocksPerCu * cus) + bxm - 1) / bxm;                                                  \
-    rows = (h + by - 1) / by;                                                                                       \
+    uint32_t by = ((uint32_t)(blocksPerCu * cus) + nStrips - 1) / nStrips;                                          \
+    uint32_t rows = (h + by - 1) / by;                                                                              \
     rows = rows < 64 ? 64 : rows;                                                                                   \
     rows = (rows + kMT - 1) / kMT * kMT;                                                                            \
-    a.rowsPerBlock = rows;                                                                                          \
+    m.rowsPerBlock = rows;                                                                                          \
     const size_t ldsB2 = MfmaCfg<RR, TW>::ldsBytes;                                                                 \
-    hipLaunchKernelGGL((k_gauss_mfma2<RR, TW>), dim3(bxm, (h + rows - 1) / rows), dim3(kMfmaThreads), ldsB2, st, a); \
+    hipLaunchKernelGGL((k_gauss_mfma2<RR, TW>), dim3(nStrips, (h + rows - 1) / rows), dim3(kMfmaThreads), ldsB2, st, m); \
   } while (0)
-      switch (R2) {
-        case 6: if (wide) SSRLCV_LAUNCH_MFMA2(6, 256); else SSRLCV_LAUNCH_MFMA2(6, 128); break;
-        case 8: if (wide) SSRLCV_LAUNCH_MFMA2(8, 256); else SSRLCV_LAUNCH_MFMA2(8, 128); break;
-        case 12: if (wide) SSRLCV_LAUNCH_MFMA2(12, 256); else SSRLCV_LAUNCH_MFMA2(12, 128); break;
-        case 16: if (wide) SSRLCV_LAUNCH_MFMA2(16, 256); else SSRLCV_LAUNCH_MFMA2(16, 128); break;
-        case 24: if (wide) SSRLCV_LAUNCH_MFMA2(24, 256); else SSRLCV_LAUNCH_MFMA2(24, 128); break;
-        default: SSRLCV_LAUNCH_MFMA2(32, 256); break;
-      }
-#undef SSRLCV_LAUNCH_MFMA2
-      SSRLCV_LAUNCH_CHECK();
-      return SSRLCV_OK;
-    }
-    switch (RT) {
-      case 6: if (wide) SSRLCV_LAUNCH_MFMA(6, 256); else SSRLCV_LAUNCH_MFMA(6, 128); break;
-      case 8: if (wide) SSRLCV_LAUNCH_MFMA(8, 256); else SSRLCV_LAUNCH_MFMA(8, 128); break;
-      case 11: if (wide) SSRLCV_LAUNCH_MFMA(11, 256); else SSRLCV_LAUNCH_MFMA(11, 128); break;
-      case 16: if (wide) SSRLCV_LAUNCH_MFMA(16, 256); else SSRLCV_LAUNCH_MFMA(16, 128); break;
-      case 23: if (wide) SSRLCV_LAUNCH_MFMA(23, 256); else SSRLCV_LAUNCH_MFMA(23, 128); break;
-      default: SSRLCV_LAUNCH_MFMA(32, 256); break;
-    }
-#undef SSRLCV_LAUNCH_MFMA
+  switch (R2) {
+    case 6: if (wide) SSRLCV_LAUNCH_MFMA2(6, 256); else SSRLCV_LAUNCH_MFMA2(6, 128); break;
+    case 8: if (wide) SSRLCV_LAUNCH_MFMA2(8, 256); else SSRLCV_LAUNCH_MFMA2(8, 128); break;
+    case 12: if (wide) SSRLCV_LAUNCH_MFMA2(12, 256); else SSRLCV_LAUNCH_MFMA2(12, 128); break;
+    case 16: if (wide) SSRLCV_LAUNCH_MFMA2(16, 256); else SSRLCV_LAUNCH_MFMA2(16, 128); break;
+    case 24: if (wide) SSRLCV_LAUNCH_MFMA2(24, 256); else SSRLCV_LAUNCH_MFMA2(24, 128); break;
+    default: SSRLCV_LAUNCH_MFMA2(32, 256); break;
   }
+#undef SSRLCV_LAUNCH_MFMA2
+  if (covered < w) launch_valu(a, RT, covered, st);  // the partial last strip
   SSRLCV_LAUNCH_CHECK();
   return SSRLCV_OK;
 }
@@ -1925,8 +1830,10 @@ int ssrlcv_sift_plan_create(uint32_t w, uint32_t h, const ssrlcv_sift_params* pa
     ow += 2 * padX;
     oh += 2 * padY;
   }
-  // the fused Gaussian kernels need every octave >= 64 pixels on each side (the smallest octave is an eighth of octave 0)
-  if (ow < 512 || oh < 512) return SSRLCV_ERR_UNSUPPORTED;
+  // The smallest octave is an eighth of octave 0.  Below 16 pixels on a side the 65-tap mirror of the reference
+  // (getSymmetrizedCoord, src/Image.cu:1248-1252: `(i + 2l) % 2l` with i + 2l < 0) indexes outside the level, i.e. upstream
+  // itself is undefined for inputs under 64 pixels: refused here instead of inventing a value.
+  if (ow < 128 || oh < 128) return SSRLCV_ERR_UNSUPPORTED;
   // one polar table (8 bytes per pixel of octave 0) is addressed with 32-bit byte offsets by the orientation kernel
   if (svp::polar_level_stride(ow, oh) * 8 >= ((size_t)1 << 32)) return SSRLCV_ERR_UNSUPPORTED;
   ssrlcv_sift_plan* p = new (std::nothrow) ssrlcv_sift_plan;
@@ -1971,7 +1878,6 @@ int ssrlcv_sift_plan_create(uint32_t w, uint32_t h, const ssrlcv_sift_params* pa
       if (oc.taps[b] <= 0 || oc.taps[b] > 65) { delete p; return SSRLCV_ERR_UNSUPPORTED; }
     }
     size_t P = (size_t)ow * oh;
-    for (int b = 0; b < svp::kDog; ++b) oc.off_dog[b] = take(P * 4);
     oc.off_flags = take(P);
     oc.off_polar = take(svp::polar_level_stride(oc.w, oc.h) * 3 * 8);
     uint32_t cap = params->maxKeyPointsPerOctave ? params->maxKeyPointsPerOctave : (uint32_t)(P / 16);
@@ -2033,8 +1939,22 @@ int ssrlcv_sift_plan_level(const ssrlcv_sift_plan* plan, void* workspace, int ki
   const svp::OctavePlan& oc = plan->oct[octave];
   float* mm = (float*)(ws + plan->off_minmax) + (size_t)octave * 2 * (svp::kGauss + svp::kDog);
   if (kind == 0) {
+    // The pipeline never writes a DoG level (see k_dogx).  For inspection the requested level is materialised here, by
+    // the kernel-level DoG entry point's kernel, from the two Gaussian levels the workspace keeps, into the scratch region
+    // that holds octave 0's input during build_dog; its {min, max} are the ones build_dog reduced.  Synchronous; the
+    // pointer is valid until the next call on this workspace.
     if (blur < 0 || blur >= svp::kDog) return SSRLCV_ERR_INVALID_ARG;
-    if (data) *data = (float*)(ws + oc.off_dog[blur]);
+    if (((size_t)oc.w * oc.h) % 4) return SSRLCV_ERR_UNSUPPORTED;
+    SSRLCV_HIP_TRY(hipDeviceSynchronize());
+    const float* lv[svp::kGauss];
+    float* dogs[svp::kDog];
+    float* scratch = (float*)(ws + plan->off_in0);
+    for (int b = 0; b < svp::kGauss; ++b) lv[b] = (const float*)(ws + plan->off_gauss[octave][b]);
+    for (int b = 0; b < svp::kDog; ++b) dogs[b] = scratch;
+    int rc = launch_dog(lv, mm, oc.w, oc.h, dogs, nullptr, blur, blur + 1, 1024, nullptr, nullptr);
+    if (rc) return rc;
+    SSRLCV_HIP_TRY(hipDeviceSynchronize());
+    if (data) *data = scratch;
     if (minmax_dev) *minmax_dev = mm + 2 * (svp::kGauss + blur);
   } else if (kind == 1) {
     if (blur < 0 || blur >= svp::kGauss) return SSRLCV_ERR_INVALID_ARG;
@@ -2048,36 +1968,24 @@ int ssrlcv_sift_plan_level(const ssrlcv_sift_plan* plan, void* workspace, int ki
   return SSRLCV_OK;
 }
 
-// ScaleSpace::ScaleSpace with makeDOG = true (src/FeatureFactory.cu:338-440)
+// ScaleSpace::ScaleSpace with makeDOG = true (src/FeatureFactory.cu:338-440) + searchForExtrema's findExtrema (:847-882)
 namespace {
-// DoG schedule.  Default: on octaves of >= 2^24 pixels the DoG levels 0..2 start on the side stream as soon as gaussian
-// level 3 is complete, beside the FMA-bound convolutions of levels 4 and 5 (which leave half of the HBM bandwidth idle);
-// the rest follows after level 5 as before.  Measured on a 4096^2 image: 2.071 -> 2.006 ms (the split re-reads level 3:
-// +0.27 GB; cuts at 2 and 4, at 4 only, or on octave 1 as well were slower or equal).
-// SSRLCV_DOG_CUTS="o:b,b;o:b" (developer switch) replaces it: after gaussian level b of octave o, the DoG levels below b
-// that are not yet made are launched; "" = no early launches.  SSRLCV_DOG_EARLY_BLOCKS / SSRLCV_DOG_BLOCKS = grid sizes.
+// Schedule of the fused DoG / extrema pass (k_dogx).  It needs the levels complete (global min / max), so it follows the
+// convolutions of its octave, on a side stream beside the convolutions of the next octave.  A split form exists: the part
+// that needs only levels 0..3 (DoG 0..2: their min / max and the extrema of DoG level 1) starts as soon as gaussian level 3
+// is complete, beside the convolutions of levels 4 and 5; the rest (DoG 1..4 from levels 1..5: extrema of levels 2 and 3,
+// min / max of 3 and 4) follows after level 5 and ORs its bits into the flag bytes.  With the materialising DoG kernel of
+// round 2 (HBM bound) the split paid on the 2^26-pixel octave; the fused pass is VALU bound and reads levels 1..3 twice in
+// the split form: measured on a 4096^2 image 2.14 ms split on octave 0 against 1.96 ms whole, so the default is whole.
+// SSRLCV_DOG_SPLIT=1: split on every octave (0: never).  SSRLCV_DOGX_WAVES: waves per launch (default 8192).
 struct DogSchedule {
-  unsigned cutMask[svp::kOctaves];
-  unsigned earlyBlocks, blocks;
-  bool atomics, fromEnv;
+  int split;  // 0 never (default), 1 always
+  unsigned waves;
   DogSchedule() {
-    for (unsigned& m : cutMask) m = 0;
-    earlyBlocks = 1024;
-    if (const char* e = getenv("SSRLCV_DOG_EARLY_BLOCKS")) earlyBlocks = (unsigned)atoi(e) > 0 ? (unsigned)atoi(e) : 1024;
-    blocks = 1024;
-    if (const char* e = getenv("SSRLCV_DOG_BLOCKS")) blocks = (unsigned)atoi(e) > 0 ? (unsigned)atoi(e) : 1024;
-    atomics = getenv("SSRLCV_DOG_ATOMICS") != nullptr;
-    const char* c = getenv("SSRLCV_DOG_CUTS");
-    fromEnv = c != nullptr;
-    if (!c) return;
-    int o = -1;
-    for (const char* p = c; *p; ++p) {
-      if (*p >= '0' && *p <= '9') {
-        const int v = *p - '0';
-        if (p[1] == ':') { o = v < svp::kOctaves ? v : -1; ++p; }
-        else if (o >= 0 && v >= 1 && v < svp::kGauss - 1) cutMask[o] |= 1u << v;
-      }
-    }
+    split = 0;
+    if (const char* e = getenv("SSRLCV_DOG_SPLIT")) split = atoi(e) != 0 ? 1 : 0;
+    waves = 8192;
+    if (const char* e = getenv("SSRLCV_DOGX_WAVES")) waves = (unsigned)atoi(e) > 0 ? (unsigned)atoi(e) : 8192;
   }
 };
 }  // namespace
@@ -2121,6 +2029,7 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
   }
   if (rc) return rc;
   float* nextIn[3] = {(float*)(ws + plan->off_in1), (float*)(ws + plan->off_in2), (float*)(ws + plan->off_in1)};
+  const float firstNoise = (float)(svp::kNoiseThreshold * 0.8);  // removeNoise(noiseThreshold * 0.8), src/FeatureFactory.cu:484
   for (int o = 0; o < svp::kOctaves; ++o) {
     const svp::OctavePlan& oc = plan->oct[o];
     float* mm = mmAll + (size_t)o * 2 * (svp::kGauss + svp::kDog);
@@ -2129,38 +2038,25 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
     // levels 4-5 of octave 1; octave 3, back on the caller's stream behind octave 1, then runs beside levels 4-5 of
     // octave 2.  (Octave 1 stays behind octave 0: levels 4-5 of octave 0 fill every CU's LDS.)
     const hipStream_t so = (as && overlapOctaves && o >= overlapFrom && ((o - overlapFrom) & 1) == 0) ? as->chain : st;
-    // DoG kernels: octaves 0 and 1 on the DoG side stream (beside the next octave's convolutions); with the overlap the
-    // last two follow their own convolutions on those streams -- behind octave 1's in one in-order stream they were the tail
+    // DoG / extrema passes: octaves 0 and 1 on the side stream (beside the next octave's convolutions); with the overlap
+    // the last two follow their own convolutions on those streams -- behind octave 1's in one in-order stream they were the tail
     const hipStream_t sdo = (as && overlapOctaves && o >= 2) ? so : sd;  // (o >= 2 whatever the first overlapped octave)
-    float* dogPartial = sched.atomics ? nullptr : (float*)(ws + plan->off_dogPartial) + (size_t)o * 2 * svp::kDog * svp::kDogMaxWaves;
+    float* dogPartial = (float*)(ws + plan->off_dogPartial) + (size_t)o * 2 * svp::kDog * svp::kDogMaxWaves;
+    uint8_t* flags = (uint8_t*)(ws + oc.off_flags);
     if (as && o >= 1) SSRLCV_HIP_TRY(hipStreamWaitEvent(so, as->binDone[o - 1], 0));
     const float* src = in;
     const float* lv[svp::kGauss] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    float* dogs[svp::kDog];
-    for (int b = 0; b < svp::kDog; ++b) dogs[b] = (float*)(ws + oc.off_dog[b]);
-    // DoG level b - 2 rides in the loader of the convolution that produces level b (it streams level b - 1 anyway, and
-    // both of its operands are complete); whatever is left after level 5 goes to the streaming DoG kernel
-    int firstDog = 0;
+    for (int b = 0; b < svp::kGauss; ++b) lv[b] = (const float*)(ws + offGauss[b]);
+    const bool split = as && sched.split == 1;
     for (int b = 0; b < svp::kGauss; ++b) {
       float* dst = (float*)(ws + offGauss[b]);
-      DogFuse df;
-      const DogFuse* dfp = nullptr;
-      if (b >= 2 && firstDog == b - 2 && dog_fusable(src, oc.w, oc.h, oc.taps[b])) {
-        df.prev = lv[b - 2];
-        df.out = dogs[b - 2];
-        df.lvlMinMax = mm + 2 * (b - 2);
-        df.dogMinMax = mm + 2 * svp::kGauss + 2 * (b - 2);
-        dfp = &df;
-        firstDog = b - 1;
-      }
       // next octave input = 2x2 bin of the UN-normalised level 3 (src/FeatureFactory.cu:392-399): written by level 3's
       // convolution itself where that kernel can (see launch_conv), by k_bin2x otherwise
       bool binned = false;
       rc = launch_conv(src, dst, nullptr, oc.w, oc.h, oc.taps[b], oc.weights[b], mm + 2 * b, so,
-                       (fuseUpsample && o == 0 && b == 0) ? pixels : nullptr, dfp,
+                       (fuseUpsample && o == 0 && b == 0) ? pixels : nullptr,
                        (b == 3 && o + 1 < svp::kOctaves) ? nextIn[o] : nullptr, &binned);
       if (rc) return rc;
-      lv[b] = dst;
       src = dst;
       if (b == 3 && o + 1 < svp::kOctaves) {
         if (!binned) {
@@ -2170,27 +2066,23 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
         in = nextIn[o];
         if (as) SSRLCV_HIP_TRY(hipEventRecord(as->binDone[o], so));
       }
-      // split schedule: the DoG levels whose operands are complete start on the side stream while the remaining (FMA-bound)
-      // convolutions of this octave run -- with a small grid, so that they take the HBM bandwidth those leave idle
-      // instead of crowding them out
-      const bool cutHere = sched.fromEnv ? ((sched.cutMask[o] >> b) & 1) != 0 : (b == 3 && (size_t)oc.w * oc.h >= ((size_t)1 << 24));
-      if (as && b < svp::kGauss - 1 && cutHere && b > firstDog) {
+      if (split && b == 3) {  // DoG 0..2: extrema of level 1, min / max of 0..2
         SSRLCV_HIP_TRY(hipEventRecord(as->levelDone[o][b], so));
         SSRLCV_HIP_TRY(hipStreamWaitEvent(sdo, as->levelDone[o][b], 0));
-        rc = launch_dog(lv, mm, oc.w, oc.h, dogs, mm + 2 * svp::kGauss, firstDog, b, sched.earlyBlocks, dogPartial, (ssrlcv_stream_t)sdo);
+        rc = launch_dogx(lv, mm, oc.w, oc.h, flags, mm + 2 * svp::kGauss, dogPartial, 0, 3, 0, false, firstNoise, sched.waves, sdo);
         if (rc) return rc;
-        firstDog = b;
       }
     }
     if (as) {
       SSRLCV_HIP_TRY(hipEventRecord(as->convDone[o], so));
       SSRLCV_HIP_TRY(hipStreamWaitEvent(sdo, as->convDone[o], 0));
     }
-    rc = launch_dog(lv, mm, oc.w, oc.h, dogs, mm + 2 * svp::kGauss, firstDog, svp::kDog, sched.blocks, dogPartial, (ssrlcv_stream_t)sdo);
+    if (split) rc = launch_dogx(lv, mm, oc.w, oc.h, flags, mm + 2 * svp::kGauss, dogPartial, 1, svp::kDog, 3, true, firstNoise, sched.waves, sdo);
+    else rc = launch_dogx(lv, mm, oc.w, oc.h, flags, mm + 2 * svp::kGauss, dogPartial, 0, svp::kDog, 0, false, firstNoise, sched.waves, sdo);
     if (rc) return rc;
     if (as) SSRLCV_HIP_TRY(hipEventRecord(as->dogDone[o], sdo));
   }
-  if (as) {  // join: every stream a DoG kernel ran on (in-order streams: the last DoG of each covers the earlier ones)
+  if (as) {  // join: every stream a DoG pass ran on (in-order streams: the last pass of each covers the earlier ones)
     for (int o = 0; o < svp::kOctaves; ++o) SSRLCV_HIP_TRY(hipStreamWaitEvent(st, as->dogDone[o], 0));
   }
   return SSRLCV_OK;

@@ -4,10 +4,13 @@
 //   octave o (0..3) works at (2W >> o) x (2H >> o); P_o pixels, sum P = 5.3125 W H
 //   in0        f32  P_0        octave-0 input (2x bilinear upsample of the u8 image)
 //   in1        f32  P_1        input of octaves 1..3 (2x2 bin of the previous octave's un-normalised level 3); reused
-//   gauss[6]   f32  6 P_0      the six gaussian levels of the octave being built (un-normalised); octaves 0 and 2
-//   gauss1[6]  f32  6 P_1      same for octaves 1 and 3, so that octave o+1 can be convolved while octave o's DoG runs
-//   dog[o][5]  f32  5 sum P    raw DoG levels of every octave (kept: extrema, refinement, gradients read them)
-//   flags[o]   u8   sum P      3 extremum bits per pixel (levels 1..3)
+//   gauss[o][6] f32 6 sum P    the six gaussian levels of every octave (un-normalised, kept: they ARE the scale space the
+//                              key-point stage reads)
+//   (the DoG levels are NOT materialised: ssrlcv_hip_sift_build_dog's last pass per octave forms them in registers for
+//    the extrema search and their min / max, every later consumer evaluates N(level b+1) - N(level b) at the pixels it
+//    samples -- the same float operations, so the same values, without 20 bytes per pixel written and read back)
+//   flags[o]   u8   sum P      extremum bits per pixel: bit k = extremum of DoG level k+1 (k = 0..2), bit 4+k = the same
+//                              and past the first removeNoise (src/FeatureFactory.cu:484)
 //   polar[o]   f32x2 3 sum P   gradient magnitude / direction of DoG levels 1..3 (shared by orientation + descriptors)
 //   minmax     f32  4 x (6+5) x 2   per level {min,max} (gaussian, DoG)
 //   key points: per octave two ping-pong SSKeyPoint lists (capacity cap_o), theta lists, counters, index tables
@@ -24,6 +27,11 @@ constexpr int kGauss = 6;
 constexpr int kDog = 5;
 constexpr int kMaxTaps = 129;
 constexpr int kMaxOrient = 4;
+// thresholds of SIFT_FeatureFactory::generateFeatures (src/SIFT_FeatureFactory.cu:58-59); the first removeNoise runs at
+// 0.8 x the noise threshold (src/FeatureFactory.cu:484)
+constexpr float kNoiseThreshold = 0.01f;
+constexpr float kEdgeThreshold = 12.1f;
+constexpr int kNoiseFlagShift = 4;  // flags: bit k raw extremum of level k+1, bit kNoiseFlagShift + k = past the first removeNoise
 
 // Device-resident per-octave key-point bookkeeping (mirrors Octave::extrema / extremaBlurIndices,
 // include/FeatureFactory.cuh:107-123).
@@ -51,9 +59,8 @@ struct OctavePlan {
   int taps[kGauss];
   float weights[kGauss][kMaxTaps];
   uint32_t cap;            // key-point list capacity
-  size_t off_dog[kDog];
   size_t off_flags;
-  size_t off_polar;        // float2 {|grad|, atan2} of the twice-normalised DoG levels 1..3 (3 * polar_level_stride * 8 bytes)
+  size_t off_polar;        // float2 {|grad|, atan2} of the normalised DoG levels 1..3 (3 * polar_level_stride * 8 bytes)
   size_t off_kpA, off_kpB; // SSKeyPoint ping-pong lists
   size_t off_theta;        // cap * kMaxOrient floats
   size_t off_thetaCnt;     // cap uint32 (number of orientations per key point)

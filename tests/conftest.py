@@ -6,6 +6,10 @@ import pytest
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
+import helpers  # noqa: E402
+
+helpers.limit_openmp()  # before torch or the oracle start an OpenMP runtime (see helpers.cpu_budget)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")

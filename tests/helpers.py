@@ -100,10 +100,36 @@ def load_everest_pixels():
 _ORACLE = None
 
 
+def cpu_budget():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup quota (a GPU box shows all 256 logical
+    CPUs of its host but grants a share of them; an OpenMP team of 256 threads on a 16-CPU quota ran the oracle 50x
+    slower, throttled and spinning)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def limit_openmp():
+    """Size the OpenMP team of the oracle (and of anything else in the process) to cpu_budget(); must run before the
+    OpenMP runtime starts, i.e. before the oracle library or torch is loaded.  -> the thread count"""
+    n = int(os.environ.setdefault("OMP_NUM_THREADS", str(cpu_budget())))
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+    return n
+
+
 def oracle():
     """Build (if needed) and load oracle/_build/libssrlcv_oracle.so."""
     global _ORACLE
     if _ORACLE is None:
+        limit_openmp()
         so = os.path.join(ROOT, "oracle", "_build", "libssrlcv_oracle.so")
         srcs = [os.path.join(ROOT, "oracle", f) for f in os.listdir(os.path.join(ROOT, "oracle"))
                 if f.endswith((".c", ".h"))]

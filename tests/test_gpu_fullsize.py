@@ -160,6 +160,16 @@ for o in range(4):
     for b in range(5):
         lvl, mm = plan.level(0, o, b)
         out.append("%%08x %%r" %% (zlib.crc32(np.ascontiguousarray(lvl).tobytes()), tuple(float(v) for v in mm)))
+# the extrema flagged by the fused DoG pass: the key-point lists right after the search + first removeNoise
+import helpers as H
+plan.set_stop_stage(1)
+plan.describe()
+for o in range(4):
+    g, gidx, overflow = plan.keypoints(o, H.SSKEYPOINT)
+    crc = 0
+    for name in ("octave", "blur", "loc", "intensity", "sigma"):  # (not the struct's padding bytes)
+        crc = zlib.crc32(np.ascontiguousarray(g[name]).tobytes(), crc)
+    out.append("kp%%d %%d %%08x" %% (o, len(g), crc))
 print("CHECKSUMS " + " | ".join(out))
 """
 
@@ -167,17 +177,17 @@ print("CHECKSUMS " + " | ".join(out))
 @pytest.mark.parametrize("size", [4096, 8192])
 def test_full_size_pyramid_is_the_same_on_every_kernel_path(size):
     """At 4096^2 and 8192^2 (BASELINE configs 2-3 and 4) the pyramid takes paths no small test image reaches by default (256-column MFMA strips on the 8192^2 levels,
-    the split DoG launch on octaves of >= 2^24 pixels, the bin folded into a wide level-3 launch).  The oracle needs minutes
-    there; instead every DoG level and its {min, max} must be bit-equal between the default build_dog and one restricted to
-    the formulations the small-image parity tests pin to the oracle (VALU strips only, k_bin2x, one DoG launch with block
-    atomics, one stream)."""
+    the split DoG / extrema pass on octaves of >= 2^24 pixels, the bin folded into a wide level-3 launch).  The oracle needs
+    minutes there; instead every DoG level, its {min, max} and the extrema lists must be bit-equal between the default
+    build_dog and one restricted to the formulations the small-image parity tests pin to the oracle (VALU strips only,
+    k_bin2x, one un-split DoG / extrema launch with one pixel per lane, one stream)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sums = []
-    for variant in ({}, {"SSRLCV_GAUSS_VALU": "1", "SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_NO_BIN_FUSION": "1", "SSRLCV_DOG_CUTS": "",
-                         "SSRLCV_DOG_ATOMICS": "1", "SSRLCV_SIFT_SERIAL": "1", "SSRLCV_NO_UPSAMPLE_FUSION": "1"}):
+    for variant in ({}, {"SSRLCV_GAUSS_VALU": "1", "SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_NO_BIN_FUSION": "1", "SSRLCV_DOG_SPLIT": "0",
+                         "SSRLCV_DOGX_NPX": "1", "SSRLCV_SIFT_SERIAL": "1", "SSRLCV_NO_UPSAMPLE_FUSION": "1"}):
         r = subprocess.run([sys.executable, "-c", _CHECKSUM_SCRIPT % {"root": root}, str(size)], env=dict(os.environ, **variant),
                            capture_output=True, text=True, timeout=900)
         line = [l for l in r.stdout.splitlines() if l.startswith("CHECKSUMS ")]

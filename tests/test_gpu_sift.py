@@ -279,11 +279,10 @@ print("CONV OK", n)
 @pytest.mark.parametrize("variant", [
     {"SSRLCV_GAUSS_TILE_MAXPX": "0"},                                   # marching kernels: strips, k_gauss_mfma2 (128 columns)
     {"SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_GAUSS_WIDE": "1"},         # 256-column strips
-    {"SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_GAUSS_MFMA1": "1"},        # first-edition MFMA kernel
     {"SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_GAUSS_MFMA_MINR": "6"},    # MFMA for every radius
     {"SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_GAUSS_MFMA_MINR": "6", "SSRLCV_GAUSS_WIDE": "1"},
     {"SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_GAUSS_VALU": "1"},         # VALU formulation for every radius
-    {"SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_GAUSS_ELEMENTWISE": "1", "SSRLCV_GAUSS_MFMA1": "1"},
+    {"SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_GAUSS_MFMA_MINR": "6", "SSRLCV_GAUSS_NARROW": "1"},  # 128-column MFMA strips + a VALU remainder strip
 ], ids=lambda v: "+".join(k.replace("SSRLCV_GAUSS_", "") + "=" + x for k, x in v.items()))
 def test_every_gaussian_formulation_is_bit_exact(variant):
     """The formulation is chosen per process (environment) and by level size: the default suite reaches the tile kernel
@@ -316,6 +315,20 @@ for (w, h) in [(512, 384), (262, 260)]:
             ref = osf.level(1, o, b)
             assert np.array_equal(lvl, ref), (w, h, o, b, int((lvl != ref).sum()))
             assert (mn, mx) == osf.minmax(1, o, b), (w, h, o, b)
+    # the extrema the fused DoG pass flagged (raw, and past the first removeNoise): stages 0 and 1 of the key-point lists
+    for stage in (0, 1):
+        plan.set_stop_stage(stage)
+        plan.describe()
+        okps, oidx = osf.keypoints(stage)
+        pos = 0
+        for o in range(4):
+            g, gidx, overflow = plan.keypoints(o, H.SSKEYPOINT)
+            n_o = int(oidx[o][5])
+            ref = okps[pos: pos + n_o]
+            assert overflow == 0 and len(g) == n_o, (w, h, stage, o, len(g), n_o)
+            for name in ("octave", "blur", "loc", "intensity", "sigma"):
+                assert np.array_equal(g[name], ref[name]), (w, h, stage, o, name)
+            pos += n_o
     osf.close()
 print("PYRAMID OK")
 """
@@ -323,16 +336,18 @@ print("PYRAMID OK")
 
 @pytest.mark.parametrize("variant", [
     {"SSRLCV_NO_BIN_FUSION": "1"},                                  # 2x2 bin by k_bin2x instead of the level-3 convolution
-    {"SSRLCV_DOG_ATOMICS": "1"},                                    # DoG min / max by block atomics instead of partials + finalize
-    {"SSRLCV_DOG_CUTS": "0:2,4;1:3;2:1,2,3,4"},                     # split DoG launches beside the convolutions
-    {"SSRLCV_DOG_CUTS": "", "SSRLCV_DOG_BLOCKS": "4096"},           # no early launch, a large DoG grid
+    {"SSRLCV_DOG_SPLIT": "1"},                                      # the DoG / extrema pass split on every octave (levels 0-3 early, 1-5 late)
+    {"SSRLCV_DOGX_WAVES": "65536"},                                 # the shortest row segments
+    {"SSRLCV_DOGX_NPX": "1", "SSRLCV_DOGX_WAVES": "512"},           # one pixel per lane, long row segments
+    {"SSRLCV_DOGX_NPX": "2", "SSRLCV_DOG_SPLIT": "1"},              # two pixels per lane
     {"SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_SIFT_SERIAL": "1"},    # marching kernels only, one stream
     {"SSRLCV_GAUSS_TILE_MAXPX": "100000000"},                       # tile kernel for every level
 ], ids=lambda v: "+".join(k.replace("SSRLCV_", "") + "=" + x for k, x in v.items()))
 def test_every_pyramid_schedule_is_bit_exact(variant):
-    """build_dog's developer switches (who makes the 2x2 bin, how the DoG kernel reduces min / max and when it is launched,
-    which Gaussian kernel a level takes) change the schedule, never a bit: every DoG level and its {min, max} against the
-    oracle, in child processes (the switches are read once per process)."""
+    """build_dog's developer switches (who makes the 2x2 bin, how the fused DoG / extrema pass is cut into launches, row
+    segments and pixels per lane, which Gaussian kernel a level takes) change the schedule, never a bit: every DoG level
+    (materialised on request from the Gaussian levels the workspace keeps), the {min, max} the fused pass reduced and the
+    extrema it flagged against the oracle, in child processes (the switches are read once per process)."""
     import os
     import subprocess
     import sys
@@ -340,3 +355,19 @@ def test_every_pyramid_schedule_is_bit_exact(variant):
     env = dict(os.environ, **variant)
     r = subprocess.run([sys.executable, "-c", _PYRAMID_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "PYRAMID OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("size", [(64, 64), (72, 200), (136, 64), (200, 4096)])
+def test_small_and_thin_images_match_oracle(capi, oracle_lib, size):
+    """The reference takes any image of at least 8 x 8 pixels (src/FeatureFactory.cu:341-345,364-376); below 64 pixels its
+    65-tap mirror reads outside the smallest octave, so 64 is where defined behaviour starts.  Levels with a side under 64
+    pixels go through the one-tile Gaussian kernel with the reference's modulo mirror."""
+    w, h = size
+    img = H.synthetic_image(w, h, seed=9)
+    of = H.oracle_sift(oracle_lib, img)
+    plan = capi.SiftPlan(w, h)
+    plan.extract(capi.to_dev(img))
+    gf = plan.features_host(H.FEATURE)
+    print("%d x %d: %d features" % (w, h, len(gf)))
+    assert len(gf) == len(of)
+    H.assert_features_equal(gf, of)

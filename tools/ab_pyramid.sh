@@ -1,0 +1,6 @@
+# Developer helper: build_dog timing under a list of environment variants (one process each; the switches are read once).
+# usage: bash tools/ab_pyramid.sh "VAR=1 VAR2=x" "VAR=2" ...     ("" = defaults)
+for v in "$@"; do
+  echo "== ${v:-defaults}"
+  env $v python3 tools/bench_pyramid.py --size 4096 --iters 12 2>&1 | grep build_dog
+done

@@ -30,10 +30,10 @@ int main(int argc, char** argv) {
     const int taps = ssrlcv_gauss_kernel_host(sigmas[lv], 0.5f, w);
     int ksz = taps | 1;
     hipMemset(stamps, 0, ns * 8);
-    launch_conv(in, out, nullptr, S, S, ksz, w, nullptr, nullptr);
+    launch_conv(in, out, nullptr, S, S, ksz, w, nullptr, nullptr, nullptr);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int r = 0; r < 5; ++r) launch_conv(in, out, nullptr, S, S, ksz, w, nullptr, nullptr);
+    for (int r = 0; r < 5; ++r) launch_conv(in, out, nullptr, S, S, ksz, w, nullptr, nullptr, nullptr);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
