@@ -298,10 +298,24 @@ __global__ __launch_bounds__(256) void k_refine(const OctaveState* st, ssrlcv_ss
 // calculatePixelGradients (src/Image.cu:1583-1598: a border pixel takes the stencil of its inner neighbour) is a choice
 // of indices, not per-pixel address arithmetic.
 constexpr int kPolRows = 16;
-__global__ __launch_bounds__(256) void k_polar(LevelSet L, float2* __restrict__ out) {
+struct PolarJobs {  // the four octaves' tables in one launch: octave o owns the blocks start[o] .. start[o + 1] - 1
+  LevelSet L[svp::kOctaves];
+  float2* out[svp::kOctaves];
+  uint32_t start[svp::kOctaves + 1];
+  uint32_t tilesX[svp::kOctaves];
+};
+__global__ __launch_bounds__(256) void k_polar(PolarJobs jobs) {
   __shared__ float s_n[kPolRows][256 + 2];  // column c of the tile at [.][c + 1]; [.][0] / [.][257] = columns x0 - 1 / x0 + 256
+  int o = 0;
+#pragma unroll
+  for (int k = 1; k < svp::kOctaves; ++k)
+    if (blockIdx.x >= jobs.start[k]) o = k;  // block-uniform
+  const LevelSet& L = jobs.L[o];
+  float2* __restrict__ out = jobs.out[o];
+  const uint32_t tile = blockIdx.x - jobs.start[o];
+  const int tileX = (int)(tile % jobs.tilesX[o]), tileY = (int)(tile / jobs.tilesX[o]);
   const int W = L.w, H = L.h;
-  const int x0 = blockIdx.x * 256, y0 = blockIdx.y * kPolRows;
+  const int x0 = tileX * 256, y0 = tileY * kPolRows;
   const int t = threadIdx.x, x = x0 + t;
   // own column, rows y0 - 1 .. y0 + 16; rows / columns clamped into the image are loaded but never used (see below)
   const int xc = x < W ? x : W - 1;
@@ -357,7 +371,7 @@ __global__ __launch_bounds__(256) void k_polar(LevelSet L, float2* __restrict__ 
     }
     __syncthreads();
     float2* __restrict__ lvlOut = out + (size_t)(lvl - 1) * svp::polar_level_stride(W, H);
-    if (blockIdx.x == 0 && blockIdx.y == 0) {  // the zero entries around the table (see svp::polar_level_stride)
+    if (tile == 0) {  // the zero entries around the table (see svp::polar_level_stride)
       if (t == 0) lvlOut[0] = make_float2(0.0f, 0.0f);
       for (int i = t; i < W + 1; i += 256) lvlOut[1 + (size_t)W * H + i] = make_float2(0.0f, 0.0f);
     }
@@ -997,6 +1011,22 @@ LevelSet make_levels(const ssrlcv_sift_plan* plan, char* ws, int o) {
   return L;
 }
 
+// the polar tables of all four octaves in one launch (the three small ones were each a launch of a few waves per CU)
+void launch_polar(const ssrlcv_sift_plan* plan, char* ws, hipStream_t st) {
+  PolarJobs jobs;
+  uint32_t pos = 0;
+  for (int o = 0; o < svp::kOctaves; ++o) {
+    const svp::OctavePlan& oc = plan->oct[o];
+    jobs.L[o] = make_levels(plan, ws, o);
+    jobs.out[o] = (float2*)(ws + oc.off_polar);
+    jobs.start[o] = pos;
+    jobs.tilesX[o] = (oc.w + 255) / 256;
+    pos += jobs.tilesX[o] * ((oc.h + kPolRows - 1) / kPolRows);
+  }
+  jobs.start[svp::kOctaves] = pos;
+  hipLaunchKernelGGL(k_polar, dim3(pos), dim3(256), 0, st, jobs);
+}
+
 // discardExtrema: stable per-segment compaction from `src` into `dst`
 hipError_t run_discard(OctaveState* st, const ssrlcv_sskeypoint* src, ssrlcv_sskeypoint* dst, uint32_t cap,
                        uint32_t* words, hipStream_t stream) {
@@ -1072,14 +1102,7 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
     SSRLCV_HIP_TRY(hipEventRecord(as->fork, caller));
     SSRLCV_HIP_TRY(hipStreamWaitEvent(as->chain, as->fork, 0));
     SSRLCV_HIP_TRY(hipStreamWaitEvent(as->table, as->fork, 0));
-    if (stop >= 6) {
-      for (int o = 0; o < svp::kOctaves; ++o) {
-        const svp::OctavePlan& oc = plan->oct[o];
-        hipLaunchKernelGGL(k_polar, dim3((oc.w + 255) / 256, (oc.h + kPolRows - 1) / kPolRows), dim3(256), 0, as->table,
-                           make_levels(plan, ws, o), (float2*)(ws + oc.off_polar));
-        SSRLCV_HIP_TRY(hipEventRecord(as->polarDone[o], as->table));
-      }
-    }
+    if (stop >= 6) launch_polar(plan, ws, as->table);
   }
   ssrlcv_sskeypoint* curBuf[svp::kOctaves];
   ssrlcv_sskeypoint* othBuf[svp::kOctaves];
@@ -1203,13 +1226,7 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
   RangeTable* thetaRanges = (RangeTable*)(ws + plan->oct[1].off_featBase);
   RangeTable* descRanges = (RangeTable*)(ws + plan->oct[2].off_featBase);
   if (stop >= 6) {  // computeKeyPointOrientations (src/FeatureFactory.cu:540-632), all octaves in one launch
-    if (!as) {
-      for (int o = 0; o < svp::kOctaves; ++o) {
-        const svp::OctavePlan& oc = plan->oct[o];
-        hipLaunchKernelGGL(k_polar, dim3((oc.w + 255) / 256, (oc.h + kPolRows - 1) / kPolRows), dim3(256), 0, caller,
-                           set.L[o], (float2*)(ws + oc.off_polar));
-      }
-    }
+    if (!as) launch_polar(plan, ws, caller);
     hipLaunchKernelGGL(k_build_ranges, dim3(1), dim3(1), 0, caller, states, thetaRanges, 6);
     const float lambdaO = plan->params.orientationContribWidth, othr = plan->params.orientationThreshold;
     switch (maxO) {
