@@ -197,6 +197,23 @@ def compact_matches(out_kind, matches_d, n, workspace):
     return cnt.value
 
 
+def compact_matches_async(out_kind, matches_d, n, workspace, count_d):
+    """Compaction without the host round trip: count_d (1-element int32 CUDA tensor / slice) receives the survivors."""
+    check(LIB.ssrlcv_hip_compact_matches_async(c_int(out_kind), ptr(matches_d), c_u32(n), ptr(count_d), ptr(workspace),
+                                               c_sz(workspace.numel()), stream_ptr()))
+
+
+def keypoints_from_members(members_d, n, feature_tensors):
+    """KeyPoint{image, location} of every {image, feature} member, gathered on the device -> uint8 tensor (16 B each)."""
+    V = len(feature_tensors)
+    assert all(t is None or t.is_cuda for t in feature_tensors), "feature arrays must live on the device"
+    ptrs = (c_vp * V)(*[t.data_ptr() if t is not None and t.numel() else 0 for t in feature_tensors])
+    counts = (c_u32 * V)(*[(t.numel() // 152) if t is not None else 0 for t in feature_tensors])
+    out = dev_bytes(16 * n)
+    check(LIB.ssrlcv_hip_keypoints_from_members(ptr(members_d), c_u32(n), ptrs, counts, c_u32(V), ptr(out), stream_ptr()))
+    return out
+
+
 def matchset_from_matches(in_kind, matches_d, n, want_max=False):
     """Device M7: (KeyPoint[2n] bytes, MultiMatch[n] bytes, max distance or None) from a validated DMatch / Match array."""
     kp = dev_bytes(32 * n)

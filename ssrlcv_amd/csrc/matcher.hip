@@ -638,6 +638,32 @@ int run_match(const ssrlcv_sift_feature* query, uint32_t nq, const ssrlcv_sift_f
 }  // namespace
 
 namespace {
+// compact_matches_async: survivors from the partition's scratch back to the front of the list, count read on the device
+__global__ __launch_bounds__(256) void k_copy_counted(uint4* __restrict__ dst, const uint4* __restrict__ src, uint32_t words16PerElem,
+                                                      const uint32_t* __restrict__ total, uint32_t* __restrict__ count_out) {
+  const size_t n = (size_t)total[0] * words16PerElem;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = total[0];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+// generateMatchesExhaustive's KeyPoint table (src/MatchFactory.cu:1007-1020): one thread per member
+constexpr int kMaxGatherImages = 64;
+struct GatherArgs {
+  const ssrlcv_sift_feature* feats[kMaxGatherImages];
+  uint32_t count[kMaxGatherImages];
+};
+__global__ __launch_bounds__(256) void k_keypoints_from_members(const ssrlcv_uint2* __restrict__ mem, uint32_t n, GatherArgs a,
+                                                                uint32_t numImages, ssrlcv_keypoint* __restrict__ out) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const ssrlcv_uint2 m = mem[i];
+  ssrlcv_keypoint kp;
+  kp.parentId = (int)m.x;
+  kp.loc.x = kp.loc.y = 0.0f;
+  if (m.x < numImages && m.y < a.count[m.x]) kp.loc = a.feats[m.x][m.y].loc;
+  out[i] = kp;
+}
+
 // M7: the 2-view MatchSet (src/Pipeline.cu:204-223).  One thread per match; ELEM = ssrlcv_match or ssrlcv_dmatch (the
 // end points sit at the same offsets).  Distances are >= 0, so the integer order of their bit patterns is the float order.
 template <typename ELEM>
@@ -750,6 +776,66 @@ int ssrlcv_hip_compact_matches(int outKind, void* matches, uint32_t numMatches, 
   *count_host = host_tot[0];
   if (host_tot[0]) SSRLCV_HIP_TRY(hipMemcpyAsync(matches, tmp, (size_t)host_tot[0] * elem, hipMemcpyDeviceToDevice, st));
   SSRLCV_HIP_TRY(hipStreamSynchronize(st));
+  return SSRLCV_OK;
+}
+
+int ssrlcv_hip_compact_matches_async(int outKind, void* matches, uint32_t numMatches, uint32_t* count_dev, void* workspace,
+                                     size_t workspaceBytes, ssrlcv_stream_t stream) {
+  if (!matches || !count_dev || !workspace || outKind < 0 || outKind > 2) return SSRLCV_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (numMatches == 0) {
+    SSRLCV_HIP_TRY(hipMemsetAsync(count_dev, 0, sizeof(uint32_t), st));
+    return SSRLCV_OK;
+  }
+  const size_t elem = outKind == SSRLCV_OUT_DMATCH ? sizeof(ssrlcv_dmatch)
+                      : outKind == SSRLCV_OUT_MATCH ? sizeof(ssrlcv_match) : sizeof(ssrlcv_uint2_pair);
+  static_assert(sizeof(ssrlcv_dmatch) % 16 == 0 && sizeof(ssrlcv_uint2_pair) % 16 == 0 && sizeof(ssrlcv_match) % 8 == 0, "copy granularity");
+  if (elem % 16 != 0 || (reinterpret_cast<size_t>(matches) & 15) != 0) return SSRLCV_ERR_UNSUPPORTED;  // Match (40 B): use the synchronous call
+  const size_t need = (size_t)numMatches * elem + 256 + svc::workspace_words<1, 8>(numMatches) * 4;
+  if (workspaceBytes < need) return SSRLCV_ERR_WORKSPACE;
+  char* tmp = (char*)workspace;
+  uint32_t* words = (uint32_t*)(tmp + ((size_t)numMatches * elem + 255) / 256 * 256);
+  uint32_t* totals = nullptr;
+  hipError_t e;
+  if (outKind == SSRLCV_OUT_UINT2_PAIR) {
+    const ssrlcv_uint2_pair* in = (const ssrlcv_uint2_pair*)matches;
+    ssrlcv_uint2_pair* o = (ssrlcv_uint2_pair*)tmp;
+    auto keyfn = [=] __device__(uint32_t i) -> uint32_t {  // validate (include/MatchFactory.cuh:83-85)
+      ssrlcv_uint2_pair m = in[i];
+      return (m.a.x == m.b.x && m.a.y == m.b.y) ? 0u : 1u;
+    };
+    auto emit = [=] __device__(uint32_t i, int, uint32_t d) { o[d] = in[i]; };
+    e = svc::partition<1, 8>(numMatches, keyfn, emit, words, &totals, st);
+  } else {
+    const ssrlcv_dmatch* in = (const ssrlcv_dmatch*)matches;
+    ssrlcv_dmatch* o = (ssrlcv_dmatch*)tmp;
+    auto keyfn = [=] __device__(uint32_t i) -> uint32_t { return in[i].invalid ? 0u : 1u; };
+    auto emit = [=] __device__(uint32_t i, int, uint32_t d) { o[d] = in[i]; };
+    e = svc::partition<1, 8>(numMatches, keyfn, emit, words, &totals, st);
+  }
+  if (e != hipSuccess) return (int)e;
+  unsigned blocks = (unsigned)(((size_t)numMatches * (elem / 16) + 255) / 256);
+  blocks = blocks > 2048u ? 2048u : blocks;
+  hipLaunchKernelGGL(k_copy_counted, dim3(blocks), dim3(256), 0, st, (uint4*)matches, (const uint4*)tmp, (uint32_t)(elem / 16), totals,
+                     count_dev);
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
+}
+
+int ssrlcv_hip_keypoints_from_members(const ssrlcv_uint2* members, uint32_t numMembers,
+                                      const ssrlcv_sift_feature* const* features_host, const uint32_t* numFeatures_host,
+                                      uint32_t numImages, ssrlcv_keypoint* keyPoints, ssrlcv_stream_t stream) {
+  if (!features_host || !numFeatures_host || numImages == 0 || numImages > (uint32_t)kMaxGatherImages) return SSRLCV_ERR_INVALID_ARG;
+  if (numMembers && (!members || !keyPoints)) return SSRLCV_ERR_INVALID_ARG;
+  if (numMembers == 0) return SSRLCV_OK;
+  GatherArgs a;
+  for (uint32_t v = 0; v < (uint32_t)kMaxGatherImages; ++v) {
+    a.feats[v] = v < numImages ? features_host[v] : nullptr;
+    a.count[v] = v < numImages && features_host[v] ? numFeatures_host[v] : 0u;
+  }
+  hipLaunchKernelGGL(k_keypoints_from_members, dim3((numMembers + 255) / 256), dim3(256), 0, (hipStream_t)stream, members,
+                     numMembers, a, numImages, keyPoints);
+  SSRLCV_LAUNCH_CHECK();
   return SSRLCV_OK;
 }
 

@@ -31,8 +31,25 @@ def pair_list(num_images):
 
 
 def pair_owner(pair_index, world):
-    """Stage B: pair p (index in pair_list order) -> rank p mod G."""
+    """Stage B without size information: pair p (index in pair_list order) -> rank p mod G."""
     return pair_index % world
+
+
+def assign_pairs(num_features, world):
+    """Stage B, balanced: the cost of pair (i, j) is nq * nt distance evaluations, known on every rank once the feature
+    arrays are exchanged.  Longest-processing-time-first: pairs by descending cost (ties by pair index) each go to the
+    least loaded rank (ties to the lowest rank) -- deterministic, so every rank derives the same table.  With six pairs
+    on four ranks round-robin gives two ranks two pairs each whatever their sizes.  -> owner rank per pair index."""
+    pairs = pair_list(len(num_features))
+    cost = [int(num_features[i]) * int(num_features[j]) for i, j in pairs]
+    order = sorted(range(len(pairs)), key=lambda p: (-cost[p], p))
+    load = [0] * world
+    owner = [0] * len(pairs)
+    for p in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        owner[p] = r
+        load[r] += cost[p]
+    return owner
 
 
 def bundle_range(num_bundles, world, rank):
@@ -96,7 +113,9 @@ def exchange_keyed(local_items, num_keys, owner_fn, group=None):
         dev = local_items[k].device
         break
     if dev is None:
-        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        # a rank that owns no key still returns everybody's items where the others keep theirs: on its GPU when it has one
+        # (also under gloo, which only stages through the host), on the CPU in the device-less tests
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     home = dev
     dev = _comm_device(home, group)
     # sizes of every key in one all-reduce (each rank fills in the keys it owns): one collective + one D2H copy
@@ -131,7 +150,9 @@ def merge_matches(num_features, pair_tensors):
     from . import _lib
     lib = _lib.load()
     counts = np.array([t.numel() // 16 for t in pair_tensors], np.uint32)
-    allp = np.concatenate([t.cpu().numpy().reshape(-1) for t in pair_tensors]) if len(pair_tensors) else np.zeros(0, np.uint8)
+    live = [t.reshape(-1) for t in pair_tensors if t.numel()]
+    # one device-side concatenation and one D2H copy (not one small copy per pair)
+    allp = torch.cat(live).cpu().numpy() if live else np.zeros(0, np.uint8)
     allp = np.ascontiguousarray(allp)
     nf = np.array(num_features, np.uint32)
     mm_p, mem_p = ctypes.c_void_p(), ctypes.c_void_p()

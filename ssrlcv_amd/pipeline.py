@@ -4,8 +4,10 @@ Mirrors src/Pipeline.cu doFeatureGeneration -> doFeatureMatching -> doTriangulat
 sweep of doBundleAdjust) with the sharding of ssrlcv_amd/dist.py:
 
   stage A   SIFT per image on its owner rank                         exchange 1: all-gather of the feature arrays
-  stage B   pair matching on the pair's owner rank                   exchange 2: all-gather of the uint2_pair arrays
-  merge     generateMatchesExhaustive's host merge, replicated (deterministic)
+  stage B   pair matching on the pair's owner rank (pairs balanced   exchange 2: all-gather of the uint2_pair arrays
+            by nq * nt, all queued, one synchronisation)
+  merge     generateMatchesExhaustive's host merge, replicated (deterministic, on all host cores); KeyPoint table
+            gathered on the device
   stage C   bundle-range triangulation                                exchange 3: all-gather of the cloud
   BA sweep  the K finite-difference evaluations of f(cameras) over this rank's bundle range of the first image pair
             (calculateImageGradient / Hessian, src/PointCloudFactory.cu:1059-1504)   all-reduce(sum) of the K sums
@@ -40,6 +42,7 @@ class Workspace:
 
     def __init__(self):
         self.plans = {}
+        self._plan_bytes = {}
         self.match_ws = None
         self.match_out = None
         self.seed = None
@@ -51,6 +54,14 @@ class Workspace:
         if key not in self.plans:
             self.plans[key] = capi.SiftPlan(w, h)
         return self.plans[key]
+
+    def plan_bytes(self, w, h):
+        """Workspace + feature buffer a plan of this size holds (from a layout-only plan: no device memory)."""
+        key = (w, h)
+        if key not in self._plan_bytes:
+            probe = capi.SiftPlan(w, h, alloc=False)
+            self._plan_bytes[key] = probe.workspace_bytes + probe.max_features * FEATURE_BYTES
+        return self._plan_bytes[key]
 
     def matcher(self, shapes, out_bytes):
         need = max(capi.LIB.ssrlcv_hip_match_workspace_bytes(capi.c_u32(nq), capi.c_u32(nt)) for nq, nt in shapes)
@@ -72,18 +83,35 @@ class Workspace:
         self.times[name] = self.times.get(name, 0.0) + (time.perf_counter() - t0)
 
 
-def extract_features(pixel_tensors, ws=None):
+def extract_features(pixel_tensors, ws=None, plan_budget_bytes=None):
     """SIFT on the images this rank owns.  pixel_tensors: {image index: u8 CUDA tensor (H, W)} -> {index: feature bytes}.
-    The extracts are queued back to back (one plan per owned image) and synchronised once."""
+    While the plans' workspaces fit the budget (default: 40 % of the device's memory) every owned image gets its own plan
+    and the extracts are queued back to back and synchronised once; past it (eight 8192^2 views on one GPU need 8 x 22 GB)
+    one plan per image size is reused: extract, copy the features out, next image."""
     ws = ws or Workspace()
-    plans = {}
-    for k, (v, pix) in enumerate(pixel_tensors.items()):
+    if plan_budget_bytes is None:
+        plan_budget_bytes = int(0.4 * torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory)
+    items = list(pixel_tensors.items())
+    need = 0
+    for k, (v, pix) in enumerate(items):
         h, w = pix.shape
-        plans[v] = ws.plan(w, h, k)
-        plans[v].extract(pix)
+        need += ws.plan_bytes(w, h)
     out = {}
-    for v, plan in plans.items():
-        n = plan.count()   # synchronises; raises if a key-point list overflowed
+    if need <= plan_budget_bytes:
+        plans = {}
+        for k, (v, pix) in enumerate(items):
+            h, w = pix.shape
+            plans[v] = ws.plan(w, h, k)
+            plans[v].extract(pix)
+        for v, plan in plans.items():
+            n = plan.count()   # synchronises; raises if a key-point list overflowed
+            out[v] = plan.features[: n * FEATURE_BYTES].clone()
+        return out
+    for v, pix in items:
+        h, w = pix.shape
+        plan = ws.plan(w, h, 0)
+        plan.extract(pix)
+        n = plan.count()
         out[v] = plan.features[: n * FEATURE_BYTES].clone()
     return out
 
@@ -96,23 +124,33 @@ def exchange_features(local, num_images):
 
 
 def match_pairs(features, cameras, seed_features=None, epsilon=25.0, delta=5.0, rel=0.6, absolute=200.0 * 200.0, mode=1,
-                ws=None):
+                ws=None, owners=None):
     """Exhaustive matching (generateMatchesExhaustive; GEO_ORBIT double-constrained for mode 1, brute force for mode 0)
-    of the pairs this rank owns.  features: list of uint8 CUDA tensors (all images).  Returns {pair index: validated
-    uint2_pair bytes}."""
+    of the pairs this rank owns (`owners`: rank per pair index, default dist.assign_pairs).  features: list of uint8 CUDA
+    tensors (all images).  Every pair is queued -- match, validation / compaction with the count left on the device --
+    and the stream is synchronised once for all the counts.  Returns {pair index: validated uint2_pair bytes}."""
     ws = ws or Workspace()
     world, rank = _world()
     num_images = len(features)
     pairs = sd.pair_list(num_images)
+    if owners is None:
+        owners = sd.assign_pairs([f.numel() // FEATURE_BYTES for f in features], world)
     seed_d = ws.seed_features(seed_features)
-    out = {}
+    mine = [p for p in range(len(pairs)) if owners[p] == rank]
+    counts = torch.zeros(max(len(mine), 1), dtype=torch.int32, device="cuda")
+    bufs = {}
     seed_cache = {}
-    for p, (qi, ti) in enumerate(pairs):
-        if sd.pair_owner(p, world) != rank:
-            continue
+    shapes = []
+    for p in mine:
+        qi, ti = pairs[p]
         nq, nt = features[qi].numel() // FEATURE_BYTES, features[ti].numel() // FEATURE_BYTES
-        shapes = [(nq, nt)] + ([(nq, len(seed_features))] if seed_features is not None else [])
-        mws, mout = ws.matcher(shapes, nq * 16)
+        shapes.append((nq, nt))
+        if seed_features is not None:
+            shapes.append((nq, len(seed_features)))
+    mws = ws.matcher(shapes, 16)[0] if shapes else None
+    for k, p in enumerate(mine):
+        qi, ti = pairs[p]
+        nq, nt = features[qi].numel() // FEATURE_BYTES, features[ti].numel() // FEATURE_BYTES
         sdist = None
         if seed_d is not None:
             if qi not in seed_cache:  # recomputed per query image upstream (src/MatchFactory.cu:925)
@@ -121,54 +159,54 @@ def match_pairs(features, cameras, seed_features=None, epsilon=25.0, delta=5.0, 
         proj = capi.projection_matrix(cameras[ti:ti + 1]) if mode == 1 else None
         params = capi.make_match_params(mode, qi, ti, epsilon, delta, rel, absolute,
                                         cameras[qi:qi + 1] if mode == 1 else None, proj)
-        res = capi.match(features[qi], nq, features[ti], nt, params, capi.OUT_UINT2_PAIR, seed_d=sdist, workspace=mws,
-                         out=mout)
-        n = capi.compact_matches(capi.OUT_UINT2_PAIR, res, nq, mws)
-        out[p] = res[: n * 16].clone()
-    return out
+        bufs[p] = capi.dev_bytes(nq * 16)
+        capi.match(features[qi], nq, features[ti], nt, params, capi.OUT_UINT2_PAIR, seed_d=sdist, workspace=mws, out=bufs[p])
+        capi.compact_matches_async(capi.OUT_UINT2_PAIR, bufs[p], nq, mws, counts[k:k + 1])
+    n = counts.cpu().tolist()  # the one synchronisation
+    return {p: bufs[p][: n[k] * 16] for k, p in enumerate(mine)}
 
 
-def exchange_pairs(local, num_pairs):
+def exchange_pairs(local, num_pairs, owners=None):
     world, _ = _world()
     if world == 1:
         return [local[p] for p in range(num_pairs)]
-    return sd.exchange_keyed(local, num_pairs, sd.pair_owner)
+    owner_fn = sd.pair_owner if owners is None else (lambda p, _world_size: owners[p])
+    return sd.exchange_keyed(local, num_pairs, owner_fn)
 
 
-def build_match_set(features, pair_tensors):
-    """Replicated host merge -> (MultiMatch numpy, KeyPoint numpy)."""
+def build_match_set(features, pair_tensors, dev=None):
+    """Replicated host merge -> (MultiMatch numpy, KeyPoint numpy).  The KeyPoint table (image, location of every member,
+    src/MatchFactory.cu:1007-1020) is gathered on the device; `dev` (a dict) receives the device copies so that the
+    triangulation does not upload them again."""
     num_features = [f.numel() // FEATURE_BYTES for f in features]
     mm, mem = sd.merge_matches(num_features, pair_tensors)
     kp = np.zeros(len(mem), KEYPOINT)
-    kp["parentId"] = mem[:, 0]
     if len(mem):
-        # key-point locations (byte 8 of each 152-byte feature) gathered on the device: one small D2H copy instead of
-        # every image's full location table
-        mem_d = torch.from_numpy(mem.astype(np.int64)).to(features[0].device)
-        loc = torch.empty(len(mem), 2, dtype=torch.float32, device=features[0].device)
-        for v, f in enumerate(features):
-            sel = (mem_d[:, 0] == v).nonzero().squeeze(1)
-            if sel.numel():
-                table = f.view(-1, FEATURE_BYTES)[:, 8:16].contiguous().view(torch.float32).view(-1, 2)
-                loc[sel] = table[mem_d[sel, 1]]
-        kp["loc"] = loc.cpu().numpy()
+        mem_d = capi.to_dev(np.ascontiguousarray(mem, np.uint32))
+        kp_d = capi.keypoints_from_members(mem_d, len(mem), features)
+        kp = capi.to_host(kp_d, KEYPOINT, len(mem))
+        kp["pad"] = 0
+        if dev is not None:
+            dev["keypoints"] = kp_d
     return mm, kp
 
 
-def triangulate(mm, kp, cameras, nview, pushbroom=None):
+def triangulate(mm, kp, cameras, nview, pushbroom=None, dev=None):
     """Bundle-range partitioned triangulation; every rank ends with the full cloud.  `pushbroom`: PushbroomCamera array
-    (config[4]): bundles then come from generatePushbroomBundle (src/PointCloudFactory.cu:875-903)."""
+    (config[4]): bundles then come from generatePushbroomBundle (src/PointCloudFactory.cu:875-903).  `dev`: device copies
+    left by build_match_set."""
     world, rank = _world()
     lo, hi = sd.bundle_range(len(mm), world, rank)
     sub = mm[lo:hi].copy()
     n = len(sub)
     pts = torch.zeros(0, dtype=torch.float32, device="cuda")
     if n:
+        kp_d = dev["keypoints"] if dev and "keypoints" in dev else capi.to_dev(kp)
         if pushbroom is not None:
-            b_d, l_d = capi.generate_pushbroom_bundles(capi.to_dev(sub), capi.to_dev(kp), n, capi.to_dev(pushbroom),
+            b_d, l_d = capi.generate_pushbroom_bundles(capi.to_dev(sub), kp_d, n, capi.to_dev(pushbroom),
                                                        len(pushbroom), len(kp))
         else:
-            b_d, l_d = capi.generate_bundles(capi.to_dev(sub), capi.to_dev(kp), n, capi.to_dev(cameras), len(cameras), len(kp))
+            b_d, l_d = capi.generate_bundles(capi.to_dev(sub), kp_d, n, capi.to_dev(cameras), len(cameras), len(kp))
         pts, _, _ = capi.triangulate(l_d, b_d, n, nview=nview)
     if world == 1:
         return pts.view(-1, 3)
@@ -254,17 +292,18 @@ def reconstruct(pixel_tensors_all, cameras, seed_features=None, epsilon=25.0, de
     feats = exchange_features(local, num_images)
     ws.tick("exchange_features", t)
     t = time.perf_counter()
-    pair_local = match_pairs(feats, cameras, seed_features, epsilon, delta, mode=mode, ws=ws)
-    torch.cuda.synchronize()
+    owners = sd.assign_pairs([f.numel() // FEATURE_BYTES for f in feats], world)
+    pair_local = match_pairs(feats, cameras, seed_features, epsilon, delta, mode=mode, ws=ws, owners=owners)
     ws.tick("match", t)
     t = time.perf_counter()
-    pair_all = exchange_pairs(pair_local, len(sd.pair_list(num_images)))
+    pair_all = exchange_pairs(pair_local, len(sd.pair_list(num_images)), owners)
     ws.tick("exchange_pairs", t)
     t = time.perf_counter()
-    mm, kp = build_match_set(feats, pair_all)
+    dev = {}
+    mm, kp = build_match_set(feats, pair_all, dev)
     ws.tick("merge", t)
     t = time.perf_counter()
-    cloud = triangulate(mm, kp, cameras, nview=num_images > 2, pushbroom=pushbroom)
+    cloud = triangulate(mm, kp, cameras, nview=num_images > 2, pushbroom=pushbroom, dev=dev)
     torch.cuda.synchronize()
     ws.tick("triangulate", t)
     out = {"features": feats, "pairs": pair_all, "matches": mm, "keypoints": kp, "points": cloud}

@@ -118,3 +118,20 @@ def test_merge_reproduces_reference_3view_fixture(oracle_lib, everest_oracle_fea
     assert len(mm) == 21177
     assert np.array_equal(mm["numKeyPoints"], v["mm0"]["numKeyPoints"]) and np.array_equal(mm["index"], v["mm0"]["index"])
     assert np.array_equal(mem[:, 0].astype(np.int32), v["kp0"]["parentId"])
+
+
+def test_pair_assignment_is_balanced_and_deterministic():
+    """Stage B's longest-processing-time-first table (dist.assign_pairs): every rank derives the same owners from the
+    feature counts, each pair has exactly one owner, and the heaviest rank carries no more than the lightest plus the
+    largest single pair (round-robin on six pairs over four ranks gives two ranks two pairs each whatever their sizes)."""
+    from ssrlcv_amd import dist as sd
+    nf = [300000, 120000, 410000, 90000]
+    for world in (1, 2, 3, 4, 8):
+        owners = sd.assign_pairs(nf, world)
+        assert owners == sd.assign_pairs(list(nf), world) and len(owners) == 6 and all(0 <= r < world for r in owners)
+        pairs = sd.pair_list(len(nf))
+        cost = [nf[i] * nf[j] for i, j in pairs]
+        load = [sum(c for c, r in zip(cost, owners) if r == k) for k in range(world)]
+        assert max(load) - min(load) <= max(cost)
+    # equal sizes on four ranks: the two ranks that take a second pair are decided by the tie rule, not by chance
+    assert sd.assign_pairs([1000] * 4, 4) == [0, 1, 2, 3, 0, 1]

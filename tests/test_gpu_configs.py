@@ -2,10 +2,11 @@
 
   config[3]  4-view 4096 x 4096: N-view flow (ssrlcv_amd.pipeline at world size 1) on tools/scene.py views -- determinism,
              every pair's uint2_pair list equal to the stand-alone matcher call, BA error sweep against the triangulator's
-             own error sum, cloud against the generator's ground truth; and the same flow (1024^2 fixtures) in TWO
-             processes on the one GPU over gloo, equal to the single-process result;
-  config[4]  8192 x 8192: SIFT properties at that size, and a pushbroom flow (generatePushbroomBundle -> N-view
-             triangulate) against the pushbroom generator's ground truth;
+             own error sum, cloud against the generator's ground truth; the same flow at 4096^2 in TWO processes on the one
+             GPU over gloo, and the 1024^2 fixtures in two and four, all equal to the single-process result;
+  config[4]  8-view 8192 x 8192 pushbroom strips through the whole flow (generatePushbroomBundle -> N-view triangulate)
+             on one GPU against the pushbroom generator's ground truth and for determinism; SIFT properties at that size;
+             the 3-strip 2048^2 flow;
   fp16 matcher (SSRLCV_MATCH_F16=1, the formulation the north star names) in a subprocess against the oracle;
   colour input (convertToBW) and the key-point capacity flag.
 """
@@ -139,23 +140,38 @@ def test_scene_pair_1024_hip_equals_oracle_end_to_end(capi, oracle_lib):
     assert np.median(err) < 3 * rig.gsd and np.percentile(err, 90) < 0.3
 
 
-def _gloo_worker(rank, world, port, out_dir):
+def _gloo_worker(rank, world, port, out_dir, workload):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        torch.cuda.set_device(0)   # both ranks on the one GPU
+        torch.cuda.set_device(0)   # all ranks on the one GPU
         from ssrlcv_amd import capi, pipeline
-        pix = [capi.to_dev(p).view(1024, 1024) for p in H.load_everest_pixels()]
         seed, _ = H.load_seed_features()
-        v = H.load_view("Pipeline3View")
-        res = pipeline.reconstruct(pix, v["cameras"], seed_features=seed, ba=True)
+        if workload == "everest":
+            pix = [capi.to_dev(p).view(1024, 1024) for p in H.load_everest_pixels()]
+            cams = H.load_view("Pipeline3View")["cameras"]
+        else:  # config[3]: the benchmark's 4-view 4096^2 scene (every rank renders it: the generator is deterministic)
+            import scene
+            pix, cams, _, _ = scene.pinhole_views(4, 4096)
+        res = pipeline.reconstruct(pix, cams, seed_features=seed, ba=True)
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), mm=res["matches"], kp=res["keypoints"],
                  pts=res["points"].cpu().numpy(), ba=res["ba_sums"].cpu().numpy())
     finally:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _spawn_ranks(world, out_dir, workload):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_gloo_worker, args=(world, port, str(out_dir), workload), nprocs=world, join=True)
+    return [np.load(out_dir / ("rank%d.npz" % r)) for r in range(world)]
 
 
 @pytest.mark.parametrize("world", [2, 4])
@@ -164,15 +180,8 @@ def test_ranks_on_one_gpu_equal_single_process(capi, tmp_path, world):
     world size 1 and the reference's 3-view fixture: same MatchSet on every rank, same cloud; BA sums to float
     accumulation accuracy (the all-reduce adds the ranks' partial sums).  With 4 ranks and 3 views / 3 pairs the last rank
     owns no image and no pair -- what ranks 4..7 see when the 4-view leg of bench.py runs on 8 GPUs."""
-    import socket
-    import torch.multiprocessing as mp
     from ssrlcv_amd import pipeline
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    mp.spawn(_gloo_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    ranks = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
+    ranks = _spawn_ranks(world, tmp_path, "everest")
     r0 = ranks[0]
     pix = [capi.to_dev(p).view(1024, 1024) for p in H.load_everest_pixels()]
     seed, _ = H.load_seed_features()
@@ -183,6 +192,23 @@ def test_ranks_on_one_gpu_equal_single_process(capi, tmp_path, world):
         assert np.array_equal(r["pts"], one["points"].cpu().numpy())
         assert np.allclose(r["ba"], one["ba_sums"].cpu().numpy(), rtol=1e-4)
     assert len(r0["mm"]) == 21177 and np.array_equal(r0["kp"]["loc"], v["kp0"]["loc"])
+
+
+def test_config3_two_ranks_on_one_gpu_at_4096(capi, tmp_path):
+    """config[3] at its size in the sharded form: the 4-view 4096^2 flow with TWO ranks (both on device 0, gloo) -- two
+    images, three of the six pairs (balanced by nq * nt) and half of the bundles each -- gives every rank the MatchSet and
+    cloud of the single-process run, entry for entry."""
+    import scene
+    from ssrlcv_amd import pipeline
+    ranks = _spawn_ranks(2, tmp_path, "scene4096")
+    imgs, cams, _, _ = scene.pinhole_views(4, 4096)
+    seed, _ = H.load_seed_features()
+    one = pipeline.reconstruct(imgs, cams, seed_features=seed, ba=True)
+    assert len(one["matches"]) > 50000
+    for r in ranks:
+        assert np.array_equal(r["mm"], one["matches"]) and np.array_equal(r["kp"], one["keypoints"])
+        assert np.array_equal(r["pts"], one["points"].cpu().numpy())
+        assert np.allclose(r["ba"], one["ba_sums"].cpu().numpy(), rtol=1e-4)
 
 
 def test_config4_sift_8192_properties(capi):
@@ -231,6 +257,44 @@ def test_config4_pushbroom_flow_against_ground_truth(capi):
     # matcher has no geometric constraint for pushbroom cameras (mode 0 + seed ratio test), so a tail of wrong matches
     # lands kilometres away -- upstream removes it with the statistical filters after triangulation
     assert np.median(err) < 0.05 and good > 0.7
+
+
+def test_config4_eight_view_8192_pushbroom_flow(capi):
+    """BASELINE config[4] at its size on ONE GPU: eight 8192 x 8192 pushbroom strips through ssrlcv_amd.pipeline -- SIFT
+    (one plan reused: eight workspaces of 22 GB would not be sensible), the 28 image pairs (brute force + seed ratio
+    test), the merge, generatePushbroomBundle (src/PointCloudFactory.cu:875-903, :4201-4283) and N-view triangulation --
+    checked for determinism and against the pushbroom generator's ground truth."""
+    import scene
+    from ssrlcv_amd import pipeline
+    S, V = 8192, 8
+    imgs, pbs, rig, sc = scene.pushbroom_views(V, S)
+    seed, _ = H.load_seed_features()
+    ws = pipeline.Workspace()
+    res = pipeline.reconstruct(imgs, None, seed_features=seed, mode=0, pushbroom=pbs, ws=ws)
+    assert len(ws.plans) == 1                      # the plan was reused, not one per strip
+    nfeat = [f.numel() // 152 for f in res["features"]]
+    assert len(nfeat) == V and all(5e5 < n < 8e6 for n in nfeat), nfeat
+    assert len(res["pairs"]) == 28
+    mm, kp, pts = res["matches"], res["keypoints"], res["points"].cpu().numpy()
+    assert len(mm) > 100000 and pts.shape == (len(mm), 3) and np.isfinite(pts).all()
+    assert mm["numKeyPoints"].max() >= 4 and set(np.unique(kp["parentId"])) == set(range(V))
+    err = _ground_truth_error(rig, sc, mm, kp, pts)
+    good = float((err < 0.2).mean())
+    print("config[4] at size: %s features, %d multi-matches (up to %d views), cloud error vs ground truth: median %.4f km, "
+          "%.1f %% within 0.2 km; stages %s" % (nfeat, len(mm), int(mm["numKeyPoints"].max()), np.median(err), 100 * good,
+                                                  {k: round(v * 1e3) for k, v in ws.times.items()}))
+    # Brute-force matching without a geometric constraint over 2-3 million features per strip leaves many more wrong
+    # matches than at 2048^2 (there 71 % of the bundles land within 0.2 km), and in an 8-view merge one wrong member spoils
+    # a bundle: upstream removes these with its statistical filters after triangulation.  What this checks is the geometry
+    # at size: a large consistent set whose pushbroom bundles intersect on the generator's ground truth.
+    inl = err[err < 0.2]
+    print("config[4] at size: %d bundles within 0.2 km, their median error %.4f km" % (len(inl), np.median(inl)))
+    assert len(inl) > 500000 and np.median(inl) < 0.03
+    # determinism: the whole flow again on the same workspace
+    res2 = pipeline.reconstruct(imgs, None, seed_features=seed, mode=0, pushbroom=pbs, ws=ws)
+    assert all(torch.equal(a, b) for a, b in zip(res["features"], res2["features"]))
+    assert np.array_equal(mm, res2["matches"]) and np.array_equal(kp, res2["keypoints"])
+    assert np.array_equal(pts, res2["points"].cpu().numpy())
 
 
 _F16_SCRIPT = r"""
