@@ -255,9 +255,9 @@ def run_nview(args, torch, dist, capi, world, rank, dev, views, size, steps, war
     return {"metric": "Mpix/s N-view reconstruction (SIFT + exhaustive orbit match + merge + N-view triangulate + BA sweep)",
             "value": views * size * size * steps / dt / 1e6, "unit": "Mpix/s", "n_gpus": world, "steps": steps,
             "ms_per_step": dt / steps * 1e3, "scaling": "strong",
-            "workload": "%d-view %dx%d scene, image/pair shard over %d GPU(s): all-gather of features, all-gather of "
-                        "uint2_pair arrays, replicated host merge, bundle-range triangulation + all-gather of the cloud, "
-                        "612-point BA error sweep + all-reduce" % (views, size, size, world),
+            "workload": "%d-view %dx%d scene, image/pair shard over %d GPU(s): all-gather of features, pairs balanced by "
+                        "nq*nt, all-gather of uint2_pair arrays, replicated host merge (all host cores), bundle-range "
+                        "triangulation + all-gather of the cloud, 612-point BA error sweep + all-reduce" % (views, size, size, world),
             "stage_ms_per_step_rank0": {k: v / steps * 1e3 for k, v in ws.times.items()},
             "multi_matches": int(len(res["matches"])), "points": int(res["points"].shape[0]),
             "ba_bundles": int(res.get("ba_bundles", 0)),
@@ -279,8 +279,7 @@ def main():
     ap.add_argument("--no-nview", action="store_true")
     ap.add_argument("--no-class-api", action="store_true")
     ap.add_argument("--nview-views", type=int, default=4)
-    ap.add_argument("--nview-size", type=int, default=2048,
-                    help="edge of the N-view leg's images (config[3] is 4096; the default keeps the whole run within minutes)")
+    ap.add_argument("--nview-size", type=int, default=4096, help="edge of the N-view leg's images (config[3]: 4-view 4096x4096)")
     ap.add_argument("--nview-steps", type=int, default=2)
     ap.add_argument("--noise-input", action="store_true", help="round-1 input: multi-scale noise instead of the scene generator")
     args = ap.parse_args()

@@ -45,6 +45,6 @@ EXPORTED = [
     "ssrlcv_hip_dog_normalised_sub",
     "ssrlcv_sift_plan_create", "ssrlcv_sift_plan_destroy", "ssrlcv_sift_plan_workspace_bytes",
     "ssrlcv_sift_plan_max_features", "ssrlcv_hip_sift_build_dog", "ssrlcv_hip_sift_describe",
-    "ssrlcv_hip_sift_extract", "ssrlcv_sift_plan_level", "ssrlcv_sift_plan_keypoints",
+    "ssrlcv_hip_sift_extract", "ssrlcv_hip_sift_stage", "ssrlcv_sift_plan_level", "ssrlcv_sift_plan_keypoints",
     "ssrlcv_sift_plan_set_stop_stage", "ssrlcv_hip_math_eval", "ssrlcv_sift_plan_overflow",
 ]

@@ -322,6 +322,11 @@ class SiftPlan:
         check(LIB.ssrlcv_hip_sift_describe(self.handle, ptr(self.workspace), ptr(self.features),
                                            ptr(self.num_features), stream_ptr()))
 
+    def stage(self, stage):
+        """One reference launch site of the key-point stage (ssrlcv_hip_sift_stage), on the state the previous one left."""
+        check(LIB.ssrlcv_hip_sift_stage(self.handle, ptr(self.workspace), c_int(stage), ptr(self.features),
+                                        ptr(self.num_features), stream_ptr()))
+
     def extract(self, pixels_d):
         check(LIB.ssrlcv_hip_sift_extract(self.handle, ptr(pixels_d), ptr(self.workspace), ptr(self.features),
                                           ptr(self.num_features), stream_ptr()))

@@ -204,6 +204,18 @@ __global__ __launch_bounds__(256) void k_flag_noise_edges_window(const OctaveSta
   }
 }
 
+// checkKeyPoints alone (src/SIFT_FeatureFactory.cu:449-461), for the stage-at-a-time entry point
+__global__ __launch_bounds__(256) void k_flag_window(const OctaveState* st, ssrlcv_sskeypoint* kps, int w, int h, float pixelWidth,
+                                                     float lambda) {
+  int n = st->hasExtrema ? st->n : 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const ssrlcv_sskeypoint kp = kps[i];
+    const float ww = kp.sigma * lambda / pixelWidth;
+    kps[i].discard = (uint8_t)((kp.loc.x - ww) < 0.0f || (kp.loc.y - ww) < 0.0f || (kp.loc.x + ww) >= (unsigned)(w - 1) ||
+                               (kp.loc.y + ww) >= (unsigned)(h - 1));
+  }
+}
+
 // ---- S10: refineLocation (src/FeatureFactory.cu:892-967) -----------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_refine(const OctaveState* st, ssrlcv_sskeypoint* kps, LevelSet L, float sigmaMin,
                                                 float mult) {
@@ -1061,10 +1073,8 @@ int ssrlcv_sift_plan_keypoints(const ssrlcv_sift_plan* plan, void* workspace, in
                                int** blurIndices_dev) {
   if (!plan || !workspace || octave < 0 || octave >= svp::kOctaves) return SSRLCV_ERR_INVALID_ARG;
   char* ws = (char*)workspace;
-  // the number of ping-pong swaps up to the stop stage decides which buffer holds the result: recorded in the plan
-  // by ssrlcv_hip_sift_describe via off_featBase + 64 (an int flag on the device is avoided: both are returned
-  // consistently by always finishing in buffer A).
-  if (list) *list = (ssrlcv_sskeypoint*)(ws + plan->oct[octave].off_kpA);
+  // the list ping-pongs between the octave's two buffers once per compaction; the plan remembers where it is
+  if (list) *list = (ssrlcv_sskeypoint*)(ws + (plan->listInB[octave] ? plan->oct[octave].off_kpB : plan->oct[octave].off_kpA));
   if (blurIndices_dev) *blurIndices_dev = (int*)(ws + plan->off_state + sizeof(OctaveState) * octave);
   return SSRLCV_OK;
 }
@@ -1083,15 +1093,243 @@ int ssrlcv_sift_plan_overflow(const ssrlcv_sift_plan* plan, const void* workspac
   return m ? SSRLCV_ERR_CAPACITY : SSRLCV_OK;
 }
 
+// ---- the key-point stages, one function per reference launch site --------------------------------------------------------
+}  // extern "C"
+namespace {
+
+struct ListCtx {  // one octave's list chain
+  const ssrlcv_sift_plan* plan;
+  const svp::OctavePlan* oc;
+  int o;
+  hipStream_t s;
+  OctaveState* st;
+  LevelSet L;
+  ssrlcv_sskeypoint *A, *B;
+  uint8_t* flags;
+  uint32_t* words;
+  uint32_t cap;
+  ssrlcv_sskeypoint* cur() const { return plan->listInB[o] ? B : A; }
+  ssrlcv_sskeypoint* oth() const { return plan->listInB[o] ? A : B; }
+  void flip() const { plan->listInB[o] ^= 1; }
+};
+ListCtx make_ctx(const ssrlcv_sift_plan* plan, char* ws, int o, hipStream_t s) {
+  ListCtx c;
+  c.plan = plan;
+  c.oc = &plan->oct[o];
+  c.o = o;
+  c.s = s;
+  c.st = (OctaveState*)(ws + plan->off_state) + o;
+  c.L = make_levels(plan, ws, o);
+  c.A = (ssrlcv_sskeypoint*)(ws + c.oc->off_kpA);
+  c.B = (ssrlcv_sskeypoint*)(ws + c.oc->off_kpB);
+  c.flags = (uint8_t*)(ws + c.oc->off_flags);
+  c.words = (uint32_t*)(ws + c.oc->off_part);
+  c.cap = c.oc->cap;
+  return c;
+}
+
+// searchForExtrema (src/FeatureFactory.cu:86-159): fillExtrema + the compaction of what findExtrema flagged.
+// findExtrema itself ran inside ssrlcv_hip_sift_build_dog (k_dogx: the DoG values exist only there); what is left is
+// the compaction of the flag bytes into the list.  removeNoise(noiseThreshold * 0.8) (src/FeatureFactory.cu:484) follows
+// the search directly and tests the raw DoG value fillExtrema stores as the intensity, so the flag byte carries a second
+// set of bits for the extrema that pass it (afterFirstNoise): the survivors, their order and extremaBlurIndices are
+// those of search + discard, without the first list (1.33 M entries per 4096^2 image, 0.1 % of them noise) being written,
+// flagged and compacted again.
+int stage_extrema(const ListCtx& c, bool afterFirstNoise) {
+  hipLaunchKernelGGL(k_state_reset, dim3(1), dim3(1), 0, c.s, c.st);
+  c.plan->listInB[c.o] = 0;
+  const uint32_t P = c.oc->w * c.oc->h, cap = c.cap;
+  const int W = (int)c.oc->w;
+  const int octaveId = c.o;
+  const float s1 = c.oc->sigma[1], s2 = c.oc->sigma[2], s3 = c.oc->sigma[3];
+  const LevelSet Lc = c.L;
+  ssrlcv_sskeypoint* first = c.A;
+  auto emit = [=] __device__(uint32_t p, int b, uint32_t d) {
+    if (d >= cap) return;
+    ssrlcv_sskeypoint kp;  // fillExtrema (src/FeatureFactory.cu:883-890)
+    kp.octave = octaveId;
+    kp.blur = (int)b + 1;
+    kp.loc.x = (float)(p % W);
+    kp.loc.y = (float)(p / W);
+    kp.intensity = dog_view(Lc, b + 1).raw(p);
+    kp.sigma = b == 0 ? s1 : b == 1 ? s2 : s3;
+    kp.theta = -1.0f;
+    kp.discard = 0;
+    first[d] = kp;
+  };
+  uint32_t* totals = nullptr;
+  hipError_t e = svc::partition_flags<3>(P, c.flags, afterFirstNoise ? svp::kNoiseFlagShift : 0, emit, c.words, &totals, c.s);
+  if (e != hipSuccess) return (int)e;
+  // (a kernel of its own here: the pixel-domain scatter has thousands of blocks, and counting them down with one
+  // same-address atomic each costs more than this launch)
+  hipLaunchKernelGGL(k_book_extrema, dim3(1), dim3(1), 0, c.s, c.st, totals, cap);
+  return SSRLCV_OK;
+}
+int discard_flagged(const ListCtx& c) {  // discardExtrema (src/FeatureFactory.cu:161-215)
+  hipError_t e = run_discard(c.st, c.cur(), c.oth(), c.cap, c.words, c.s);
+  if (e != hipSuccess) return (int)e;
+  c.flip();
+  return SSRLCV_OK;
+}
+int stage_noise(const ListCtx& c, float threshold) {  // removeNoise (:267-285)
+  hipLaunchKernelGGL(k_flag_noise, dim3(list_blocks(c.cap)), dim3(256), 0, c.s, c.st, c.cur(), threshold);
+  return discard_flagged(c);
+}
+int stage_refine(const ListCtx& c) {  // refineExtremaLocation (:217-265)
+  hipLaunchKernelGGL(k_refine, dim3(list_blocks(c.cap)), dim3(256), 0, c.s, c.st, c.cur(), c.L, c.oc->sigma[0],
+                     c.oc->sigma[1] / c.oc->sigma[0]);
+  int rc = discard_flagged(c);
+  if (rc) return rc;
+  // thrust::stable_sort by blur == stable partition on the blur value
+  OctaveState* st = c.st;
+  const OctaveState* cst = c.st;
+  const ssrlcv_sskeypoint* src = c.cur();
+  ssrlcv_sskeypoint* dst = c.oth();
+  auto keyfn = [=] __device__(uint32_t i) -> uint32_t {
+    if (!cst->hasExtrema || (int)i >= cst->n) return 0u;
+    int b = src[i].blur;
+    return (b < 0 || b >= svp::kDog) ? 0u : (1u << b);
+  };
+  auto emit = [=] __device__(uint32_t i, int, uint32_t d) { dst[d] = src[i]; };
+  uint32_t* totals = nullptr;
+  auto post = [=] __device__(const uint32_t* tot) { book_rescan(st, tot); };
+  hipError_t e = svc::partition<svp::kDog, 8>(c.cap, keyfn, emit, c.words, &totals, c.s, &st->n, 1u, post);
+  if (e != hipSuccess) return (int)e;
+  c.flip();
+  return SSRLCV_OK;
+}
+int stage_edges(const ListCtx& c) {  // removeEdges (:287-306)
+  hipLaunchKernelGGL(k_flag_edges, dim3(list_blocks(c.cap)), dim3(256), 0, c.s, c.st, c.cur(), c.L, svp::kEdgeThreshold);
+  return discard_flagged(c);
+}
+int stage_window(const ListCtx& c) {  // checkKeyPoints (src/SIFT_FeatureFactory.cu:81-110,449-461)
+  hipLaunchKernelGGL(k_flag_window, dim3(list_blocks(c.cap)), dim3(256), 0, c.s, c.st, c.cur(), c.L.w, c.L.h, c.oc->pixelWidth,
+                     c.plan->params.descriptorContribWidth);
+  return discard_flagged(c);
+}
+int stage_noise_edges_window(const ListCtx& c) {  // the three of them with one discard (see k_flag_noise_edges_window)
+  hipLaunchKernelGGL(k_flag_noise_edges_window, dim3(list_blocks(c.cap)), dim3(256), 0, c.s, c.st, c.cur(), c.L, svp::kNoiseThreshold,
+                     svp::kEdgeThreshold, c.oc->pixelWidth, c.plan->params.descriptorContribWidth);
+  return discard_flagged(c);
+}
+
+OctaveSet make_set(const ssrlcv_sift_plan* plan, char* ws, uint32_t* unitBlocks) {
+  OctaveSet set;
+  uint32_t blocks = 20;  // upper bound of the orientation kernel's grid: one block per 64 key points of a range
+  for (int o = 0; o < svp::kOctaves; ++o) {
+    const svp::OctavePlan& oc = plan->oct[o];
+    set.L[o] = make_levels(plan, ws, o);
+    set.kps[o] = (const ssrlcv_sskeypoint*)(ws + (plan->listInB[o] ? oc.off_kpB : oc.off_kpA));
+    set.pixelWidth[o] = oc.pixelWidth;
+    set.thetas[o] = (float*)(ws + oc.off_theta);
+    set.thetaCnt[o] = (uint32_t*)(ws + oc.off_thetaCnt);
+    set.consts[o] = ws + oc.off_descConst;
+    blocks += (oc.cap + 63) / 64;
+  }
+  if (unitBlocks) *unitBlocks = blocks;
+  return set;
+}
+
+// computeKeyPointOrientations (src/FeatureFactory.cu:540-632) for all octaves: gradient tables (unless the caller built
+// them on a side stream already), one orientation launch, the expansion of every key point into its orientations
+int stage_orientations(const ssrlcv_sift_plan* plan, char* ws, hipStream_t caller, svp::PlanAsync* as, bool polarDone) {
+  OctaveState* states = (OctaveState*)(ws + plan->off_state);
+  const uint32_t maxO = plan->params.maxOrientations;
+  uint32_t unitBlocks = 0;
+  OctaveSet set = make_set(plan, ws, &unitBlocks);
+  // the two range tables live in the bookkeeping slots of octaves 1 and 2 (octave 0's holds the feature offsets)
+  RangeTable* thetaRanges = (RangeTable*)(ws + plan->oct[1].off_featBase);
+  if (!polarDone) launch_polar(plan, ws, caller);
+  hipLaunchKernelGGL(k_build_ranges, dim3(1), dim3(1), 0, caller, states, thetaRanges, 6);
+  const float lambdaO = plan->params.orientationContribWidth, othr = plan->params.orientationThreshold;
+  switch (maxO) {
+    case 1: hipLaunchKernelGGL(k_thetas<1>, dim3(unitBlocks), dim3(64), 0, caller, states, thetaRanges, set, lambdaO, othr); break;
+    case 2: hipLaunchKernelGGL(k_thetas<2>, dim3(unitBlocks), dim3(64), 0, caller, states, thetaRanges, set, lambdaO, othr); break;
+    case 3: hipLaunchKernelGGL(k_thetas<3>, dim3(unitBlocks), dim3(64), 0, caller, states, thetaRanges, set, lambdaO, othr); break;
+    default: hipLaunchKernelGGL(k_thetas<4>, dim3(unitBlocks), dim3(64), 0, caller, states, thetaRanges, set, lambdaO, othr); break;
+  }
+  // The four expansions are independent three-kernel chains of ~30 us each (launch-bound on the short lists): octave 1's
+  // runs on one side stream, those of octaves 2 and 3 on the other, beside octave 0's on the caller's stream.
+  if (as) {
+    SSRLCV_HIP_TRY(hipEventRecord(as->expandFork, caller));
+    SSRLCV_HIP_TRY(hipStreamWaitEvent(as->chain, as->expandFork, 0));
+    SSRLCV_HIP_TRY(hipStreamWaitEvent(as->table, as->expandFork, 0));
+  }
+  for (int o = 0; o < svp::kOctaves; ++o) {
+    // thrust::remove of the -FLT_MAX / -1 slots + expandKeyPoints (:594-611): element space n x maxOrientations
+    const hipStream_t es = !as || o == 0 ? caller : (o == 1 ? as->chain : as->table);
+    const svp::OctavePlan& oc = plan->oct[o];
+    const uint32_t cap = oc.cap;
+    const OctaveState* cst = states + o;
+    const ssrlcv_sskeypoint* src = (const ssrlcv_sskeypoint*)(ws + (plan->listInB[o] ? oc.off_kpB : oc.off_kpA));
+    ssrlcv_sskeypoint* dst = (ssrlcv_sskeypoint*)(ws + (plan->listInB[o] ? oc.off_kpA : oc.off_kpB));
+    const float* thetas = set.thetas[o];
+    const uint32_t* thetaCnt = set.thetaCnt[o];
+    auto keyfn = [=] __device__(uint32_t e2) -> uint32_t {
+      uint32_t i = e2 / maxO, j = e2 - i * maxO;
+      if (!cst->hasExtrema || (int)i >= cst->n) return 0u;
+      if (j >= thetaCnt[i]) return 0u;
+      return 1u << segment_of(cst, (int)i);
+    };
+    auto emit = [=] __device__(uint32_t e2, int, uint32_t d) {
+      if (d >= cap) return;
+      uint32_t i = e2 / maxO, j = e2 - i * maxO;
+      ssrlcv_sskeypoint kp = src[i];
+      kp.theta = thetas[(size_t)i * svp::kMaxOrient + j];
+      dst[d] = kp;
+    };
+    uint32_t* totals = nullptr;
+    OctaveState* sto = states + o;
+    auto post = [=] __device__(const uint32_t* tot) { book_orient(sto, tot, cap); };
+    hipError_t e = svc::partition<svp::kDog, 8>(cap * maxO, keyfn, emit, (uint32_t*)(ws + oc.off_part), &totals, es,
+                                                &states[o].n, maxO, post);
+    if (e != hipSuccess) return (int)e;
+    plan->listInB[o] ^= 1;
+  }
+  if (as) {
+    SSRLCV_HIP_TRY(hipEventRecord(as->expandJoin[0], as->chain));
+    SSRLCV_HIP_TRY(hipEventRecord(as->expandJoin[1], as->table));
+    SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->expandJoin[0], 0));
+    SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->expandJoin[1], 0));
+  }
+  return SSRLCV_OK;
+}
+
+void book_features(const ssrlcv_sift_plan* plan, char* ws, uint32_t* numFeatures, hipStream_t caller) {
+  hipLaunchKernelGGL(k_book_featbase, dim3(1), dim3(1), 0, caller, (OctaveState*)(ws + plan->off_state),
+                     (uint32_t*)(ws + plan->oct[0].off_featBase), numFeatures, plan->maxFeatures);
+}
+
+// fillDescriptors (src/SIFT_FeatureFactory.cu:131-166,475-549), all octaves in one launch (book_features first)
+int stage_descriptors(const ssrlcv_sift_plan* plan, char* ws, ssrlcv_sift_feature* features, hipStream_t caller) {
+  OctaveState* states = (OctaveState*)(ws + plan->off_state);
+  OctaveSet set = make_set(plan, ws, nullptr);
+  RangeTable* descRanges = (RangeTable*)(ws + plan->oct[2].off_featBase);
+  uint32_t* featBase = (uint32_t*)(ws + plan->oct[0].off_featBase);
+  uint32_t descBlocks = 0, maxBlocks = 1;
+  for (int o = 0; o < svp::kOctaves; ++o) {
+    const svp::OctavePlan& oc = plan->oct[o];
+    descBlocks += list_blocks(oc.cap);
+    maxBlocks = list_blocks(oc.cap) > maxBlocks ? list_blocks(oc.cap) : maxBlocks;
+  }
+  hipLaunchKernelGGL(k_desc_consts, dim3(maxBlocks, svp::kOctaves), dim3(256), 0, caller, states, set,
+                     plan->params.descriptorContribWidth);
+  // one launch over every octave's key points, largest windows first (see RangeTable)
+  hipLaunchKernelGGL(k_build_ranges, dim3(1), dim3(1), 0, caller, states, descRanges, 0);
+  hipLaunchKernelGGL(k_descriptors, dim3(descBlocks * kWaveKernelOversubscription), dim3(256), 0, caller, descRanges, set,
+                     featBase, features, plan->maxFeatures);
+  return SSRLCV_OK;
+}
+
+}  // namespace
+extern "C" {
+
 int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrlcv_sift_feature* features,
                              uint32_t* numFeatures, ssrlcv_stream_t stream) {
   if (!plan || !workspace || !numFeatures) return SSRLCV_ERR_INVALID_ARG;
   char* ws = (char*)workspace;
-  OctaveState* states = (OctaveState*)(ws + plan->off_state);
-  const float noiseThreshold = svp::kNoiseThreshold;  // src/SIFT_FeatureFactory.cu:58
-  const float edgeThreshold = svp::kEdgeThreshold;    // :59
   const int stop = plan->stopStage;
-  const uint32_t maxO = plan->params.maxOrientations;
+  if (stop >= 7 && !features) return SSRLCV_ERR_INVALID_ARG;
   // The four octaves' chains are independent until the feature offsets are summed, and each is a long run of small
   // launches (bookkeeping kernels, compactions of short lists): octave 0's runs on the caller's stream, the three
   // short ones of octaves 1-3 beside it on `chain`, the polar tables on `table`, all forked from and joined back into
@@ -1104,104 +1342,20 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
     SSRLCV_HIP_TRY(hipStreamWaitEvent(as->table, as->fork, 0));
     if (stop >= 6) launch_polar(plan, ws, as->table);
   }
-  ssrlcv_sskeypoint* curBuf[svp::kOctaves];
-  ssrlcv_sskeypoint* othBuf[svp::kOctaves];
   for (int o = 0; o < svp::kOctaves; ++o) {
-    const svp::OctavePlan& oc = plan->oct[o];
-    OctaveState* st = states + o;
-    const hipStream_t s = (as && o > 0) ? as->chain : caller;
-    LevelSet L = make_levels(plan, ws, o);
-    ssrlcv_sskeypoint* A = (ssrlcv_sskeypoint*)(ws + oc.off_kpA);
-    ssrlcv_sskeypoint* B = (ssrlcv_sskeypoint*)(ws + oc.off_kpB);
-    uint8_t* flags = (uint8_t*)(ws + oc.off_flags);
-    uint32_t* words = (uint32_t*)(ws + oc.off_part);
-    const uint32_t cap = oc.cap;
-    // the list ping-pongs between A and B once per compaction; start so that the final list lands in A
-    // stages 3-5 (noise, edges, window check) collapse into one discard when the run goes past them
-    const bool fused = stop >= 5;
-    const int nswaps = 2 * (stop >= 2) + (fused ? 1 : (stop >= 3) + (stop >= 4)) + (stop >= 6);
-    hipLaunchKernelGGL(k_state_reset, dim3(1), dim3(1), 0, s, st);
-    // --- searchForExtrema (src/FeatureFactory.cu:86-159) ---
-    // findExtrema itself ran inside ssrlcv_hip_sift_build_dog (k_dogx: the DoG values exist only there); what is left is
-    // the compaction of the flag bytes into the list.  removeNoise(noiseThreshold * 0.8) (src/FeatureFactory.cu:484)
-    // follows the search directly and tests the raw DoG value fillExtrema stores as the intensity, so the flag byte
-    // carries a second set of bits for the extrema that pass it: when the run goes past that stage the list is built
-    // from those -- the survivors, their order and extremaBlurIndices are those of search + discard, without the first
-    // list (1.33 M entries per 4096^2 image, 0.1 % of them noise) being written, flagged and compacted again.
-    {
-      const uint32_t P = oc.w * oc.h;
-      const int W = (int)oc.w;
-      const int octaveId = o;
-      const float s1 = oc.sigma[1], s2 = oc.sigma[2], s3 = oc.sigma[3];
-      const LevelSet Lc = L;
-      ssrlcv_sskeypoint* first = (nswaps & 1) ? B : A;
-      auto emit = [=] __device__(uint32_t p, int b, uint32_t d) {
-        if (d >= cap) return;
-        ssrlcv_sskeypoint kp;  // fillExtrema (src/FeatureFactory.cu:883-890)
-        kp.octave = octaveId;
-        kp.blur = (int)b + 1;
-        kp.loc.x = (float)(p % W);
-        kp.loc.y = (float)(p / W);
-        kp.intensity = dog_view(Lc, b + 1).raw(p);
-        kp.sigma = b == 0 ? s1 : b == 1 ? s2 : s3;
-        kp.theta = -1.0f;
-        kp.discard = 0;
-        first[d] = kp;
-      };
-      uint32_t* totals = nullptr;
-      hipError_t e = svc::partition_flags<3>(P, flags, stop >= 1 ? svp::kNoiseFlagShift : 0, emit, words, &totals, s);
-      if (e != hipSuccess) return (int)e;
-      // (a kernel of its own here: the pixel-domain scatter has thousands of blocks, and counting them down with one
-      // same-address atomic each costs more than this launch)
-      hipLaunchKernelGGL(k_book_extrema, dim3(1), dim3(1), 0, s, st, totals, cap);
+    const ListCtx c = make_ctx(plan, ws, o, (as && o > 0) ? as->chain : caller);
+    int rc = stage_extrema(c, stop >= 1);
+    if (!rc && stop >= 2) rc = stage_refine(c);
+    // stages 3-5 (noise, edges, window check) collapse into one discard when the run goes past them: the three tests are
+    // independent per key point and the compaction is stable
+    if (!rc && stop >= 5) rc = stage_noise_edges_window(c);
+    else {
+      if (!rc && stop >= 3) rc = stage_noise(c, svp::kNoiseThreshold);
+      if (!rc && stop >= 4) rc = stage_edges(c);
     }
-    ssrlcv_sskeypoint* cur = (nswaps & 1) ? B : A;
-    ssrlcv_sskeypoint* oth = (nswaps & 1) ? A : B;
-    auto swap = [&]() { ssrlcv_sskeypoint* t = cur; cur = oth; oth = t; };
-    hipError_t e;
-    if (stop >= 2) {  // refineExtremaLocation (:217-265)
-      hipLaunchKernelGGL(k_refine, dim3(list_blocks(cap)), dim3(256), 0, s, st, cur, L, oc.sigma[0],
-                         oc.sigma[1] / oc.sigma[0]);
-      if ((e = run_discard(st, cur, oth, cap, words, s)) != hipSuccess) return (int)e;
-      swap();
-      // thrust::stable_sort by blur == stable partition on the blur value
-      {
-        const OctaveState* cst = st;
-        const ssrlcv_sskeypoint* src = cur;
-        ssrlcv_sskeypoint* dst = oth;
-        auto keyfn = [=] __device__(uint32_t i) -> uint32_t {
-          if (!cst->hasExtrema || (int)i >= cst->n) return 0u;
-          int b = src[i].blur;
-          return (b < 0 || b >= svp::kDog) ? 0u : (1u << b);
-        };
-        auto emit = [=] __device__(uint32_t i, int, uint32_t d) { dst[d] = src[i]; };
-        uint32_t* totals = nullptr;
-        auto post = [=] __device__(const uint32_t* tot) { book_rescan(st, tot); };
-        if ((e = svc::partition<svp::kDog, 8>(cap, keyfn, emit, words, &totals, s, &st->n, 1u, post)) != hipSuccess) return (int)e;
-        swap();
-      }
-    }
-    if (fused) {  // removeNoise + removeEdges + checkKeyPoints, one discard (see k_flag_noise_edges_window)
-      hipLaunchKernelGGL(k_flag_noise_edges_window, dim3(list_blocks(cap)), dim3(256), 0, s, st, cur, L, noiseThreshold,
-                         edgeThreshold, oc.pixelWidth, plan->params.descriptorContribWidth);
-      if ((e = run_discard(st, cur, oth, cap, words, s)) != hipSuccess) return (int)e;
-      swap();
-    } else {
-      if (stop >= 3) {  // removeNoise(noiseThreshold)
-        hipLaunchKernelGGL(k_flag_noise, dim3(list_blocks(cap)), dim3(256), 0, s, st, cur, noiseThreshold);
-        if ((e = run_discard(st, cur, oth, cap, words, s)) != hipSuccess) return (int)e;
-        swap();
-      }
-      if (stop >= 4) {  // removeEdges(edgeThreshold)
-        hipLaunchKernelGGL(k_flag_edges, dim3(list_blocks(cap)), dim3(256), 0, s, st, cur, L, edgeThreshold);
-        if ((e = run_discard(st, cur, oth, cap, words, s)) != hipSuccess) return (int)e;
-        swap();
-      }
-    }
-    curBuf[o] = cur;
-    othBuf[o] = oth;
+    if (rc) return rc;
     if (as && o == svp::kOctaves - 1) {  // `chain` is in order: its last event joins octaves 1-3
-      SSRLCV_HIP_TRY(hipEventRecord(as->join[o], s));
+      SSRLCV_HIP_TRY(hipEventRecord(as->join[o], c.s));
       SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->join[o], 0));
     }
   }
@@ -1209,99 +1363,48 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
     SSRLCV_HIP_TRY(hipEventRecord(as->join[svp::kOctaves], as->table));
     SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->join[svp::kOctaves], 0));
   }
-  // per-octave arguments of the two combined sampling launches
-  OctaveSet set;
-  uint32_t unitBlocks = 20;  // upper bound of the orientation kernel's grid: one block per 64 key points of a range
-  for (int o = 0; o < svp::kOctaves; ++o) {
-    const svp::OctavePlan& oc = plan->oct[o];
-    set.L[o] = make_levels(plan, ws, o);
-    set.kps[o] = curBuf[o];
-    set.pixelWidth[o] = oc.pixelWidth;
-    set.thetas[o] = (float*)(ws + oc.off_theta);
-    set.thetaCnt[o] = (uint32_t*)(ws + oc.off_thetaCnt);
-    set.consts[o] = ws + oc.off_descConst;
-    unitBlocks += (oc.cap + 63) / 64;
+  if (stop >= 6) {
+    int rc = stage_orientations(plan, ws, caller, as, as != nullptr);
+    if (rc) return rc;
   }
-  // the two range tables live in the bookkeeping slots of octaves 1 and 2 (octave 0's holds the feature offsets)
-  RangeTable* thetaRanges = (RangeTable*)(ws + plan->oct[1].off_featBase);
-  RangeTable* descRanges = (RangeTable*)(ws + plan->oct[2].off_featBase);
-  if (stop >= 6) {  // computeKeyPointOrientations (src/FeatureFactory.cu:540-632), all octaves in one launch
-    if (!as) launch_polar(plan, ws, caller);
-    hipLaunchKernelGGL(k_build_ranges, dim3(1), dim3(1), 0, caller, states, thetaRanges, 6);
-    const float lambdaO = plan->params.orientationContribWidth, othr = plan->params.orientationThreshold;
-    switch (maxO) {
-      case 1: hipLaunchKernelGGL(k_thetas<1>, dim3(unitBlocks), dim3(64), 0, caller, states, thetaRanges, set, lambdaO, othr); break;
-      case 2: hipLaunchKernelGGL(k_thetas<2>, dim3(unitBlocks), dim3(64), 0, caller, states, thetaRanges, set, lambdaO, othr); break;
-      case 3: hipLaunchKernelGGL(k_thetas<3>, dim3(unitBlocks), dim3(64), 0, caller, states, thetaRanges, set, lambdaO, othr); break;
-      default: hipLaunchKernelGGL(k_thetas<4>, dim3(unitBlocks), dim3(64), 0, caller, states, thetaRanges, set, lambdaO, othr); break;
-    }
-    // The four expansions are independent three-kernel chains of ~30 us each (launch-bound on the short lists): octave 1's
-    // runs on one side stream, those of octaves 2 and 3 on the other, beside octave 0's on the caller's stream.
-    if (as) {
-      SSRLCV_HIP_TRY(hipEventRecord(as->expandFork, caller));
-      SSRLCV_HIP_TRY(hipStreamWaitEvent(as->chain, as->expandFork, 0));
-      SSRLCV_HIP_TRY(hipStreamWaitEvent(as->table, as->expandFork, 0));
-    }
-    for (int o = 0; o < svp::kOctaves; ++o) {
-      // thrust::remove of the -FLT_MAX / -1 slots + expandKeyPoints (:594-611): element space n x maxOrientations
-      const hipStream_t es = !as || o == 0 ? caller : (o == 1 ? as->chain : as->table);
-      const svp::OctavePlan& oc = plan->oct[o];
-      const uint32_t cap = oc.cap;
-      const OctaveState* cst = states + o;
-      const ssrlcv_sskeypoint* src = curBuf[o];
-      ssrlcv_sskeypoint* dst = othBuf[o];
-      const float* thetas = set.thetas[o];
-      const uint32_t* thetaCnt = set.thetaCnt[o];
-      auto keyfn = [=] __device__(uint32_t e2) -> uint32_t {
-        uint32_t i = e2 / maxO, j = e2 - i * maxO;
-        if (!cst->hasExtrema || (int)i >= cst->n) return 0u;
-        if (j >= thetaCnt[i]) return 0u;
-        return 1u << segment_of(cst, (int)i);
-      };
-      auto emit = [=] __device__(uint32_t e2, int, uint32_t d) {
-        if (d >= cap) return;
-        uint32_t i = e2 / maxO, j = e2 - i * maxO;
-        ssrlcv_sskeypoint kp = src[i];
-        kp.theta = thetas[(size_t)i * svp::kMaxOrient + j];
-        dst[d] = kp;
-      };
-      uint32_t* totals = nullptr;
-      OctaveState* sto = states + o;
-      auto post = [=] __device__(const uint32_t* tot) { book_orient(sto, tot, cap); };
-      hipError_t e = svc::partition<svp::kDog, 8>(cap * maxO, keyfn, emit, (uint32_t*)(ws + oc.off_part), &totals, es,
-                                                  &states[o].n, maxO, post);
-      if (e != hipSuccess) return (int)e;
-      ssrlcv_sskeypoint* tmp = curBuf[o];
-      curBuf[o] = othBuf[o];
-      othBuf[o] = tmp;
-    }
-    if (as) {
-      SSRLCV_HIP_TRY(hipEventRecord(as->expandJoin[0], as->chain));
-      SSRLCV_HIP_TRY(hipEventRecord(as->expandJoin[1], as->table));
-      SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->expandJoin[0], 0));
-      SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->expandJoin[1], 0));
-    }
-  }
-  for (int o = 0; o < svp::kOctaves; ++o)
-    if (curBuf[o] != (ssrlcv_sskeypoint*)(ws + plan->oct[o].off_kpA)) return SSRLCV_ERR_INVALID_ARG;  // cannot happen: nswaps accounts for every swap
-  uint32_t* featBase = (uint32_t*)(ws + plan->oct[0].off_featBase);
-  hipLaunchKernelGGL(k_book_featbase, dim3(1), dim3(1), 0, caller, states, featBase, numFeatures, plan->maxFeatures);
+  book_features(plan, ws, numFeatures, caller);
   if (stop >= 7) {
-    if (!features) return SSRLCV_ERR_INVALID_ARG;
-    uint32_t descBlocks = 0, maxBlocks = 1;
-    for (int o = 0; o < svp::kOctaves; ++o) {
-      const svp::OctavePlan& oc = plan->oct[o];
-      set.kps[o] = curBuf[o];
-      descBlocks += list_blocks(oc.cap);
-      maxBlocks = list_blocks(oc.cap) > maxBlocks ? list_blocks(oc.cap) : maxBlocks;
-    }
-    hipLaunchKernelGGL(k_desc_consts, dim3(maxBlocks, svp::kOctaves), dim3(256), 0, caller, states, set,
-                       plan->params.descriptorContribWidth);
-    // one launch over every octave's key points, largest windows first (see RangeTable)
-    hipLaunchKernelGGL(k_build_ranges, dim3(1), dim3(1), 0, caller, states, descRanges, 0);
-    hipLaunchKernelGGL(k_descriptors, dim3(descBlocks * kWaveKernelOversubscription), dim3(256), 0, caller, descRanges, set,
-                       featBase, features, plan->maxFeatures);
+    int rc = stage_descriptors(plan, ws, features, caller);
+    if (rc) return rc;
   }
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
+}
+
+// One reference launch site at a time (INTEGRATION.md option B) on the state the previous stages left in `workspace`:
+//   0 searchForExtrema  1 removeNoise(0.8 x 0.01)  2 refineExtremaLocation (+ sort, re-scan)  3 removeNoise(0.01)
+//   4 removeEdges  5 checkKeyPoints  6 computeKeyPointOrientations  7 fillDescriptors
+int ssrlcv_hip_sift_stage(const ssrlcv_sift_plan* plan, void* workspace, int stage, ssrlcv_sift_feature* features,
+                          uint32_t* numFeatures, ssrlcv_stream_t stream) {
+  if (!plan || !workspace || !numFeatures || stage < 0 || stage > 7) return SSRLCV_ERR_INVALID_ARG;
+  if (stage == 7 && !features) return SSRLCV_ERR_INVALID_ARG;
+  char* ws = (char*)workspace;
+  const hipStream_t caller = (hipStream_t)stream;
+  int rc = SSRLCV_OK;
+  if (stage <= 5) {
+    for (int o = 0; o < svp::kOctaves && !rc; ++o) {
+      const ListCtx c = make_ctx(plan, ws, o, caller);
+      switch (stage) {
+        case 0: rc = stage_extrema(c, false); break;
+        case 1: rc = stage_noise(c, (float)(svp::kNoiseThreshold * 0.8)); break;
+        case 2: rc = stage_refine(c); break;
+        case 3: rc = stage_noise(c, svp::kNoiseThreshold); break;
+        case 4: rc = stage_edges(c); break;
+        default: rc = stage_window(c); break;
+      }
+    }
+  } else if (stage == 6) {
+    rc = stage_orientations(plan, ws, caller, nullptr, false);
+  }
+  if (rc) return rc;
+  book_features(plan, ws, numFeatures, caller);
+  if (stage == 7) rc = stage_descriptors(plan, ws, features, caller);
+  if (rc) return rc;
   SSRLCV_LAUNCH_CHECK();
   return SSRLCV_OK;
 }

@@ -113,6 +113,10 @@ struct ssrlcv_sift_plan {
   size_t total;
   uint32_t maxFeatures;
   int stopStage;
+  // which of an octave's two list buffers holds the current key-point list (it ping-pongs once per compaction); written
+  // by every key-point stage, read by the next one and by ssrlcv_sift_plan_keypoints.  Host-side state of the (plan,
+  // workspace) pair the stages run on: one extraction at a time per plan.
+  mutable uint8_t listInB[svp::kOctaves];
   mutable svp::PlanAsync* async;  // created on first use (needs a device); see svp::plan_async
   mutable int asyncState;         // 0 not tried, 1 ready, -1 serial (SSRLCV_SIFT_SERIAL set or creation failed)
 };

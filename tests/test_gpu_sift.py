@@ -371,3 +371,34 @@ def test_small_and_thin_images_match_oracle(capi, oracle_lib, size):
     print("%d x %d: %d features" % (w, h, len(gf)))
     assert len(gf) == len(of)
     H.assert_features_equal(gf, of)
+
+
+def test_stage_at_a_time_entry_point_matches_the_fused_call(capi, oracle_lib, image_small):
+    """ssrlcv_hip_sift_stage runs one reference launch site per call (INTEGRATION.md option B).  After every call the
+    octave lists equal the oracle's at that stage, and stages 0..7 in order land on the features of the fused
+    ssrlcv_hip_sift_extract, bit for bit."""
+    img = image_small
+    h, w = img.shape
+    osf = H.OracleSift(oracle_lib, img)
+    plan = capi.SiftPlan(w, h)
+    plan.build_dog(capi.to_dev(img))
+    for stage in range(8):
+        plan.stage(stage)
+        if stage <= 6:
+            okps, oidx = osf.keypoints(stage)
+            pos = 0
+            for o in range(4):
+                g, gidx, overflow = plan.keypoints(o, H.SSKEYPOINT)
+                n_o = int(oidx[o][5])
+                assert overflow == 0
+                _compare_keypoints(g, okps[pos: pos + n_o], stage)
+                if n_o:
+                    assert np.array_equal(gidx[:5], oidx[o][:5]), (stage, o, gidx, oidx[o])
+                pos += n_o
+            assert plan.count() == len(okps)
+    osf.close()
+    staged = plan.features_host(H.FEATURE)
+    fused = capi.SiftPlan(w, h)
+    fused.extract(capi.to_dev(img))
+    H.assert_features_equal(staged, fused.features_host(H.FEATURE))
+    H.assert_features_equal(staged, H.oracle_sift(oracle_lib, img))
