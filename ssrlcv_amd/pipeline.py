@@ -184,7 +184,13 @@ def build_match_set(features, pair_tensors, dev=None):
     if len(mem):
         mem_d = capi.to_dev(np.ascontiguousarray(mem, np.uint32))
         kp_d = capi.keypoints_from_members(mem_d, len(mem), features)
-        kp = capi.to_host(kp_d, KEYPOINT, len(mem))
+        # D2H through a pinned staging buffer (16 B per member: 16 MB for four 4096^2 views; pageable it took 5.6 ms)
+        nbytes = 16 * len(mem)
+        if getattr(build_match_set, "_stage", None) is None or build_match_set._stage.numel() < nbytes:
+            build_match_set._stage = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, pin_memory=True)
+        stage = build_match_set._stage[:nbytes]
+        stage.copy_(kp_d[:nbytes])
+        kp = stage.numpy().view(KEYPOINT).copy()
         kp["pad"] = 0
         if dev is not None:
             dev["keypoints"] = kp_d
