@@ -44,7 +44,14 @@ OMP_THREADS = _H.limit_openmp()  # the OpenMP team = the CPUs this process is gr
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (~2.5 PF)
 MFMA_I8_PEAK_TOPS = 5000.0     # dense int8 MFMA peak: twice the bf16 rate per clock (MI355X_MICROARCH.md)
-VALU_PEAK_GINST = 1024 * 2.4 / 4.0  # wave-instructions per ns: 256 CUs x 4 SIMDs, one VALU issue per 4 clocks at 2.4 GHz
+# Vector-ALU issue peak in wave-instructions per ns: 256 CUs x 4 SIMDs x 2.4 GHz, a wave64 instruction every TWO clocks (the
+# CDNA4 SIMD is 32 lanes wide: MI355X_MICROARCH.md glossary; tools/valu_rate.hip measures 2.4-2.9 clocks for the simple
+# ops and 4.2 for an FMA with an SGPR source).  Round 2 priced against one per four clocks and reported a kernel above 1.
+VALU_PEAK_GINST = 1024 * 2.4 / 2.0
+# what v_mfma_i32_32x32x32_i8 sustains on this part with random operands, issued back to back from registers with nothing
+# else in the way (tools/mfma_i8_peak.hip: 4.96 POP/s on zeros, 3.38 on random bytes -- the clock the chip holds under the
+# load depends on the toggling): the practical ceiling beside the data-sheet peak the roofline is priced against
+MFMA_I8_SUSTAINED_TOPS = 3380.0
 
 
 def synth_images(n, w, h, seed, device):
@@ -81,9 +88,15 @@ def synth_descriptors(n, seed):
 
 
 def git_head():
+    """The commit this tree was built from: git when it is there, else the stamp __graft_entry__.build() leaves beside the
+    library (the GPU box receives a snapshot without .git)."""
     try:
         return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
     except Exception:
+        pass
+    try:
+        return open(os.path.join(ROOT, "ssrlcv_amd", "_build_commit.txt")).read().strip() or None
+    except OSError:
         return None
 
 
@@ -114,9 +127,14 @@ def bench_matcher(capi, torch, nq, nt, iters):
             "roofline": {"bound": "mfma", "achieved": tops, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
                          "frac": tops / MFMA_I8_PEAK_TOPS, "traffic": None,
                          "frac_of_fp16_peak": tops / MFMA_F16_PEAK_TFLOPS,
+                         "sustained_peak_random_operands": MFMA_I8_SUSTAINED_TOPS,
+                         "frac_of_sustained_peak": tops / MFMA_I8_SUSTAINED_TOPS,
                          "kernel": "k_match_i8 (v_mfma_i32_32x32x32_i8, exact), whole ssrlcv_hip_match_u8x128 call; "
                                    "ops = 2*128*Nq*Nt, priced against the int8 dense peak (2x the fp16 peak the "
-                                   "north star names: frac_of_fp16_peak is the same rate against that)"}}
+                                   "north star names: frac_of_fp16_peak is the same rate against that); "
+                                   "sustained_peak_random_operands = the same instruction alone on random bytes "
+                                   "(tools/mfma_i8_peak.hip: the part is power-limited there, 4.96 POP/s on zeros); "
+                                   "matrix-pipe busy cycles and clock: profiles/r03_matcher_pmc.txt"}}
 
 
 def bench_matcher_epipolar(capi, torch, n, size, iters):
@@ -203,22 +221,35 @@ def class_api_leg(img_u8, size, value_c_abi, iters=5):
 
 
 def describe_roofline(ms_per_image, features, size):
-    """VALU-issue roofline of the key-point stage from the committed PMC reduction of its kernels (instruction counts per
-    feature do not depend on the run; the time does)."""
-    path = os.path.join(ROOT, "profiles", "r02_describe_pmc.json")
+    """Roofline of the key-point stage.  Its kernels are bound by vector-instruction issue (the sampling kernels) or move
+    little data, so the stage is priced against the VALU issue peak with the wave-instruction count of the committed PMC
+    reduction (instructions per feature do not depend on the run; the time does), and its algorithmic bytes against HBM
+    beside it.  Per-kernel fractions come from the PMC run's own image and time (profiles/r03_describe_pmc.json)."""
+    path = os.path.join(ROOT, "profiles", "r03_describe_pmc.json")
     out = {"ms_per_image": ms_per_image, "features_per_image": features,
            "ns_per_feature": ms_per_image * 1e6 / max(features, 1),
-           "kernels": "k_extrema_flags, partitions, k_refine, k_flag_*, k_polar, k_thetas, k_desc_consts, k_descriptors "
-                      "(ssrlcv_hip_sift_describe); events bracket the call on the launching stream"}
+           "kernels": "flag-byte compaction, k_refine, k_flag_*, list partitions, k_polar, k_thetas, k_desc_consts, k_descriptors "
+                      "(ssrlcv_hip_sift_describe; the extrema search itself runs in the pyramid stage's fused DoG pass); "
+                      "events bracket the call on the launching stream"}
     if os.path.exists(path):
         pmc = json.load(open(path))
         per_feature = pmc.get("valu_wave_instructions_per_feature")
         if per_feature:
-            ginst = per_feature * features / (ms_per_image * 1e6)  # wave-instructions per ns
+            # instructions of this run's images: the per-PIXEL kernel (polar tables) as counted, the list and sampling
+            # kernels scaled by the feature count (the PMC run's image has pmc["features_per_image"] features)
+            total = pmc["valu_wave_instructions_per_image"]
+            per_pixel = pmc.get("per_kernel", {}).get("k_polar", {}).get("valu_wave_instructions_per_image", 0.0)
+            valu = per_pixel + (total - per_pixel) * features / max(pmc["features_per_image"], 1)
+            ginst = valu / (ms_per_image * 1e6)
             out.update({"bound": "valu", "achieved": ginst, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
                         "frac": ginst / VALU_PEAK_GINST, "traffic": pmc.get("hbm_bytes_per_image"),
                         "algorithmic_bytes_per_image": pmc.get("algorithmic_bytes_per_image"),
-                        "pmc_source": "profiles/r02_describe_pmc.json @ %s" % pmc.get("commit")})
+                        "hbm_frac": pmc.get("algorithmic_bytes_per_image", 0) / (ms_per_image * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "per_kernel_from_pmc_run": {k: {"ms": round(v["ms_per_image_under_pmc"], 4),
+                                                        "valu_frac": None if v.get("valu_frac") is None else round(v["valu_frac"], 3),
+                                                        "hbm_frac": None if v.get("hbm_frac") is None else round(v["hbm_frac"], 3)}
+                                                    for k, v in pmc.get("per_kernel", {}).items()},
+                        "pmc_source": "profiles/r03_describe_pmc.json @ %s (its own image: %d features)" % (pmc.get("commit"), pmc.get("features_per_image", 0))})
     return out
 
 
@@ -347,16 +378,22 @@ def main():
     line = None
     if rank == 0:
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r02_pyramid_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_pyramid_traffic.json")
         if W == 4096 and H_ == 4096 and os.path.exists(tpath):
             # HBM bytes of the pyramid stage per image from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the stage
             # benchmark (collected off-line: counters cannot be read from inside the timed run)
             tj = json.load(open(tpath))
-            traffic, traffic_src = tj["pyramid_stage_bytes_per_image"], "profiles/r02_pyramid_traffic.json @ %s" % tj.get("commit")
+            traffic, traffic_src = tj["pyramid_stage_bytes_per_image"], "profiles/r03_pyramid_traffic.json @ %s" % tj.get("commit")
         pixels_per_step = world * args.images * W * H_
         value = pixels_per_step * args.steps / dt / 1e6
-        b_pyr = 362.25 * W * H_  # bytes per image
-        achieved = b_pyr / (pyr_ms * 1e-3) / 1e9
+        # Algorithmic bytes of the stage.  B_pyr = 362.25 W H covers S1-S7 with the DoG levels written; the
+        # stage now also runs S8 (findExtrema) in the same pass, whose own figure there is 20 B per scale-space pixel
+        # read (5 DoG levels) + 1 B of flags written: (20 + 1) x 5.3125 W H.  The roofline prices what the stage does
+        # (S1-S8) against the sum; `frac_pyramid_only` keeps the S1-S7 figure alone over the same time for comparison with
+        # rounds 1-2 (there S8 was a separate 0.43 ms kernel of the key-point stage).
+        b_pyr = 362.25 * W * H_
+        b_ext = 21.0 * 5.3125 * W * H_
+        achieved = (b_pyr + b_ext) / (pyr_ms * 1e-3) / 1e9
         line = {
             "metric": "Mpix/s SIFT extract (+ Mmatches/s 128-D brute-force, see `matcher`)",
             "value": value, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -367,9 +404,13 @@ def main():
                        "images_per_gpu": args.images, "features_per_image": nfeat, "parallelism": "image-pair shard"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "DoG pyramid stage = ssrlcv_hip_sift_build_dog (u8 upsample in the first level's loader, 24 "
-                                   "gaussian levels -- the level-3 launches also write the 2x2 bin --, 5 DoG launches per image); "
-                                   "algorithmic bytes 362.25*W*H per image; events bracket the stage on the launching stream",
+                         "kernel": "scale-space stage = ssrlcv_hip_sift_build_dog: S1-S8 (u8 upsample in the first level's loader, "
+                                   "24 gaussian levels -- the level-3 launches also write the 2x2 bin --, then per octave ONE pass "
+                                   "that forms the 5 DoG levels in registers, reduces their min / max and finds the extrema: the "
+                                   "DoG levels are never written); algorithmic bytes (362.25 + 111.56)*W*H per image = B_pyr (S1-S7) "
+                                   "+ S8's 21 B per scale-space pixel; events bracket the stage on the launching stream",
+                         "algorithmic_bytes": b_pyr + b_ext,
+                         "frac_pyramid_only": b_pyr / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "ms_per_image": pyr_ms},
             "describe": describe_roofline(desc_ms, int(np.mean(nfeat)), W),
         }
