@@ -1331,19 +1331,22 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
   const int stop = plan->stopStage;
   if (stop >= 7 && !features) return SSRLCV_ERR_INVALID_ARG;
   // The four octaves' chains are independent until the feature offsets are summed, and each is a long run of small
-  // launches (bookkeeping kernels, compactions of short lists): octave 0's runs on the caller's stream, the three
-  // short ones of octaves 1-3 beside it on `chain`, the polar tables on `table`, all forked from and joined back into
-  // the caller's stream.
+  // launches (bookkeeping kernels, compactions of short lists): octave 0's runs on the caller's stream, octave 1's on
+  // `chain`, those of octaves 2-3 on `chain2`, the polar tables on `table`, all forked from and joined back into the
+  // caller's stream.
   svp::PlanAsync* as = svp::plan_async(plan);
   const hipStream_t caller = (hipStream_t)stream;
   if (as) {
     SSRLCV_HIP_TRY(hipEventRecord(as->fork, caller));
     SSRLCV_HIP_TRY(hipStreamWaitEvent(as->chain, as->fork, 0));
+    SSRLCV_HIP_TRY(hipStreamWaitEvent(as->chain2, as->fork, 0));
     SSRLCV_HIP_TRY(hipStreamWaitEvent(as->table, as->fork, 0));
     if (stop >= 6) launch_polar(plan, ws, as->table);
   }
   for (int o = 0; o < svp::kOctaves; ++o) {
-    const ListCtx c = make_ctx(plan, ws, o, (as && o > 0) ? as->chain : caller);
+    // octave 1's chain on one side stream, those of octaves 2 and 3 one after the other on a second (round 3: the three
+    // short chains in a row on one stream, ~25 launch-bound kernels each, ended after the polar tables)
+    const ListCtx c = make_ctx(plan, ws, o, !as || o == 0 ? caller : (o == 1 ? as->chain : as->chain2));
     int rc = stage_extrema(c, stop >= 1);
     if (!rc && stop >= 2) rc = stage_refine(c);
     // stages 3-5 (noise, edges, window check) collapse into one discard when the run goes past them: the three tests are
@@ -1354,7 +1357,7 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
       if (!rc && stop >= 4) rc = stage_edges(c);
     }
     if (rc) return rc;
-    if (as && o == svp::kOctaves - 1) {  // `chain` is in order: its last event joins octaves 1-3
+    if (as && (o == 1 || o == svp::kOctaves - 1)) {  // the side streams are in order: their last events join them
       SSRLCV_HIP_TRY(hipEventRecord(as->join[o], c.s));
       SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->join[o], 0));
     }

@@ -1639,22 +1639,25 @@ PlanAsync* plan_async(const ssrlcv_sift_plan* plan) {
       auto mk = [&](hipEvent_t& e) { ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
       if (ok) {
         // per-device side streams, created once and kept for the life of the process
-        static std::map<int, std::pair<hipStream_t, hipStream_t>> pool;
+        struct Side { hipStream_t chain, table, chain2; };
+        static std::map<int, Side> pool;
         int dev = 0;
         ok = hipGetDevice(&dev) == hipSuccess;
         auto it = pool.find(dev);
         if (ok && it == pool.end()) {
-          std::pair<hipStream_t, hipStream_t> pr{nullptr, nullptr};
+          Side pr{nullptr, nullptr, nullptr};
           int least = 0, greatest = 0;
           (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
           const int tablePrio = getenv("SSRLCV_SIDE_LOW_PRIORITY") ? least : 0;
-          ok = hipStreamCreateWithFlags(&pr.first, hipStreamNonBlocking) == hipSuccess &&
-               hipStreamCreateWithPriority(&pr.second, hipStreamNonBlocking, tablePrio) == hipSuccess;
+          ok = hipStreamCreateWithFlags(&pr.chain, hipStreamNonBlocking) == hipSuccess &&
+               hipStreamCreateWithPriority(&pr.table, hipStreamNonBlocking, tablePrio) == hipSuccess &&
+               hipStreamCreateWithFlags(&pr.chain2, hipStreamNonBlocking) == hipSuccess;
           if (ok) it = pool.emplace(dev, pr).first;
         }
         if (ok) {
-          a->chain = it->second.first;
-          a->table = it->second.second;
+          a->chain = it->second.chain;
+          a->table = it->second.table;
+          a->chain2 = it->second.chain2;
         }
         mk(a->fork);
         for (hipEvent_t& e : a->join) mk(e);

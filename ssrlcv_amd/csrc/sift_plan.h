@@ -83,7 +83,7 @@ constexpr unsigned kDogMaxBlocks = 16384;               // grid bound of the str
 constexpr unsigned kDogMaxWaves = kDogMaxBlocks * 4;
 
 struct PlanAsync {
-  hipStream_t chain, table;
+  hipStream_t chain, table, chain2;  // chain2: the list chains of octaves 2-3 in describe (octave 1's runs on `chain`)
   hipEvent_t fork;
   hipEvent_t join[kOctaves + 1], convDone[kOctaves], dogDone[kOctaves], polarDone[kOctaves];
   hipEvent_t binDone[kOctaves];              // build_dog: level 3 of octave o and its 2x2 bin are complete
