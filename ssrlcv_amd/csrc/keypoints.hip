@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <math.h>
+#include <stdlib.h>
 #include "compact.h"
 #include "device_math.h"
 #include "sift_plan.h"
@@ -1240,6 +1241,10 @@ int stage_orientations(const ssrlcv_sift_plan* plan, char* ws, hipStream_t calle
   // the two range tables live in the bookkeeping slots of octaves 1 and 2 (octave 0's holds the feature offsets)
   RangeTable* thetaRanges = (RangeTable*)(ws + plan->oct[1].off_featBase);
   if (!polarDone) launch_polar(plan, ws, caller);
+  // (Round 3 built this kernel with two and with four lanes per key point -- the 36 bins split between the lanes of a
+  // group, each bin keeping its sequential chain, the samples' weights shared by DPP: bit-identical, and the same 0.58 ms
+  // per 4096^2 image with 1, 2 or 4 lanes.  The kernel is bound by the gather of the polar tables: it reads all 2.2 GB of
+  // them once, at the ~4 TB/s that 150-300-byte row segments reach.)
   hipLaunchKernelGGL(k_build_ranges, dim3(1), dim3(1), 0, caller, states, thetaRanges, 6);
   const float lambdaO = plan->params.orientationContribWidth, othr = plan->params.orientationThreshold;
   switch (maxO) {

@@ -402,3 +402,4 @@ def test_stage_at_a_time_entry_point_matches_the_fused_call(capi, oracle_lib, im
     fused.extract(capi.to_dev(img))
     H.assert_features_equal(staged, fused.features_host(H.FEATURE))
     H.assert_features_equal(staged, H.oracle_sift(oracle_lib, img))
+
