@@ -58,7 +58,8 @@ class SIFT_FeatureFactory : public FeatureFactory {
     }
     if (rc == SSRLCV_ERR_UNSUPPORTED) {
       logger.err << "ERROR: image size / contribution widths outside what the MI355X SIFT plan supports "
-                    "(octave 0 below 512 px or above 16384 px on a side, descriptor width > 30, orientation width > 5)";
+                    "(input below 64 px on a side -- upstream's 65-tap mirror reads outside its smallest octave there -- or "
+                    "octave 0 above 16384 px, descriptor width > 30, orientation width > 5)";
       std::exit(-1);
     }
     HipSafeCall(rc);
