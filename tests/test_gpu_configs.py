@@ -368,3 +368,45 @@ def test_keypoint_capacity_overflow_is_reported_and_truncates(capi, oracle_lib):
     full.extract(capi.to_dev(img))
     assert full.overflow_mask() == 0
     H.assert_features_equal(full.features_host(H.FEATURE), of)
+
+
+def _nccl_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        from ssrlcv_amd import dist as sd
+        dev = torch.device("cuda", 0)
+        items = {k: torch.arange(100 * (k + 1), dtype=torch.uint8, device=dev) for k in range(3)}
+        out = sd.exchange_keyed(items, 3, sd.image_owner)
+        assert all(o.is_cuda and torch.equal(o, items[k]) for k, o in enumerate(out))
+        owners = sd.assign_pairs([1000, 2000, 3000], world)
+        out = sd.exchange_keyed(items, 3, lambda p, _w: owners[p])
+        assert all(torch.equal(o, items[k]) for k, o in enumerate(out))
+        parts = sd.all_gather_bytes(items[2])
+        assert len(parts) == 1 and torch.equal(parts[0], items[2])
+        assert sd.all_gather_bytes(torch.zeros(0, dtype=torch.uint8, device=dev))[0].numel() == 0
+        t = torch.arange(612, dtype=torch.float32, device=dev)
+        sd.all_reduce_sum(t)
+        assert torch.equal(t, torch.arange(612, dtype=torch.float32, device=dev))
+        dist.barrier()
+        open(os.path.join(out_dir, "nccl_ok"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchanges_run_on_the_nccl_backend(tmp_path):
+    """The collectives of ssrlcv_amd.dist on CUDA tensors under the `nccl` (= RCCL) backend -- the branch the gloo tests
+    never take: device-side size all-reduce, padded uint8 all-gather, float all-reduce, barrier.  One rank (one GPU here;
+    RCCL refuses two ranks on one device), so the data path is the identity, but every call is the one an 8-GPU run makes."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_nccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    assert (tmp_path / "nccl_ok").exists()
