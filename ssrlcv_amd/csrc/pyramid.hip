@@ -850,6 +850,8 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma2(ConvArgs a) {
   if (a.minmax) block_minmax_commit(mn, mx, a.minmax, s_mem);
 }
 
+#include "gauss_rm.inc"
+
 // ---- S4 for the small levels: one tile per block, no marching ---------------------------------------------------------
 // The marching kernels pay a 2R-row warm-up and one barrier per 8 or 16 rows; a 1024^2 or 2048^2 level gives them 64 to
 // 512 blocks of 8 to 12 sequential steps each -- 16 to 60 us per level for work the chip does in 2 (octaves 2 and 3: 0.40 ms
@@ -1488,6 +1490,26 @@ void launch_valu(ConvArgs a, int RT, uint32_t firstColumn, hipStream_t st) {
 #undef SSRLCV_LAUNCH_VALU
 }
 
+// Which radii go to the register-marching kernel (gauss_rm.inc): a bit per padded radius 6, 8, 12, 16, 24, 32, and the
+// smallest level (pixels) it is used for.  Measured per 8192^2 level on MI355X (tools/gauss_rm_lab.hip, us, established
+// kernel -> register-marching): 13 taps 114 -> 123, 17 taps 117 -> 123, 23 taps 154 -> 126, 33 taps 169 -> 154, 47 taps
+// 207 -> 186, 65 taps 240 -> 268; per 4096^2 level 41 -> 42, 45 -> 53, 56 -> 62 at 23 / 33 / 47 taps (its blocks are 128
+// rows there, a quarter to a half of them warm-up).  Default: radii 12, 16 and 24 from 2^25 pixels up.
+// SSRLCV_GAUSS_RM=<mask>, SSRLCV_GAUSS_RM_MINPX=<pixels>, SSRLCV_GAUSS_RM_ROWS=<rows per block> override; lab drivers
+// overwrite them in place.
+int& rm_mask() {
+  static int m = getenv("SSRLCV_GAUSS_RM") ? atoi(getenv("SSRLCV_GAUSS_RM")) : (4 | 8 | 16);
+  return m;
+}
+size_t& rm_min_px() {
+  static size_t v = getenv("SSRLCV_GAUSS_RM_MINPX") ? (size_t)atoll(getenv("SSRLCV_GAUSS_RM_MINPX")) : ((size_t)1 << 25);
+  return v;
+}
+int& rm_rows() {
+  static int r = getenv("SSRLCV_GAUSS_RM_ROWS") ? atoi(getenv("SSRLCV_GAUSS_RM_ROWS")) : 0;
+  return r;
+}
+
 // binOut (nullable): where the 2x2 bin of the result may be written by the convolution itself; *binned tells whether it was
 // (only k_gauss_mfma2 / k_gauss_tile do it, for even sizes with W % 4 == 0 and no partial strip) -- otherwise the caller
 // runs k_bin2x
@@ -1562,6 +1584,52 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
     SSRLCV_LAUNCH_CHECK();
     return SSRLCV_OK;
   }
+  // the register-marching kernel (gauss_rm.inc): 256-column strips
+  const int rmMask = rm_mask(), rmRows = rm_rows();
+  const int R2 = R <= 6 ? 6 : R <= 8 ? 8 : R <= 12 ? 12 : R <= 16 ? 16 : R <= 24 ? 24 : 32;  // radii padded to even values
+  const int r2bit = R2 == 6 ? 1 : R2 == 8 ? 2 : R2 == 12 ? 4 : R2 == 16 ? 8 : R2 == 24 ? 16 : 32;
+  if ((rmMask & r2bit) && !forceValu && !forceMfma && (size_t)w * h >= rm_min_px() && !u8src && w >= 256 && h >= 64 && (w & 3) == 0 && (h & 3) == 0 && (reinterpret_cast<size_t>(in) & 15) == 0 &&
+      (reinterpret_cast<size_t>(out) & 15) == 0 && (uint64_t)w * h * 4 < ((uint64_t)1 << 32)) {
+    const uint32_t nS = w / 256, cov = nS * 256;
+    ConvArgs r = a;
+    if (canBin && cov == w) { r.binOut = binOut; if (binned) *binned = true; }
+    memset(r.wgt, 0, sizeof r.wgt);
+    for (int k = 0; k <= R; ++k) r.wgt[(R2 - R) + k] = weights_host[k];
+#define SSRLCV_LAUNCH_RM(RR)                                                                                        \
+  do {                                                                                                              \
+    static int blocksPerCu = 0, cus = 0;                                                                            \
+    if (!blocksPerCu) {                                                                                             \
+      SSRLCV_HIP_TRY(hipFuncSetAttribute((const void*)k_gauss_rm<RR>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                         (int)RmCfg<RR>::ldsBytes));                                                \
+      int dev = 0, occ = 0;                                                                                         \
+      SSRLCV_HIP_TRY(hipGetDevice(&dev));                                                                           \
+      SSRLCV_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));                      \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_gauss_rm<RR>, 256,                    \
+                                                       RmCfg<RR>::ldsBytes) != hipSuccess || occ < 1)               \
+        occ = 1;                                                                                                    \
+      blocksPerCu = occ;                                                                                            \
+    }                                                                                                               \
+    uint32_t by = ((uint32_t)(blocksPerCu * cus) + nS - 1) / nS;                                                    \
+    uint32_t rows = (h + by - 1) / by;                                                                              \
+    rows = rows < 128 ? 128 : rows;                                                                                 \
+    if (rmRows > 0) rows = (uint32_t)rmRows;                                                                        \
+    rows = (rows + 15) / 16 * 16;                                                                                   \
+    r.rowsPerBlock = rows;                                                                                          \
+    hipLaunchKernelGGL(k_gauss_rm<RR>, dim3(nS, (h + rows - 1) / rows), dim3(256), RmCfg<RR>::ldsBytes, st, r); \
+  } while (0)
+    switch (R2) {
+      case 6: SSRLCV_LAUNCH_RM(6); break;
+      case 8: SSRLCV_LAUNCH_RM(8); break;
+      case 12: SSRLCV_LAUNCH_RM(12); break;
+      case 16: SSRLCV_LAUNCH_RM(16); break;
+      case 24: SSRLCV_LAUNCH_RM(24); break;
+      default: SSRLCV_LAUNCH_RM(32); break;
+    }
+#undef SSRLCV_LAUNCH_RM
+    if (cov < w) launch_valu(a, RT, cov, st);
+    SSRLCV_LAUNCH_CHECK();
+    return SSRLCV_OK;
+  }
   // the MFMA kernel serves full strips of 16-byte aligned rows; what is left of the width goes to the VALU kernel
   // 128-column strips let two blocks (8 waves each) share a CU's 160 KB of LDS (R <= 24).  Alone on the chip they are
   // slower than the 256-column ones (more halo, two accumulation chains per wave instead of four: 0.632 / 0.834 / 0.801
@@ -1578,8 +1646,6 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
     SSRLCV_LAUNCH_CHECK();
     return SSRLCV_OK;
   }
-  // radii padded to even values (see k_gauss_mfma2)
-  const int R2 = R <= 6 ? 6 : R <= 8 ? 8 : R <= 12 ? 12 : R <= 16 ? 16 : R <= 24 ? 24 : 32;
   const uint32_t nStrips = w / tw, covered = nStrips * tw;
   ConvArgs m = a;
   if (canBin && covered == w) { m.binOut = binOut; if (binned) *binned = true; }

@@ -283,11 +283,14 @@ print("CONV OK", n)
     {"SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_GAUSS_MFMA_MINR": "6", "SSRLCV_GAUSS_WIDE": "1"},
     {"SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_GAUSS_VALU": "1"},         # VALU formulation for every radius
     {"SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_GAUSS_MFMA_MINR": "6", "SSRLCV_GAUSS_NARROW": "1"},  # 128-column MFMA strips + a VALU remainder strip
+    {"SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_GAUSS_RM": "63", "SSRLCV_GAUSS_RM_MINPX": "0"},      # register-marching 4x4x1 kernel for every radius
+    {"SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_GAUSS_RM": "63", "SSRLCV_GAUSS_RM_MINPX": "0", "SSRLCV_GAUSS_RM_ROWS": "48"},  # ... in short blocks
 ], ids=lambda v: "+".join(k.replace("SSRLCV_GAUSS_", "") + "=" + x for k, x in v.items()))
 def test_every_gaussian_formulation_is_bit_exact(variant):
     """The formulation is chosen per process (environment) and by level size: the default suite reaches the tile kernel
     on its small images; the marching kernels (VALU strips, both MFMA editions, 128- and 256-column strips) are run here
-    in child processes on sizes with full and partial strips, each against the oracle bit for bit."""
+    and the register-marching kernel in child processes on sizes with full and partial strips, each against the oracle bit for
+    bit."""
     import os
     import subprocess
     import sys
@@ -342,6 +345,7 @@ print("PYRAMID OK")
     {"SSRLCV_DOGX_NPX": "2", "SSRLCV_DOG_SPLIT": "1"},              # two pixels per lane
     {"SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_SIFT_SERIAL": "1"},    # marching kernels only, one stream
     {"SSRLCV_GAUSS_TILE_MAXPX": "100000000"},                       # tile kernel for every level
+    {"SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_GAUSS_RM": "63", "SSRLCV_GAUSS_RM_MINPX": "0"},  # register-marching Gaussian (with the folded 2x2 bin)
 ], ids=lambda v: "+".join(k.replace("SSRLCV_", "") + "=" + x for k, x in v.items()))
 def test_every_pyramid_schedule_is_bit_exact(variant):
     """build_dog's developer switches (who makes the 2x2 bin, how the fused DoG / extrema pass is cut into launches, row
