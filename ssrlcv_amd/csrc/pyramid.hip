@@ -2117,6 +2117,8 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
     const float* lv[svp::kGauss] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     for (int b = 0; b < svp::kGauss; ++b) lv[b] = (const float*)(ws + offGauss[b]);
     const bool split = as && sched.split == 1;
+    // (Round 3 handed the row chunks of odd levels out bottom-up, so that a level starts on the rows its predecessor wrote
+    // last and finds them in the 256 MB memory-side cache: build_dog 2.07-2.11 ms against 2.05-2.08 top-down, no gain.)
     for (int b = 0; b < svp::kGauss; ++b) {
       float* dst = (float*)(ws + offGauss[b]);
       // next octave input = 2x2 bin of the UN-normalised level 3 (src/FeatureFactory.cu:392-399): written by level 3's
