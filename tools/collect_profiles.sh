@@ -28,5 +28,5 @@ python3 tools/pmc_describe.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_S
 for k in "k_gauss_mfma2<32, 256" "k_gauss_rm<24" "k_gauss_rm<16" "k_gauss_rm<12" "k_gauss_mfma2<24, 128" "k_gauss_mfma2<16, 128" "k_gauss_mfma2<12, 128"; do python3 tools/pmcsum.py "$k" $OUT/pmc_MFMA; done > $OUT/mfma_busy.txt 2>&1 || true
 python3 tools/pmcsum.py "k_match_i8" $OUT/pmc_MATCH > $OUT/matcher_pmc.txt 2>&1 || true
 tools/_build/mfma_i8_peak >> $OUT/matcher_pmc.txt 2>&1 || true
-rm -rf $OUT/stats $OUT/serial $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ $OUT/pmc_MFMA $OUT/pmc_MATCH
+rm -rf $OUT/stats $OUT/serial $OUT/pmc_SQ $OUT/pmc_MFMA $OUT/pmc_MATCH  # (the FETCH / WRITE csv stay for re-reductions: a few MB)
 ls -la $OUT
