@@ -1494,7 +1494,9 @@ void launch_valu(ConvArgs a, int RT, uint32_t firstColumn, hipStream_t st) {
 // smallest level (pixels) it is used for.  Measured per 8192^2 level on MI355X (tools/gauss_rm_lab.hip, us, established
 // kernel -> register-marching): 13 taps 114 -> 123, 17 taps 117 -> 123, 23 taps 154 -> 126, 33 taps 169 -> 154, 47 taps
 // 207 -> 186, 65 taps 240 -> 268; per 4096^2 level 41 -> 42, 45 -> 53, 56 -> 62 at 23 / 33 / 47 taps (its blocks are 128
-// rows there, a quarter to a half of them warm-up).  Default: radii 12, 16 and 24 from 2^25 pixels up.
+// rows there, a quarter to a half of them warm-up) -- but inside build_dog, where octave 1 runs beside the DoG / extrema pass
+// of octave 0, the stage is 10-20 us shorter with them than without (median of 30, three alternations: 1.766-1.783 against
+// 1.787-1.797 ms).  Default: radii 12, 16 and 24 from 2^24 pixels up.
 // SSRLCV_GAUSS_RM=<mask>, SSRLCV_GAUSS_RM_MINPX=<pixels>, SSRLCV_GAUSS_RM_ROWS=<rows per block> override; lab drivers
 // overwrite them in place.
 int& rm_mask() {
@@ -1502,7 +1504,7 @@ int& rm_mask() {
   return m;
 }
 size_t& rm_min_px() {
-  static size_t v = getenv("SSRLCV_GAUSS_RM_MINPX") ? (size_t)atoll(getenv("SSRLCV_GAUSS_RM_MINPX")) : ((size_t)1 << 25);
+  static size_t v = getenv("SSRLCV_GAUSS_RM_MINPX") ? (size_t)atoll(getenv("SSRLCV_GAUSS_RM_MINPX")) : ((size_t)1 << 24);
   return v;
 }
 int& rm_rows() {
