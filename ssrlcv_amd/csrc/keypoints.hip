@@ -317,6 +317,22 @@ struct PolarJobs {  // the four octaves' tables in one launch: octave o owns the
   uint32_t start[svp::kOctaves + 1];
   uint32_t tilesX[svp::kOctaves];
 };
+// k_polar streams: it reads four Gaussian levels once and writes 2.2 GB of tables that no cache holds until the sampling
+// kernels gather them -- non-temporal loads and stores (describe 3.06-3.09 -> 2.95-3.04 ms per 4096^2 image; the stores
+// alone 2.99-3.02).  The same hint on the Gaussian kernels' level stores gained 10-18 us per level alone and nothing
+// inside build_dog: a plainly stored 268 MB level is still largely in the 256 MB memory-side cache when the next level
+// reads it.  -DSSRLCV_NT_STORES=0 builds the plain form (A/B).
+#ifndef SSRLCV_NT_STORES
+#define SSRLCV_NT_STORES 1
+#endif
+typedef float f32x2p __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float polar_ld(const float* p) {
+#if SSRLCV_NT_STORES
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
 __global__ __launch_bounds__(256) void k_polar(PolarJobs jobs) {
   __shared__ float s_n[kPolRows][256 + 2];  // column c of the tile at [.][c + 1]; [.][0] / [.][257] = columns x0 - 1 / x0 + 256
   int o = 0;
@@ -354,7 +370,7 @@ __global__ __launch_bounds__(256) void k_polar(PolarJobs jobs) {
     const sv::Divisor rg = sv::make_divisor(L.lvlMinMax[3] - mn);
     const float* __restrict__ g = L.lvl[1];
 #pragma unroll
-    for (int j = 0; j < kPolRows + 2; ++j) nlo[j] = sv::div_by(g[rowOff[j]] - mn, rg);
+    for (int j = 0; j < kPolRows + 2; ++j) nlo[j] = sv::div_by(polar_ld(g + rowOff[j]) - mn, rg);
     if (haloRole) nloH = sv::div_by(g[haloOff] - mn, rg);
   }
   // LDS columns of the two horizontal taps: x - 1 / x + 1, at the image border x / x + 2 resp. x - 2 / x
@@ -370,7 +386,7 @@ __global__ __launch_bounds__(256) void k_polar(PolarJobs jobs) {
     float v[kPolRows + 2];
 #pragma unroll
     for (int j = 0; j < kPolRows + 2; ++j) {
-      const float nhi = sv::div_by(g[rowOff[j]] - mn, rg);
+      const float nhi = sv::div_by(polar_ld(g + rowOff[j]) - mn, rg);
       v[j] = sv::div_by((nhi - nlo[j]) - dmn, drg);  // the twice-normalised DoG value
       nlo[j] = nhi;
     }
@@ -403,7 +419,11 @@ __global__ __launch_bounds__(256) void k_polar(PolarJobs jobs) {
         float2 r;
         r.x = sqrtf((g2.x * g2.x) + (g2.y * g2.y));
         r.y = sv_atan2f(g2.y, g2.x);
+#if SSRLCV_NT_STORES
+        __builtin_nontemporal_store(f32x2p{r.x, r.y}, reinterpret_cast<f32x2p*>(o + (size_t)i * W));  // 2.2 GB per image, gathered later
+#else
         o[(size_t)i * W] = r;
+#endif
       }
     }
   }
