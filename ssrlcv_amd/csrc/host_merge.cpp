@@ -261,6 +261,11 @@ int ssrlcv_merge_matches_host_mode(uint32_t numImages, const uint32_t* numFeatur
         outcome[f] = (uint8_t)o;
         commit(L, a, o);
       }
+      if (timing) {
+        long long nd = 0, ns = 0;
+        for (long long f = 0; f < nf; ++f) { nd += dirty[f]; ns += outcome[f] != kSkip; }
+        std::fprintf(stderr, "merge image %u: %lld seeds with a list, %lld of them share a list with another seed\n", i, ns, nd);
+      }
       // 5. stitch in feature order
       mmOff[0] = memOff[0] = 0;
       for (long long f = 0; f < nf; ++f) {
