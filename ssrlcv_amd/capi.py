@@ -214,6 +214,29 @@ def keypoints_from_members(members_d, n, feature_tensors):
     return out
 
 
+def merge_matches_device(num_features, pair_counts, pairs_d, workspace=None):
+    """Device merge of the validated uint2_pair arrays of all image pairs (concatenated in pair order, on the device) ->
+    (MultiMatch bytes, member bytes, numMatches, numMembers, rounds).  One small D2H copy of the two counts."""
+    V = len(num_features)
+    nf = (c_u32 * V)(*[int(x) for x in num_features])
+    pc = (c_u32 * max(len(pair_counts), 1))(*[int(x) for x in pair_counts])
+    total = int(sum(int(x) for x in pair_counts))
+    LIB.ssrlcv_hip_merge_workspace_bytes.restype = ctypes.c_size_t
+    need = int(LIB.ssrlcv_hip_merge_workspace_bytes(c_u32(V), nf, c_u32(total)))
+    if need == 0:
+        raise ValueError("ssrlcv_hip_merge_matches: 2..32 images")
+    if workspace is None or workspace.numel() < need:
+        workspace = dev_bytes(need)
+    mm = dev_bytes(8 * max(total, 1))
+    mem = dev_bytes(8 * 2 * max(total, 1))
+    counts = torch.zeros(2, dtype=torch.int32, device="cuda")
+    rounds = c_u32(0)
+    check(LIB.ssrlcv_hip_merge_matches(c_u32(V), nf, c_u32(len(pair_counts)), pc, ptr(pairs_d) if total else None, ptr(workspace),
+                                       c_sz(workspace.numel()), ptr(mm), ptr(mem), ptr(counts), ctypes.byref(rounds), stream_ptr()))
+    n_mm, n_mem = [int(x) for x in counts.cpu().tolist()]
+    return mm[: 8 * n_mm], mem[: 8 * n_mem], n_mm, n_mem, int(rounds.value), workspace
+
+
 def matchset_from_matches(in_kind, matches_d, n, want_max=False):
     """Device M7: (KeyPoint[2n] bytes, MultiMatch[n] bytes, max distance or None) from a validated DMatch / Match array."""
     kp = dev_bytes(32 * n)

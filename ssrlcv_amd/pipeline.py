@@ -16,6 +16,7 @@ With world size 1 (no process group) every exchange is the identity.  Python her
 torch.distributed); all compute is libssrlcv_hip.so.  A `Workspace` keeps the per-rank plans, matcher workspaces and
 seed descriptors between calls: creating and freeing them per pair / per image was a third of a step.
 """
+import os
 import time
 
 import numpy as np
@@ -174,26 +175,48 @@ def exchange_pairs(local, num_pairs, owners=None):
     return sd.exchange_keyed(local, num_pairs, owner_fn)
 
 
+def _pinned_copy(t_d, nbytes, slot):
+    """D2H through a pinned staging buffer kept between calls (pageable, 16 MB took 5.6 ms) -> uint8 numpy view."""
+    stages = build_match_set.__dict__.setdefault("_stages", {})
+    if slot not in stages or stages[slot].numel() < nbytes:
+        stages[slot] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, pin_memory=True)
+    stage = stages[slot][:nbytes]
+    stage.copy_(t_d[:nbytes])
+    return stage.numpy()
+
+
 def build_match_set(features, pair_tensors, dev=None):
-    """Replicated host merge -> (MultiMatch numpy, KeyPoint numpy).  The KeyPoint table (image, location of every member,
-    src/MatchFactory.cu:1007-1020) is gathered on the device; `dev` (a dict) receives the device copies so that the
-    triangulation does not upload them again."""
+    """Replicated merge -> (MultiMatch numpy, KeyPoint numpy).  The merge (src/MatchFactory.cu:943-1020) and the KeyPoint
+    table (image, location of every member, :1007-1020) are built on the device (csrc/merge.hip, every rank from the same
+    all-gathered pairs: deterministic); `dev` (a dict) receives the device copies so that the triangulation does not upload
+    them again.  SSRLCV_MERGE_HOST=1 (or more than 32 images) takes the host merge (csrc/host_merge.cpp) instead."""
     num_features = [f.numel() // FEATURE_BYTES for f in features]
-    mm, mem = sd.merge_matches(num_features, pair_tensors)
-    kp = np.zeros(len(mem), KEYPOINT)
-    if len(mem):
-        mem_d = capi.to_dev(np.ascontiguousarray(mem, np.uint32))
-        kp_d = capi.keypoints_from_members(mem_d, len(mem), features)
-        # D2H through a pinned staging buffer (16 B per member: 16 MB for four 4096^2 views; pageable it took 5.6 ms)
-        nbytes = 16 * len(mem)
-        if getattr(build_match_set, "_stage", None) is None or build_match_set._stage.numel() < nbytes:
-            build_match_set._stage = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, pin_memory=True)
-        stage = build_match_set._stage[:nbytes]
-        stage.copy_(kp_d[:nbytes])
-        kp = stage.numpy().view(KEYPOINT).copy()
+    counts = [t.numel() // 16 for t in pair_tensors]
+    if os.environ.get("SSRLCV_MERGE_HOST") or len(features) > 32:
+        mm, mem = sd.merge_matches(num_features, pair_tensors)
+        kp = np.zeros(len(mem), KEYPOINT)
+        if len(mem):
+            mem_d = capi.to_dev(np.ascontiguousarray(mem, np.uint32))
+            kp_d = capi.keypoints_from_members(mem_d, len(mem), features)
+            kp = _pinned_copy(kp_d, 16 * len(mem), "kp").view(KEYPOINT).copy()
+            kp["pad"] = 0
+            if dev is not None:
+                dev["keypoints"] = kp_d
+        return mm, kp
+    live = [t.reshape(-1) for t in pair_tensors if t.numel()]
+    pairs_d = torch.cat(live) if live else torch.zeros(16, dtype=torch.uint8, device="cuda")
+    mm_d, mem_d, n_mm, n_mem, rounds, build_match_set._ws = capi.merge_matches_device(
+        num_features, counts, pairs_d, getattr(build_match_set, "_ws", None))
+    mm = np.zeros(0, MULTIMATCH)
+    kp = np.zeros(0, KEYPOINT)
+    if n_mem:
+        kp_d = capi.keypoints_from_members(mem_d, n_mem, features)
+        mm = _pinned_copy(mm_d, 8 * n_mm, "mm").view(MULTIMATCH).copy()
+        kp = _pinned_copy(kp_d, 16 * n_mem, "kp").view(KEYPOINT).copy()
         kp["pad"] = 0
         if dev is not None:
             dev["keypoints"] = kp_d
+            dev["matches"] = mm_d
     return mm, kp
 
 
@@ -203,16 +226,16 @@ def triangulate(mm, kp, cameras, nview, pushbroom=None, dev=None):
     left by build_match_set."""
     world, rank = _world()
     lo, hi = sd.bundle_range(len(mm), world, rank)
-    sub = mm[lo:hi].copy()
-    n = len(sub)
+    n = hi - lo
     pts = torch.zeros(0, dtype=torch.float32, device="cuda")
     if n:
         kp_d = dev["keypoints"] if dev and "keypoints" in dev else capi.to_dev(kp)
+        sub_d = dev["matches"][8 * lo: 8 * hi] if dev and "matches" in dev else capi.to_dev(mm[lo:hi].copy())
         if pushbroom is not None:
-            b_d, l_d = capi.generate_pushbroom_bundles(capi.to_dev(sub), kp_d, n, capi.to_dev(pushbroom),
+            b_d, l_d = capi.generate_pushbroom_bundles(sub_d, kp_d, n, capi.to_dev(pushbroom),
                                                        len(pushbroom), len(kp))
         else:
-            b_d, l_d = capi.generate_bundles(capi.to_dev(sub), kp_d, n, capi.to_dev(cameras), len(cameras), len(kp))
+            b_d, l_d = capi.generate_bundles(sub_d, kp_d, n, capi.to_dev(cameras), len(cameras), len(kp))
         pts, _, _ = capi.triangulate(l_d, b_d, n, nview=nview)
     if world == 1:
         return pts.view(-1, 3)
