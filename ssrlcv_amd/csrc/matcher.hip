@@ -528,7 +528,7 @@ struct Layout {
 Layout make_layout(uint32_t nq, uint32_t nt) {
   Layout L;
   // a multiple of both kernels' queries per block
-  L.nq_pad = round_up(nq ? nq : 1, lcm_u32(kQPerBlock, kQPerBlock8));
+  L.nq_pad = round_up(nq ? nq : 1, lcm_u32(kQPerBlock, lcm_u32(kQPerBlock8, kQPerBlock8Band)));
   L.nt_pad = round_up(nt ? nt : 1, 32);
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) / 256 * 256; return r; };
@@ -607,14 +607,15 @@ int run_match(const ssrlcv_sift_feature* query, uint32_t nq, const ssrlcv_sift_f
     hipLaunchKernelGGL(k_group_boxes, dim3((numGroups + 255) / 256), dim3(256), 0, st, tileBox, numTiles, numGroups,
                        groupBox);
     // every wave walks all groups (most are rejected by one box test); target splits only while the grid is small
+    const uint32_t qbBand = useF16 ? qblocks : L.nq_pad / kQPerBlock8Band;
     uint32_t splits = 1;
-    while (qblocks * splits < 512 && splits * 2 <= numGroups) splits *= 2;
+    while (qbBand * splits < 512 && splits * 2 <= numGroups) splits *= 2;
     uint32_t tilesPerSplit = ((numGroups + splits - 1) / splits) * 32;
     if (useF16)
       hipLaunchKernelGGL(k_match<true>, dim3(qblocks, splits), dim3(256), 0, st, pq, pt, nqv, lt, geom, nq, nt,
                          tilesPerSplit, mode, eps, absThreshold, keys, permT, tileBox, groupBox);
     else
-      hipLaunchKernelGGL(k_match_i8<true>, dim3(qblocks, splits), dim3(256), 0, st, (const uint8_t*)pq, (const uint8_t*)pt,
+      hipLaunchKernelGGL((k_match_i8<true, kQT8Band>), dim3(qbBand, splits), dim3(256), 0, st, (const uint8_t*)pq, (const uint8_t*)pt,
                          (const int*)nqv, ntn, lt, geom, nq, nt, tilesPerSplit, mode, eps, absThreshold, keys, permT,
                          tileBox, groupBox);
   } else {
@@ -627,7 +628,7 @@ int run_match(const ssrlcv_sift_feature* query, uint32_t nq, const ssrlcv_sift_f
                          tilesPerSplit, mode, eps, absThreshold, keys, (const uint32_t*)nullptr, (const Box*)nullptr,
                          (const Box*)nullptr);
     else
-      hipLaunchKernelGGL(k_match_i8<false>, dim3(qblocks, splits), dim3(256), 0, st, (const uint8_t*)pq, (const uint8_t*)pt,
+      hipLaunchKernelGGL((k_match_i8<false, kQT8Brute>), dim3(qblocks, splits), dim3(256), 0, st, (const uint8_t*)pq, (const uint8_t*)pt,
                          (const int*)nqv, ntn, lt, geom, nq, nt, tilesPerSplit, mode, eps, absThreshold, keys,
                          (const uint32_t*)nullptr, (const Box*)nullptr, (const Box*)nullptr);
   }

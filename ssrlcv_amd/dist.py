@@ -5,9 +5,9 @@ Units are independent -- SIFT per image, matching per ordered pair (i < j), tria
 collectives are the two exchanges the flow really has:
 
   exchange 1  all-gather of the per-image feature arrays (F x 152 B), so every rank holds both sides of its pairs;
-  exchange 2  all-gather of the per-pair validated `uint2_pair` arrays (16 B per match) before the host merge
+  exchange 2  all-gather of the per-pair validated `uint2_pair` arrays (16 B per match) before the merge
               (MatchFactory::generateMatchesExhaustive, src/MatchFactory.cu:943-1020), which then runs replicated and
-              deterministic on every rank (ssrlcv_merge_matches_host).
+              deterministic on every rank (ssrlcv_hip_merge_matches on the device; merge_matches below is the host form).
 
 Arrays have different lengths per rank, so each exchange is one small size collective (with a single device-to-host
 copy of the size vector) followed by one all-gather into a flat buffer padded to the largest rank (payloads are tens

@@ -6,7 +6,7 @@ sweep of doBundleAdjust) with the sharding of ssrlcv_amd/dist.py:
   stage A   SIFT per image on its owner rank                         exchange 1: all-gather of the feature arrays
   stage B   pair matching on the pair's owner rank (pairs balanced   exchange 2: all-gather of the uint2_pair arrays
             by nq * nt, all queued, one synchronisation)
-  merge     generateMatchesExhaustive's host merge, replicated (deterministic, on all host cores); KeyPoint table
+  merge     generateMatchesExhaustive's merge on the device, replicated (deterministic: csrc/merge.hip); KeyPoint table
             gathered on the device
   stage C   bundle-range triangulation                                exchange 3: all-gather of the cloud
   BA sweep  the K finite-difference evaluations of f(cameras) over this rank's bundle range of the first image pair
