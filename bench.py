@@ -287,7 +287,7 @@ def run_nview(args, torch, dist, capi, world, rank, dev, views, size, steps, war
             "value": views * size * size * steps / dt / 1e6, "unit": "Mpix/s", "n_gpus": world, "steps": steps,
             "ms_per_step": dt / steps * 1e3, "scaling": "strong",
             "workload": "%d-view %dx%d scene, image/pair shard over %d GPU(s): all-gather of features, pairs balanced by "
-                        "nq*nt, all-gather of uint2_pair arrays, replicated host merge (all host cores), bundle-range "
+                        "nq*nt, all-gather of uint2_pair arrays, replicated merge on the device (ssrlcv_hip_merge_matches), bundle-range "
                         "triangulation + all-gather of the cloud, 612-point BA error sweep + all-reduce" % (views, size, size, world),
             "stage_ms_per_step_rank0": {k: v / steps * 1e3 for k, v in ws.times.items()},
             "multi_matches": int(len(res["matches"])), "points": int(res["points"].shape[0]),
