@@ -813,6 +813,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8), amdg
   const float inv45 = 1.0f / rad45;
   const uint32_t totalUnits = tab->total;
   // one work unit = one key point; units walk the octaves' blur segments from the largest windows to the smallest
+  // (Round 3 re-tried an XCD-contiguous unit order now that the kernel is gather-bound -- the blocks of residue class y
+  // mod 8 of a range take the y-th eighth of its key points, so that an XCD's L2 sees one band of the tables instead of the
+  // hundreds of rows the ~8000 key points in flight span: 1.19-1.23 ms either way.)
   for (uint32_t unit = blockIdx.x * 4 + wave; unit < totalUnits; unit += gridDim.x * 4) {
     const int range = range_of(tab, unit);
     const int octave = range & 3;
