@@ -237,15 +237,58 @@ class MatchFactory {
       logger.err << "exiting...";
       std::exit(0);
     }
-    // host merge (adjacency lists + consistency walk, :943-1005) lives in the library so that the single-GPU shell
-    // and the multi-GPU driver share one implementation
+    // the merge (adjacency lists + consistency walk, :943-1005) and the KeyPoint table (:1007-1020) live in the library,
+    // shared with the multi-GPU driver: on the device for up to 32 images (ssrlcv_hip_merge_matches: the same MatchSet as
+    // upstream's single-threaded walk, the match arrays never leave the GPU), on the host beyond (ssrlcv_merge_matches_host)
     const size_t V = images.size();
     std::vector<uint32_t> numFeatures(V), pairCounts;
-    std::vector<uint2_pair> allPairs;
     for (size_t i = 0; i < V; ++i) numFeatures[i] = (uint32_t)features[i]->size();
+    for (auto& m : matchIndices) pairCounts.push_back((uint32_t)m->size());
+    const size_t mergeBytes = ssrlcv_hip_merge_workspace_bytes((uint32_t)V, numFeatures.data(), (uint32_t)totalMatches);
+    if (mergeBytes != 0 && totalMatches <= 0x7fffffffull) {
+      std::vector<MemoryState> origin(V);
+      std::vector<const ssrlcv_sift_feature*> featPtr(V);
+      for (size_t i = 0; i < V; ++i) {
+        origin[i] = features[i]->getMemoryState();
+        if (origin[i] != gpu && origin[i] != both) features[i]->setMemoryState(gpu);
+        else if (origin[i] == both && features[i]->getFore() == cpu) features[i]->transferMemoryTo(gpu);
+        featPtr[i] = reinterpret_cast<const ssrlcv_sift_feature*>(features[i]->device.get());
+      }
+      ptr::device<uint2_pair> allPairs((long)totalMatches);
+      size_t at = 0;
+      for (auto& m : matchIndices) {
+        if (m->size() == 0) continue;
+        if (m->getMemoryState() != gpu && m->getMemoryState() != both) m->setMemoryState(gpu);
+        HipSafeCall(ssrlcv_hip_memcpy(allPairs.get() + at, m->device.get(), m->size() * sizeof(uint2_pair), 2));
+        at += m->size();
+      }
+      ptr::device<unsigned char> mergeWs((long)mergeBytes);
+      ptr::device<MultiMatch> mm_d((long)totalMatches);
+      ptr::device<uint2> mem_d((long)(2 * totalMatches));
+      ptr::device<uint32_t> counts_d(2);
+      HipSafeCall(ssrlcv_hip_merge_matches((uint32_t)V, numFeatures.data(), (uint32_t)pairCounts.size(), pairCounts.data(),
+                                           reinterpret_cast<const ssrlcv_uint2_pair*>(allPairs.get()), mergeWs.get(), mergeBytes,
+                                           reinterpret_cast<ssrlcv_multimatch*>(mm_d.get()),
+                                           reinterpret_cast<ssrlcv_uint2*>(mem_d.get()), counts_d.get(), nullptr, nullptr));
+      uint32_t counts[2] = {0, 0};
+      HipSafeCall(ssrlcv_hip_memcpy(counts, counts_d.get(), sizeof counts, 1));
+      const uint32_t nmm = counts[0], nmem = counts[1];
+      logger.info.printf("total matches found in set = %d", (int)nmm);
+      matchSet.matches = ptr::value<Unity<MultiMatch>>(nullptr, (unsigned long)nmm, cpu);
+      if (nmm) HipSafeCall(ssrlcv_hip_memcpy(matchSet.matches->host.get(), mm_d.get(), sizeof(MultiMatch) * nmm, 1));
+      matchSet.keyPoints = ptr::value<Unity<KeyPoint>>(nullptr, (unsigned long)nmem, gpu);
+      if (nmem)
+        HipSafeCall(ssrlcv_hip_keypoints_from_members(reinterpret_cast<const ssrlcv_uint2*>(mem_d.get()), nmem, featPtr.data(),
+                                                      numFeatures.data(), (uint32_t)V,
+                                                      reinterpret_cast<ssrlcv_keypoint*>(matchSet.keyPoints->device.get()), nullptr));
+      HipCheckError();
+      for (size_t i = 0; i < V; ++i)
+        if (origin[i] != gpu && origin[i] != both) features[i]->setMemoryState(origin[i]);
+      return matchSet;
+    }
+    std::vector<uint2_pair> allPairs;
     for (auto& m : matchIndices) {
       if (m->getMemoryState() != cpu) m->setMemoryState(cpu);
-      pairCounts.push_back((uint32_t)m->size());
       allPairs.insert(allPairs.end(), m->host.get(), m->host.get() + m->size());
     }
     ssrlcv_multimatch* mm_raw = nullptr;
