@@ -331,7 +331,7 @@ class SiftPlan:
         self.num_features = torch.zeros(1, dtype=torch.int32, device="cuda") if alloc else None
 
     def __del__(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and LIB is not None:  # (module globals are gone at interpreter shutdown)
             LIB.ssrlcv_sift_plan_destroy(self.handle)
             self.handle = None
 
