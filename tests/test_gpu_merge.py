@@ -23,7 +23,7 @@ def device_merge(capi, nf, blocks):
 
 @pytest.mark.parametrize("V,n,density,spread", [(3, 2000, 0.5, 2000), (4, 3000, 0.6, 3000), (4, 5000, 0.7, 40),
                                                  (5, 1500, 0.9, 1500), (6, 800, 0.8, 25), (8, 400, 0.5, 400), (3, 50000, 0.4, 50000),
-                                                 (4, 200000, 0.6, 200000), (12, 300, 0.7, 60)])
+                                                 (4, 200000, 0.6, 200000), (12, 300, 0.7, 60), (32, 120, 0.4, 50)])
 def test_device_merge_equals_the_sequential_walk(capi, V, n, density, spread):
     from ssrlcv_amd import _lib
     lib = _lib.load()
