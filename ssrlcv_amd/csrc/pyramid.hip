@@ -2049,15 +2049,17 @@ namespace {
 // min / max of 3 and 4) follows after level 5 and ORs its bits into the flag bytes.  With the materialising DoG kernel of
 // round 2 (HBM bound) the split paid on the 2^26-pixel octave; the fused pass is VALU bound and reads levels 1..3 twice in
 // the split form: measured on a 4096^2 image 2.14 ms split on octave 0 against 1.96 ms whole, so the default is whole.
-// SSRLCV_DOG_SPLIT=1: split on every octave (0: never).  SSRLCV_DOGX_WAVES: waves per launch (default 8192).
+// SSRLCV_DOG_SPLIT=1: split on every octave (0: never).  SSRLCV_DOGX_WAVES: waves per launch (default 14336: build_dog of a
+// 4096^2 image, median of 30, two sweeps: 8192 waves 1.760-1.776 ms, 10240 1.73-1.75, 12288 1.70-1.71, 14336 1.698-1.699,
+// 16384 1.70-1.71, 20480 1.72-1.73, 24576 1.71-1.72).
 struct DogSchedule {
   int split;  // 0 never (default), 1 always
   unsigned waves;
   DogSchedule() {
     split = 0;
     if (const char* e = getenv("SSRLCV_DOG_SPLIT")) split = atoi(e) != 0 ? 1 : 0;
-    waves = 8192;
-    if (const char* e = getenv("SSRLCV_DOGX_WAVES")) waves = (unsigned)atoi(e) > 0 ? (unsigned)atoi(e) : 8192;
+    waves = 14336;
+    if (const char* e = getenv("SSRLCV_DOGX_WAVES")) waves = (unsigned)atoi(e) > 0 ? (unsigned)atoi(e) : 14336;
   }
 };
 }  // namespace
