@@ -12,8 +12,8 @@
  * and say so.
  *
  * Pinning status (see DESIGN.md "Oracle"):
- *   P1+P2 (bundles + two-view triangulation)  pinned by Pipeline2View/0_* fixtures
- *   P3   (N-view triangulation)               pinned by Pipeline3View/0_* fixtures (ill-conditioned, ~1e-3 km)
+ *   P1+P2 (bundles + two-view triangulation)  pinned by Pipeline2View/{0,1}_* fixtures: all 13 534 / 13 308 points BIT-EQUAL (round 4)
+ *   P3   (N-view triangulation)               pinned by Pipeline3View/{0,1}_* fixtures: all 21 177 / 21 099 points BIT-EQUAL (round 4)
  *   M6/M7 (match-set assembly)                pinned structurally by the MultiMatch/KeyPoint fixtures
  *   filters                                   pinned by Pipeline{2,3}View/1_* fixtures
  *   S1-S14, M1-M4                             pinned jointly (consistency) by pixels fixtures + seed features + 0_KeyPoint fixtures

@@ -105,7 +105,9 @@ __device__ __forceinline__ float two_view_point(const ssrlcv_line& L1, const ssr
   f3 s1 = add(L1.pnt, lscale(numer1 / denom1, L1.vec));
   f3 s2 = add(L2.pnt, lscale(numer2 / denom2, L2.vec));
   point = divs(add(s1, s2), 2.0f);
-  return (s1.x - s2.x) * (s1.x - s2.x) + (s1.y - s2.y) * (s1.y - s2.y) + (s1.z - s2.z) * (s1.z - s2.z);
+  // :4532, inside the kernel's own body upstream: fused by the rule of device_math.h
+  const float dx = s1.x - s2.x, dy = s1.y - s2.y, dz = s1.z - s2.z;
+  return __builtin_fmaf(dz, dz, nv_pp(dx, dx, dy, dy));
 }
 
 __global__ __launch_bounds__(kBlock) void k_triangulate2(const ssrlcv_line* __restrict__ lines,

@@ -112,7 +112,7 @@ def test_reference_stage_flow_through_class_api(tmp_path, views):
     diff = pts - gv["points0"]
     rms = float(np.sqrt((diff.astype(np.float64) ** 2).sum(1).mean()))
     print("class API, %d views: cloud rms vs golden %.3e km" % (views, rms))
-    assert rms <= (1e-4 if views == 2 else 2.5e-3)  # float tolerance north_star states (N-view: S is near-singular)
+    assert rms == 0.0  # every point of the reference cloud bit for bit (round 4)
     if views == 2:
         adj, _, _ = read_uty(os.path.join(d, "101_6float3.uty"), np.dtype(("<f4", (3,))))
         # BundleAdjustTwoView is an identity on the cloud upstream (2_6float3.uty == 1_6float3.uty)
@@ -197,7 +197,7 @@ def test_filter_stage_through_class_api_matches_fixture(tmp_path, views):
     assert np.array_equal(kp["loc"], gv["kp1"]["loc"]) and np.array_equal(mm["index"], gv["mm1"]["index"])
     diff = pts - gv["points1"]
     rms = float(np.sqrt((diff.astype(np.float64) ** 2).sum(1).mean()))
-    assert rms <= (1e-4 if views == 2 else 2.5e-3), rms
+    assert rms == 0.0, rms
 
 
 @pytest.mark.gpu
