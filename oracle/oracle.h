@@ -15,7 +15,7 @@
  *   P1+P2 (bundles + two-view triangulation)  pinned by Pipeline2View/{0,1}_* fixtures: all 13 534 / 13 308 points BIT-EQUAL (round 4)
  *   P3   (N-view triangulation)               pinned by Pipeline3View/{0,1}_* fixtures: all 21 177 / 21 099 points BIT-EQUAL (round 4)
  *   M6/M7 (match-set assembly)                pinned structurally by the MultiMatch/KeyPoint fixtures
- *   filters                                   pinned by Pipeline{2,3}View/1_* fixtures
+ *   filters                                   pinned by Pipeline{2,3}View/1_* fixtures (13 534 -> 13 308, 21 177 -> 21 099, every key point)
  *   S1-S14, M1-M4                             pinned jointly (consistency) by pixels fixtures + seed features + 0_KeyPoint fixtures
  *   P1c (pushbroom), P5 (SVD pseudo-inverse)  PARITY UNPINNED (no reference fixture reaches them)
  *   F-matrix prefilter (match mode 2), Match-output ratio rules, pose LM terms (oracle_pose.c)
@@ -110,6 +110,11 @@ float oracle_two_view_triangulate(uint32_t n, const o_line* lines, o_bundle* bun
 /* src/PointCloudFactory.cu:4880-5293 computeNViewTriangulate family */
 float oracle_n_view_triangulate(uint32_t n, const o_line* lines, o_bundle* bundles, o_float3* points,
                                 float* errors, const float* cutoff);
+/* filters between triangulation and BA (src/PointCloudFactory.cu:3070-3275, 3500-3644), their host halves:
+ * the statistical cutoff and the rebuild of the MatchSet without the flagged bundles */
+float oracle_sample_cutoff(const float* errors, uint32_t n, uint32_t sampleJump, float sigma);
+void oracle_filter_matchset(uint32_t numBundles, const o_bundle* bundles, const o_keypoint* keyPoints, o_multimatch* matchesOut,
+                            o_keypoint* keyPointsOut, uint32_t counts[3]);
 /* src/Image.cu:445-472 Image::setFloatVector (6 params: pos xyz, rot xyz) then generateBundle + void two-view error:
  * the evaluation BundleAdjustTwoView repeats 612x per iteration (src/PointCloudFactory.cu:1059-1504). */
 float oracle_ba_eval(uint32_t numBundles, const o_multimatch* matches, const o_keypoint* keyPoints,

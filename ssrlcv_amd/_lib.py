@@ -41,6 +41,7 @@ EXPORTED = [
     "ssrlcv_hip_match_u8x128", "ssrlcv_hip_compact_matches", "ssrlcv_hip_compact_matches_async", "ssrlcv_hip_keypoints_from_members",
     "ssrlcv_hip_matchset_from_matches", "ssrlcv_merge_matches_host", "ssrlcv_merge_matches_host_mode", "ssrlcv_host_free",
     "ssrlcv_hip_merge_workspace_bytes", "ssrlcv_hip_merge_matches",
+    "ssrlcv_hip_error_sample_cutoff", "ssrlcv_hip_filter_workspace_bytes", "ssrlcv_hip_filter_matchset",
     "ssrlcv_hip_convert_to_bw", "ssrlcv_hip_u8_to_f32", "ssrlcv_hip_upsample2x", "ssrlcv_hip_upsample2x_u8", "ssrlcv_hip_bin2x",
     "ssrlcv_gauss_kernel_host", "ssrlcv_hip_gauss_sep_conv", "ssrlcv_hip_minmax", "ssrlcv_hip_normalize",
     "ssrlcv_hip_dog_normalised_sub",

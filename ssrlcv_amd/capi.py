@@ -22,6 +22,10 @@ class SsrlcvError(RuntimeError):
     pass
 
 
+class MalformedPairList(SsrlcvError):
+    """the device merge's input status word: an index out of range or a query matched twice in one pair"""
+
+
 def check(rc):
     if rc != 0:
         raise SsrlcvError("ssrlcv_hip status %d: %s" % (rc, LIB.ssrlcv_hip_status_string(int(rc)).decode()))
@@ -98,7 +102,8 @@ def triangulate(lines_d, bundles_d, n, nview=False, want_points=True, want_error
                 no_error_variant=False):
     points = torch.zeros(max(n, 1) * 3, dtype=torch.float32, device="cuda") if want_points else None
     errors = torch.zeros(max(n, 1), dtype=torch.float32, device="cuda") if want_errors else None
-    cut = torch.tensor([cutoff], dtype=torch.float32, device="cuda") if cutoff is not None else None
+    # cutoff: a float, or a 1-element float32 CUDA tensor (a cutoff computed on the device: error_sample_cutoff)
+    cut = None if cutoff is None else (cutoff if torch.is_tensor(cutoff) else torch.tensor([cutoff], dtype=torch.float32, device="cuda"))
     esum = torch.zeros(1, dtype=torch.float32, device="cuda")
     if nview:
         check(LIB.ssrlcv_hip_triangulateN(ptr(lines_d), ptr(bundles_d), c_u32(n), ptr(points), ptr(errors), ptr(cut),
@@ -107,6 +112,27 @@ def triangulate(lines_d, bundles_d, n, nview=False, want_points=True, want_error
         check(LIB.ssrlcv_hip_triangulate2(ptr(lines_d), ptr(bundles_d), c_u32(n), ptr(points), ptr(errors), ptr(cut),
                                           ptr(esum), stream_ptr()))
     return points, errors, esum
+
+
+def error_sample_cutoff(errors_d, n, sample_jump, sigma):
+    """deterministicStatisticalFilter's cutoff (sigma x std of every sample_jump-th error, sequential float sums) on the
+    device -> 1-element float32 CUDA tensor."""
+    cut = torch.zeros(1, dtype=torch.float32, device="cuda")
+    check(LIB.ssrlcv_hip_error_sample_cutoff(ptr(errors_d), c_u32(n), c_u32(sample_jump), c_f32(sigma), ptr(cut), stream_ptr()))
+    return cut
+
+
+def filter_matchset(bundles_d, keypoints_d, num_bundles, num_keypoints):
+    """The MatchSet without the bundles flagged invalid -> (MultiMatch bytes, KeyPoint bytes, counts tensor {bundles kept,
+    key points kept, key points in}); asynchronous."""
+    LIB.ssrlcv_hip_filter_workspace_bytes.restype = ctypes.c_size_t
+    ws = dev_bytes(int(LIB.ssrlcv_hip_filter_workspace_bytes(c_u32(num_bundles))))
+    mm = dev_bytes(8 * max(num_bundles, 1))
+    kp = dev_bytes(16 * max(num_keypoints, 1))
+    counts = torch.zeros(3, dtype=torch.int32, device="cuda")
+    check(LIB.ssrlcv_hip_filter_matchset(ptr(bundles_d), ptr(keypoints_d), c_u32(num_bundles), ptr(mm), ptr(kp), ptr(counts),
+                                         ptr(ws), c_sz(ws.numel()), stream_ptr()))
+    return mm, kp, counts
 
 
 def ba_sweep2(matches_d, keypoints_d, num_bundles, cameras_d, num_cameras, params_d, K):
@@ -229,12 +255,13 @@ def merge_matches_device(num_features, pair_counts, pairs_d, workspace=None):
         workspace = dev_bytes(need)
     mm = dev_bytes(8 * max(total, 1))
     mem = dev_bytes(8 * 2 * max(total, 1))
-    counts = torch.zeros(2, dtype=torch.int32, device="cuda")
-    rounds = c_u32(0)
+    counts = torch.zeros(4, dtype=torch.int32, device="cuda")
     check(LIB.ssrlcv_hip_merge_matches(c_u32(V), nf, c_u32(len(pair_counts)), pc, ptr(pairs_d) if total else None, ptr(workspace),
-                                       c_sz(workspace.numel()), ptr(mm), ptr(mem), ptr(counts), ctypes.byref(rounds), stream_ptr()))
-    n_mm, n_mem = [int(x) for x in counts.cpu().tolist()]
-    return mm[: 8 * n_mm], mem[: 8 * n_mem], n_mm, n_mem, int(rounds.value), workspace
+                                       c_sz(workspace.numel()), ptr(mm), ptr(mem), ptr(counts), stream_ptr()))
+    n_mm, n_mem, bad, rounds = [int(x) for x in counts.cpu().tolist()]  # the one synchronisation of the (asynchronous) call
+    if bad:
+        raise MalformedPairList("ssrlcv_hip_merge_matches: malformed pair list (status word %d)" % bad)
+    return mm[: 8 * n_mm], mem[: 8 * n_mem], n_mm, n_mem, rounds, workspace
 
 
 def matchset_from_matches(in_kind, matches_d, n, want_max=False):

@@ -653,16 +653,31 @@ struct GatherArgs {
   const ssrlcv_sift_feature* feats[kMaxGatherImages];
   uint32_t count[kMaxGatherImages];
 };
+// One launch covers the members of kMaxGatherImages consecutive images [imageBase, imageBase + kMaxGatherImages) (their
+// feature-array pointers travel in the kernel arguments); more images = more launches over the same member list.
 __global__ __launch_bounds__(256) void k_keypoints_from_members(const ssrlcv_uint2* __restrict__ mem, uint32_t n, GatherArgs a,
-                                                                uint32_t numImages, ssrlcv_keypoint* __restrict__ out) {
+                                                                uint32_t numImages, uint32_t imageBase, ssrlcv_keypoint* __restrict__ out) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const ssrlcv_uint2 m = mem[i];
-  ssrlcv_keypoint kp;
-  kp.parentId = (int)m.x;
-  kp.loc.x = kp.loc.y = 0.0f;
-  if (m.x < numImages && m.y < a.count[m.x]) kp.loc = a.feats[m.x][m.y].loc;
-  out[i] = kp;
+  const uint32_t rel = m.x - imageBase;  // wraps for images below the chunk
+  ssrlcv_float2 loc;
+  loc.x = loc.y = 0.0f;
+  if (m.x < numImages) {
+    if (rel >= (uint32_t)kMaxGatherImages) return;  // another launch's member
+    if (m.y < a.count[rel]) loc = a.feats[rel][m.y].loc;
+  } else if (imageBase != 0) {
+    return;  // a member naming no image gets its zero location from the first launch
+  }
+  // the whole 16-byte element in one store, the 4 padding bytes behind parentId as zeros: a caller that copies the array
+  // to the host gets defined bytes without a pass over it
+  static_assert(sizeof(ssrlcv_keypoint) == 16, "KeyPoint layout");
+  uint4 w;
+  w.x = m.x;
+  w.y = 0u;
+  w.z = __float_as_uint(loc.x);
+  w.w = __float_as_uint(loc.y);
+  reinterpret_cast<uint4*>(out)[i] = w;
 }
 
 // M7: the 2-view MatchSet (src/Pipeline.cu:204-223).  One thread per match; ELEM = ssrlcv_match or ssrlcv_dmatch (the
@@ -826,16 +841,19 @@ int ssrlcv_hip_compact_matches_async(int outKind, void* matches, uint32_t numMat
 int ssrlcv_hip_keypoints_from_members(const ssrlcv_uint2* members, uint32_t numMembers,
                                       const ssrlcv_sift_feature* const* features_host, const uint32_t* numFeatures_host,
                                       uint32_t numImages, ssrlcv_keypoint* keyPoints, ssrlcv_stream_t stream) {
-  if (!features_host || !numFeatures_host || numImages == 0 || numImages > (uint32_t)kMaxGatherImages) return SSRLCV_ERR_INVALID_ARG;
+  if (!features_host || !numFeatures_host || numImages == 0) return SSRLCV_ERR_INVALID_ARG;
   if (numMembers && (!members || !keyPoints)) return SSRLCV_ERR_INVALID_ARG;
   if (numMembers == 0) return SSRLCV_OK;
-  GatherArgs a;
-  for (uint32_t v = 0; v < (uint32_t)kMaxGatherImages; ++v) {
-    a.feats[v] = v < numImages ? features_host[v] : nullptr;
-    a.count[v] = v < numImages && features_host[v] ? numFeatures_host[v] : 0u;
+  for (uint32_t base = 0; base < numImages; base += (uint32_t)kMaxGatherImages) {
+    GatherArgs a;
+    for (uint32_t v = 0; v < (uint32_t)kMaxGatherImages; ++v) {
+      const uint32_t img = base + v;
+      a.feats[v] = img < numImages ? features_host[img] : nullptr;
+      a.count[v] = img < numImages && features_host[img] ? numFeatures_host[img] : 0u;
+    }
+    hipLaunchKernelGGL(k_keypoints_from_members, dim3((numMembers + 255) / 256), dim3(256), 0, (hipStream_t)stream, members,
+                       numMembers, a, numImages, base, keyPoints);
   }
-  hipLaunchKernelGGL(k_keypoints_from_members, dim3((numMembers + 255) / 256), dim3(256), 0, (hipStream_t)stream, members,
-                     numMembers, a, numImages, keyPoints);
   SSRLCV_LAUNCH_CHECK();
   return SSRLCV_OK;
 }

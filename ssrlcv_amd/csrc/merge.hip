@@ -18,12 +18,12 @@
 //             upstream appends in pair order = ascending partner image: the slot of an entry is the number of smaller
 //             partner images present, from a per-list bit mask -- no ordering between threads needed.  (Two entries of one
 //             list with the same partner image, which upstream would append twice, are refused: SSRLCV_ERR_INVALID_ARG.)
-//   output  : exclusive scans over the seeds' (accepted ? 1 : 0) and (accepted ? members : 0).
+//   output  : one pass over the seeds with two running sums, (accepted ? 1 : 0) and (accepted ? members : 0), by decoupled
+//             look-back (scan_lookback.h); the records are written from them directly.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <string.h>  // rocprim's texture_cache_iterator.hpp calls memset without including it
-#include <rocprim/rocprim.hpp>
 #include "device_math.h"
+#include "scan_lookback.h"
 #include "ssrlcv_hip.h"
 
 namespace {
@@ -125,107 +125,210 @@ __global__ __launch_bounds__(256) void k_merge_fill(Lists L, const ssrlcv_uint2_
   const uint32_t e = blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
   const ssrlcv_uint2_pair p = pairs[e];
+  const uint32_t V = L.V;
+  if (p.a.x >= V - 1 || p.b.x >= V || p.b.x <= p.a.x || p.a.y >= L.nf[p.a.x] || p.b.y >= L.nf[p.b.x]) return;  // flagged by k_merge_masks
   const uint32_t l = L.list_of(p.a.x, p.a.y);
   const uint32_t slot = (uint32_t)__popc(mask[l] & ((1u << p.b.x) - 1u));
   entries[L.start[l] + slot] = U2{p.b.x, p.b.y};
 }
 
-// ---- rounds of image i.  state[f]: 1 = unresolved
-__global__ __launch_bounds__(256) void k_merge_begin(Lists L, uint32_t i, uint8_t* __restrict__ state, uint8_t* __restrict__ outcome) {
-  const uint32_t f = blockIdx.x * 256 + threadIdx.x;
-  if (f >= L.nf[i]) return;
-  state[f] = L.len[L.list_of(i, f)] != 0;
-  outcome[f] = kSkip;
-}
-__global__ __launch_bounds__(256) void k_merge_mark(Lists L, uint32_t i, const uint8_t* __restrict__ state, uint32_t* __restrict__ minReader,
-                                                    uint32_t* __restrict__ minWriter, uint32_t* __restrict__ unresolved) {
-  const uint32_t f = blockIdx.x * 256 + threadIdx.x;
-  const bool live = f < L.nf[i] && state[f];
-  if (live) {
-    const uint32_t a = L.list_of(i, f);
-    walk(L, a, [&](uint32_t l) { atomicMin(&minReader[l], f); });
-    for_each_cleared(L, a, [&](uint32_t l) { atomicMin(&minWriter[l], f); });
+// ---- the walk of every seed image in ONE persistent launch (round 4).  Round 3 launched mark / ready / commit per round and
+// read the number of unresolved seeds back to the host after every mark (13-16 stream synchronisations per call); now
+// the rounds are phases of one kernel separated by a grid-wide barrier, and the call is asynchronous.
+//
+// The grid is sized to be co-resident (launched cooperatively: the runtime refuses a grid that is not), every block
+// passes every barrier -- the loop bounds and the `left` test are grid-uniform -- so the grid always drains.
+// Barrier = __threadfence (release: this thread's stores and atomics are visible device-wide, across the XCDs' L2s),
+// one atomicAdd per block on a monotone counter, spin until it reaches (barriers so far) x gridDim.x, __threadfence
+// (acquire: drop what this CU cached before the barrier).
+struct WalkCtl {
+  uint32_t* barrier;      // [0] groups arrived (monotone); [64 (1 + g)] arrivals of group g, each on its own 256-byte line
+  uint32_t* unresolved;   // [(V - 2) x (kMaxRounds + 2)] one slot per (image, round), zeroed before the launch
+  uint32_t* counts;       // counts[3] receives the number of rounds
+  const int* bad;         // set by k_merge_masks on malformed input: the walk is skipped
+};
+// Same-address atomics serialise at ~50 ns each on this part, so 256 blocks arriving on ONE counter cost 13 us per
+// barrier (the first version: 60 barriers = 3.7 ms for a merge whose kernels take 0.4).  Arrival is two-level: a block
+// arrives on the counter of its group (blockIdx mod kBarrierGroups, 16 arrivals each, the groups in parallel), the last
+// of a group on the global one, everybody polls the global one.  Fences: thread 0 alone releases before and acquires
+// after -- the block's other threads are ordered with it by the __syncthreads on either side, and an agent-scope
+// release / acquire writes back / invalidates the caches for the whole CU, not for one wave.
+constexpr uint32_t kBarrierGroups = 16;
+constexpr size_t kBarrierBytes = 256 * (1 + kBarrierGroups);
+__device__ __forceinline__ void grid_barrier(uint32_t* ctr, uint32_t& passed) {
+  __syncthreads();
+  ++passed;
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const uint32_t groups = gridDim.x < kBarrierGroups ? gridDim.x : kBarrierGroups;
+    const uint32_t g = blockIdx.x % kBarrierGroups;
+    const uint32_t groupSize = (gridDim.x - g + kBarrierGroups - 1) / kBarrierGroups;  // blocks with this residue
+    if (atomicAdd(ctr + 64 * (1 + g), 1u) == passed * groupSize - 1u) atomicAdd(ctr, 1u);
+    const uint32_t target = passed * groups;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    __threadfence();
   }
-  const unsigned long long b = __ballot(live);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(unresolved, (uint32_t)__popcll(b));
+  __syncthreads();
 }
-// ready: no unresolved lower seed clears what f reads, none reads what f clears (the marks of f itself are f)
-__global__ __launch_bounds__(256) void k_merge_ready(Lists L, uint32_t i, uint8_t* __restrict__ state, const uint32_t* __restrict__ minReader,
-                                                     const uint32_t* __restrict__ minWriter) {
-  const uint32_t f = blockIdx.x * 256 + threadIdx.x;
-  if (f >= L.nf[i] || !state[f]) return;
-  const uint32_t a = L.list_of(i, f);
-  bool ready = true;
-  walk(L, a, [&](uint32_t l) { ready = ready && minWriter[l] >= f; });
-  for_each_cleared(L, a, [&](uint32_t l) { ready = ready && minReader[l] >= f; });
-  if (ready) state[f] = 2;
+// state[f]: 1 = unresolved, 2 = ready this round
+__global__ __launch_bounds__(256) void k_merge_walk(Lists L, uint32_t numLists, uint8_t* __restrict__ state, uint8_t* __restrict__ outcome,
+                                                    uint32_t* __restrict__ minReader, uint32_t* __restrict__ minWriter,
+                                                    uint32_t* __restrict__ good, uint32_t* __restrict__ members, WalkCtl ctl) {
+  if (*ctl.bad) return;  // grid-uniform (written by an earlier kernel)
+  const uint32_t tid = blockIdx.x * 256 + threadIdx.x, nthreads = gridDim.x * 256;
+  uint32_t passed = 0, seedBase = 0, rounds = 0;
+  for (uint32_t i = 0; i + 2 < L.V; ++i) {
+    const uint32_t nf = L.nf[i];
+    const uint32_t later = L.base[i + 1];  // marks of lists of later images only
+    for (uint32_t f = tid; f < nf; f += nthreads) {
+      state[f] = L.len[L.list_of(i, f)] != 0;
+      outcome[f] = kSkip;
+    }
+    for (uint32_t l = later + tid; l < numLists; l += nthreads) minReader[l] = minWriter[l] = 0xffffffffu;
+    grid_barrier(ctl.barrier, passed);
+    for (uint32_t r = 0;; ++r) {
+      // mark: R(f) and W(f) of every unresolved seed on the current state
+      uint32_t* slot = ctl.unresolved + i * (kMaxRounds + 2) + (r < (uint32_t)kMaxRounds + 1 ? r : (uint32_t)kMaxRounds + 1);
+      uint32_t mine = 0;
+      for (uint32_t f = tid; f < nf; f += nthreads) {
+        if (!state[f]) continue;
+        const uint32_t a = L.list_of(i, f);
+        walk(L, a, [&](uint32_t l) { atomicMin(&minReader[l], f); });
+        for_each_cleared(L, a, [&](uint32_t l) { atomicMin(&minWriter[l], f); });
+        ++mine;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+      if ((threadIdx.x & 63) == 0 && mine) atomicAdd(slot, mine);
+      grid_barrier(ctl.barrier, passed);
+      const uint32_t left = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the same for every thread
+      if (!left) break;
+      if (r >= (uint32_t)kMaxRounds) {  // what is left after kMaxRounds, in upstream's order, by one thread
+        if (tid == 0) {
+          for (uint32_t f = 0; f < nf; ++f) {
+            if (!state[f]) continue;
+            const uint32_t a = L.list_of(i, f);
+            const Outcome o = walk(L, a, [](uint32_t) {});
+            outcome[f] = o;
+            commit(L, a, o);
+            state[f] = 0;
+          }
+        }
+        grid_barrier(ctl.barrier, passed);
+        break;
+      }
+      // ready: no unresolved lower seed clears what f reads, none reads what f clears (the marks of f itself are f)
+      for (uint32_t f = tid; f < nf; f += nthreads) {
+        if (!state[f]) continue;
+        const uint32_t a = L.list_of(i, f);
+        bool ready = true;
+        walk(L, a, [&](uint32_t l) { ready = ready && minWriter[l] >= f; });
+        for_each_cleared(L, a, [&](uint32_t l) { ready = ready && minReader[l] >= f; });
+        if (ready) state[f] = 2;
+      }
+      grid_barrier(ctl.barrier, passed);
+      // commit the ready seeds (independent of each other and of every earlier unresolved seed), reset the marks
+      for (uint32_t f = tid; f < nf; f += nthreads) {
+        if (state[f] != 2) continue;
+        const uint32_t a = L.list_of(i, f);
+        const Outcome o = walk(L, a, [](uint32_t) {});
+        outcome[f] = o;
+        commit(L, a, o);
+        state[f] = 0;
+      }
+      for (uint32_t l = later + tid; l < numLists; l += nthreads) minReader[l] = minWriter[l] = 0xffffffffu;
+      ++rounds;
+      grid_barrier(ctl.barrier, passed);
+    }
+    // tally: an accepted seed's own list is final (only seeds of earlier images clear it)
+    for (uint32_t f = tid; f < nf; f += nthreads) {
+      const bool g = outcome[f] == kGood;
+      good[seedBase + f] = g ? 1u : 0u;
+      members[seedBase + f] = g ? L.len[L.list_of(i, f)] + 1u : 0u;
+    }
+    seedBase += nf;
+    if (i + 3 < L.V) grid_barrier(ctl.barrier, passed);  // the next image reuses state / outcome
+  }
+  if (tid == 0) ctl.counts[3] = rounds;
 }
-__global__ __launch_bounds__(256) void k_merge_commit(Lists L, uint32_t i, uint8_t* __restrict__ state, uint8_t* __restrict__ outcome) {
-  const uint32_t f = blockIdx.x * 256 + threadIdx.x;
-  if (f >= L.nf[i] || state[f] != 2) return;
-  const uint32_t a = L.list_of(i, f);
-  const Outcome o = walk(L, a, [](uint32_t) {});
-  outcome[f] = o;
-  commit(L, a, o);
-  state[f] = 0;
-}
-// what is left after kMaxRounds, in upstream's order
-__global__ void k_merge_sequential(Lists L, uint32_t i, uint8_t* __restrict__ state, uint8_t* __restrict__ outcome) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  for (uint32_t f = 0; f < L.nf[i]; ++f) {
-    if (!state[f]) continue;
-    const uint32_t a = L.list_of(i, f);
-    const Outcome o = walk(L, a, [](uint32_t) {});
-    outcome[f] = o;
-    commit(L, a, o);
-    state[f] = 0;
+// ---- output in (image, feature) order: one pass over the seeds (seed index = list index: image i's seeds are its
+// lists) with two running sums by decoupled look-back (scan_lookback.h) -- multi-matches before this seed, members before
+// it -- and the records written straight from them.  (Round 3: two library scans, one emit launch per image, a totals
+// kernel.)
+constexpr int kEmitItems = 4;
+__global__ __launch_bounds__(svs::kThreads) void k_merge_emit(Lists L, uint32_t numSeeds, const uint32_t* __restrict__ good,
+                                                              const uint32_t* __restrict__ memberCnt, ssrlcv_multimatch* __restrict__ mm,
+                                                              ssrlcv_uint2* __restrict__ mem, uint32_t* __restrict__ counts,
+                                                              const int* __restrict__ bad, svs::TileScan<2> ts) {
+  if (*bad) {  // grid-uniform: malformed input, the walk did not run
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      counts[0] = counts[1] = counts[3] = 0u;
+      counts[2] = (uint32_t)*bad;
+    }
+    return;
+  }
+  constexpr uint32_t kTile = svs::kThreads * kEmitItems;
+  for (uint32_t tile = svs::next_tile(ts.counter); tile < ts.numTiles; tile = svs::next_tile(ts.counter)) {
+    const uint32_t base = tile * kTile + threadIdx.x * kEmitItems;
+    uint32_t g[kEmitItems], c[kEmitItems], mine[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < kEmitItems; ++j) {
+      const bool in = base + j < numSeeds;
+      g[j] = in ? good[base + j] : 0u;
+      c[j] = in ? memberCnt[base + j] : 0u;
+      mine[0] += g[j];
+      mine[1] += c[j];
+    }
+    uint32_t excl[2], total[2], prefix[2];
+    svs::block_exclusive<2>(mine, excl, total);
+    svs::tile_prefix<2>(ts, tile, total, prefix);
+    uint32_t mmAt = prefix[0] + excl[0], memAt = prefix[1] + excl[1];
+#pragma unroll
+    for (int j = 0; j < kEmitItems; ++j) {
+      if (g[j]) {
+        const uint32_t a = base + j, n = L.len[a];
+        uint32_t i = 0;
+        while (i + 1 < L.V && L.base[i + 1] <= a) ++i;
+        ssrlcv_multimatch m;
+        m.numKeyPoints = n + 1;
+        m.index = (int)memAt;
+        mm[mmAt] = m;
+        mem[memAt].x = i;
+        mem[memAt].y = a - L.base[i];
+        for (uint32_t k = 0; k < n; ++k) {
+          const U2 e = L.entries[L.start[a] + k];
+          mem[memAt + 1 + k].x = e.x;
+          mem[memAt + 1 + k].y = e.y;
+        }
+        ++mmAt;
+        memAt += c[j];
+      }
+    }
+    if (tile == ts.numTiles - 1 && threadIdx.x == 0) {
+      counts[0] = prefix[0] + total[0];
+      counts[1] = prefix[1] + total[1];
+      counts[2] = 0u;  // counts[3] (rounds) was written by k_merge_walk
+    }
   }
 }
-__global__ __launch_bounds__(256) void k_merge_tally(Lists L, uint32_t i, const uint8_t* __restrict__ outcome, uint32_t seedBase,
-                                                     uint32_t* __restrict__ good, uint32_t* __restrict__ members) {
-  const uint32_t f = blockIdx.x * 256 + threadIdx.x;
-  if (f >= L.nf[i]) return;
-  const bool g = outcome[f] == kGood;
-  good[seedBase + f] = g ? 1u : 0u;
-  members[seedBase + f] = g ? L.len[L.list_of(i, f)] + 1u : 0u;  // an accepted seed's own list is final: only seeds of earlier images clear it
+__global__ void k_merge_no_seeds(const int* __restrict__ bad, uint32_t* __restrict__ counts) {  // two images: nothing seeds a multi-match
+  counts[0] = counts[1] = counts[3] = 0u;
+  counts[2] = (uint32_t)*bad;
 }
-__global__ __launch_bounds__(256) void k_merge_emit(Lists L, uint32_t i, uint32_t seedBase, const uint32_t* __restrict__ good,
-                                                    const uint32_t* __restrict__ mmOff, const uint32_t* __restrict__ memOff,
-                                                    ssrlcv_multimatch* __restrict__ mm, ssrlcv_uint2* __restrict__ mem) {
-  const uint32_t f = blockIdx.x * 256 + threadIdx.x;
-  if (f >= L.nf[i] || !good[seedBase + f]) return;
-  const uint32_t a = L.list_of(i, f), n = L.len[a], at = memOff[seedBase + f];
-  ssrlcv_multimatch m;
-  m.numKeyPoints = n + 1;
-  m.index = (int)at;
-  mm[mmOff[seedBase + f]] = m;
-  mem[at].x = i;
-  mem[at].y = f;
-  for (uint32_t k = 0; k < n; ++k) {
-    const U2 e = L.entries[L.start[a] + k];
-    mem[at + 1 + k].x = e.x;
-    mem[at + 1 + k].y = e.y;
-  }
-}
-__global__ void k_merge_totals(const uint32_t* __restrict__ good, const uint32_t* __restrict__ members, const uint32_t* __restrict__ mmOff,
-                               const uint32_t* __restrict__ memOff, uint32_t numSeeds, uint32_t* __restrict__ counts) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    counts[0] = numSeeds ? mmOff[numSeeds - 1] + good[numSeeds - 1] : 0u;
-    counts[1] = numSeeds ? memOff[numSeeds - 1] + members[numSeeds - 1] : 0u;
-  }
-}
+inline uint32_t emit_tiles(uint32_t numSeeds) { return (numSeeds + svs::kThreads * kEmitItems - 1) / (svs::kThreads * kEmitItems); }
 
 inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 struct Layout {
-  size_t mask, len, start, entries, minReader, minWriter, state, outcome, good, members, mmOff, memOff, scalars, scanTmp, total;
+  size_t mask, len, start, entries, minReader, minWriter, state, outcome, good, members, scalars, ctl, scanTmp, total;
+  size_t ctlBytes;
   size_t scanTmpBytes;
 };
-Layout make_layout(uint32_t numLists, uint32_t total, uint32_t maxSeeds, uint32_t numSeeds) {
+Layout make_layout(uint32_t numImages, uint32_t numLists, uint32_t total, uint32_t maxSeeds, uint32_t numSeeds) {
   Layout y;
   size_t p = 0;
   auto take = [&](size_t bytes) { const size_t at = p; p += up256(bytes); return at; };
   y.mask = take((size_t)numLists * 4);
-  y.len = take((size_t)numLists * 4);
+  y.len = take(((size_t)numLists + 1) * 4);  // + the element the scan over numLists + 1 inputs reads (zeroed)
   y.start = take(((size_t)numLists + 1) * 4);
   y.entries = take((size_t)(total ? total : 1) * 8);
   y.minReader = take((size_t)numLists * 4);
@@ -234,12 +337,13 @@ Layout make_layout(uint32_t numLists, uint32_t total, uint32_t maxSeeds, uint32_
   y.outcome = take(maxSeeds ? maxSeeds : 1);
   y.good = take((size_t)(numSeeds ? numSeeds : 1) * 4);
   y.members = take((size_t)(numSeeds ? numSeeds : 1) * 4);
-  y.mmOff = take((size_t)(numSeeds ? numSeeds : 1) * 4);
-  y.memOff = take((size_t)(numSeeds ? numSeeds : 1) * 4);
   y.scalars = take(256);
-  size_t s1 = 0, s2 = 0;
-  (void)rocprim::exclusive_scan(nullptr, s1, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)numLists + 1, rocprim::plus<uint32_t>());
-  (void)rocprim::exclusive_scan(nullptr, s2, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)(numSeeds ? numSeeds : 1), rocprim::plus<uint32_t>());
+  // barrier counters + one unresolved-count slot per (seed image, round)
+  y.ctlBytes = kBarrierBytes + (size_t)(numImages > 2 ? numImages - 2 : 1) * (kMaxRounds + 2) * 4;
+  y.ctl = take(y.ctlBytes);
+  // descriptors of the two single-pass scans (used one after the other): list starts over numLists + 1 lengths, emit over the seeds
+  const size_t s1 = svs::workspace_bytes<1>(svs::scan_tiles<8>(numLists + 1));
+  const size_t s2 = svs::workspace_bytes<2>(emit_tiles(numSeeds ? numSeeds : 1));
   y.scanTmpBytes = s1 > s2 ? s1 : s2;
   y.scanTmp = take(y.scanTmpBytes ? y.scanTmpBytes : 256);
   y.total = p;
@@ -268,12 +372,12 @@ extern "C" {
 size_t ssrlcv_hip_merge_workspace_bytes(uint32_t numImages, const uint32_t* numFeatures_host, uint32_t totalPairs) {
   uint32_t numLists = 0, maxSeeds = 0, numSeeds = 0;
   if (!sizes_of(numImages, numFeatures_host, &numLists, &maxSeeds, &numSeeds)) return 0;
-  return make_layout(numLists, totalPairs, maxSeeds, numSeeds).total;
+  return make_layout(numImages, numLists, totalPairs, maxSeeds, numSeeds).total;
 }
 
 int ssrlcv_hip_merge_matches(uint32_t numImages, const uint32_t* numFeatures_host, uint32_t numPairs, const uint32_t* pairCounts_host,
                              const ssrlcv_uint2_pair* pairs, void* workspace, size_t workspaceBytes, ssrlcv_multimatch* matches,
-                             ssrlcv_uint2* members, uint32_t* counts, uint32_t* rounds_host, ssrlcv_stream_t stream) {
+                             ssrlcv_uint2* members, uint32_t* counts, ssrlcv_stream_t stream) {
   uint32_t numLists = 0, maxSeeds = 0, numSeeds = 0;
   if (!sizes_of(numImages, numFeatures_host, &numLists, &maxSeeds, &numSeeds) || (numPairs && !pairCounts_host) || !workspace || !matches ||
       !members || !counts)
@@ -283,7 +387,7 @@ int ssrlcv_hip_merge_matches(uint32_t numImages, const uint32_t* numFeatures_hos
   if (total64 > 0x7fffffffull) return SSRLCV_ERR_CAPACITY;  // MultiMatch::index is an int (members <= 2 x pairs)
   const uint32_t total = (uint32_t)total64;
   if (total && !pairs) return SSRLCV_ERR_INVALID_ARG;
-  const Layout y = make_layout(numLists, total, maxSeeds, numSeeds);
+  const Layout y = make_layout(numImages, numLists, total, maxSeeds, numSeeds);
   if (workspaceBytes < y.total) return SSRLCV_ERR_WORKSPACE;
   const hipStream_t st = (hipStream_t)stream;
   char* ws = (char*)workspace;
@@ -295,10 +399,7 @@ int ssrlcv_hip_merge_matches(uint32_t numImages, const uint32_t* numFeatures_hos
   uint8_t* outcome = (uint8_t*)(ws + y.outcome);
   uint32_t* good = (uint32_t*)(ws + y.good);
   uint32_t* memberCnt = (uint32_t*)(ws + y.members);
-  uint32_t* mmOff = (uint32_t*)(ws + y.mmOff);
-  uint32_t* memOff = (uint32_t*)(ws + y.memOff);
   int* bad = (int*)(ws + y.scalars);
-  uint32_t* unresolved = (uint32_t*)(ws + y.scalars + 64);
   Lists L;
   L.V = numImages;
   L.base[0] = 0;
@@ -309,72 +410,51 @@ int ssrlcv_hip_merge_matches(uint32_t numImages, const uint32_t* numFeatures_hos
   L.start = start;
   L.len = (uint32_t*)(ws + y.len);
   L.entries = (const U2*)(ws + y.entries);
-  if (rounds_host) *rounds_host = 0;
 
   // ---- lists
   SSRLCV_HIP_TRY(hipMemsetAsync(mask, 0, (size_t)numLists * 4, st));
   SSRLCV_HIP_TRY(hipMemsetAsync(bad, 0, 128, st));
+  SSRLCV_HIP_TRY(hipMemsetAsync(ws + y.ctl, 0, y.ctlBytes, st));
+  SSRLCV_HIP_TRY(hipMemsetAsync(L.len + numLists, 0, 4, st));  // the scan's last input (its result is the total)
   const unsigned eb = (total + 255) / 256, lb = (numLists + 255) / 256;
   if (total) hipLaunchKernelGGL(k_merge_masks, dim3(eb), dim3(256), 0, st, L, pairs, total, mask, bad);
   if (numLists) hipLaunchKernelGGL(k_merge_len, dim3(lb), dim3(256), 0, st, mask, numLists, L.len);
-  {
-    // start = exclusive scan of the lengths over numLists + 1 elements (the element behind the last list is never read as a length)
-    size_t tmp = y.scanTmpBytes;
-    SSRLCV_HIP_TRY(rocprim::exclusive_scan(ws + y.scanTmp, tmp, (const uint32_t*)L.len, start, 0u, (size_t)numLists + 1, rocprim::plus<uint32_t>(), st));
-  }
+  // start = exclusive scan of the lengths over numLists + 1 elements (the last input is zero, its result the total)
+  SSRLCV_HIP_TRY(svs::exclusive_scan<8>((const uint32_t*)L.len, start, numLists + 1, ws + y.scanTmp, st));
   if (total) hipLaunchKernelGGL(k_merge_fill, dim3(eb), dim3(256), 0, st, L, pairs, total, (const uint32_t*)mask, (U2*)(ws + y.entries));
-  int badHost = 0;
-  SSRLCV_HIP_TRY(hipMemcpyAsync(&badHost, bad, sizeof(int), hipMemcpyDeviceToHost, st));
-  SSRLCV_HIP_TRY(hipStreamSynchronize(st));
-  if (badHost) return SSRLCV_ERR_INVALID_ARG;
 
-  // ---- the walk, image by image (only images 0..V-3 seed multi-matches, :969)
-  uint32_t seedBase = 0, roundsTotal = 0;
-  for (uint32_t i = 0; i + 2 < numImages; ++i) {
-    const uint32_t nf = numFeatures_host[i];
-    const unsigned sb = (nf + 255) / 256;
-    if (nf) {
-      hipLaunchKernelGGL(k_merge_begin, dim3(sb), dim3(256), 0, st, L, i, state, outcome);
-      const uint32_t later = L.base[i + 1];  // marks of lists of later images only
-      for (int r = 0;; ++r) {
-        SSRLCV_HIP_TRY(hipMemsetAsync(minReader + later, 0xff, (size_t)(numLists - later) * 4, st));
-        SSRLCV_HIP_TRY(hipMemsetAsync(minWriter + later, 0xff, (size_t)(numLists - later) * 4, st));
-        SSRLCV_HIP_TRY(hipMemsetAsync(unresolved, 0, 4, st));
-        hipLaunchKernelGGL(k_merge_mark, dim3(sb), dim3(256), 0, st, L, i, (const uint8_t*)state, minReader, minWriter, unresolved);
-        uint32_t left = 0;
-        SSRLCV_HIP_TRY(hipMemcpyAsync(&left, unresolved, 4, hipMemcpyDeviceToHost, st));
-        SSRLCV_HIP_TRY(hipStreamSynchronize(st));
-        if (!left) break;
-        if (r >= kMaxRounds) {
-          hipLaunchKernelGGL(k_merge_sequential, dim3(1), dim3(1), 0, st, L, i, state, outcome);
-          break;
-        }
-        hipLaunchKernelGGL(k_merge_ready, dim3(sb), dim3(256), 0, st, L, i, state, (const uint32_t*)minReader, (const uint32_t*)minWriter);
-        hipLaunchKernelGGL(k_merge_commit, dim3(sb), dim3(256), 0, st, L, i, state, outcome);
-        ++roundsTotal;
-      }
-      hipLaunchKernelGGL(k_merge_tally, dim3(sb), dim3(256), 0, st, L, i, (const uint8_t*)outcome, seedBase, good, memberCnt);
+  // ---- the walk, image by image (only images 0..V-3 seed multi-matches, :969), in one persistent cooperative launch
+  if (numSeeds) {
+    static int s_blocks = 0;  // co-resident blocks of k_merge_walk on this device (all devices of a node are alike)
+    if (s_blocks == 0) {
+      int dev = 0, cus = 0, perCu = 0;
+      SSRLCV_HIP_TRY(hipGetDevice(&dev));
+      SSRLCV_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      SSRLCV_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_merge_walk, 256, 0));
+      if (cus <= 0 || perCu <= 0) return SSRLCV_ERR_UNSUPPORTED;
+      s_blocks = cus;  // one block per CU: more only lengthen the barrier
     }
-    seedBase += nf;
+    unsigned blocks = (maxSeeds + 255) / 256;
+    if (blocks > (unsigned)s_blocks) blocks = (unsigned)s_blocks;
+    if (blocks == 0) blocks = 1;
+    WalkCtl ctl;
+    ctl.barrier = (uint32_t*)(ws + y.ctl);
+    ctl.unresolved = (uint32_t*)(ws + y.ctl + kBarrierBytes);
+    ctl.counts = counts;
+    ctl.bad = bad;
+    void* args[] = {&L, &numLists, &state, &outcome, &minReader, &minWriter, &good, &memberCnt, &ctl};
+    SSRLCV_HIP_TRY(hipLaunchCooperativeKernel((const void*)k_merge_walk, dim3(blocks), dim3(256), args, 0, st));
   }
   // ---- output in (image, feature) order
   if (numSeeds) {
-    size_t tmp = y.scanTmpBytes;
-    SSRLCV_HIP_TRY(rocprim::exclusive_scan(ws + y.scanTmp, tmp, (const uint32_t*)good, mmOff, 0u, (size_t)numSeeds, rocprim::plus<uint32_t>(), st));
-    tmp = y.scanTmpBytes;
-    SSRLCV_HIP_TRY(rocprim::exclusive_scan(ws + y.scanTmp, tmp, (const uint32_t*)memberCnt, memOff, 0u, (size_t)numSeeds, rocprim::plus<uint32_t>(), st));
-    seedBase = 0;
-    for (uint32_t i = 0; i + 2 < numImages; ++i) {
-      const uint32_t nf = numFeatures_host[i];
-      if (nf)
-        hipLaunchKernelGGL(k_merge_emit, dim3((nf + 255) / 256), dim3(256), 0, st, L, i, seedBase, (const uint32_t*)good, (const uint32_t*)mmOff,
-                           (const uint32_t*)memOff, matches, members);
-      seedBase += nf;
-    }
+    const uint32_t tiles = emit_tiles(numSeeds);
+    SSRLCV_HIP_TRY(hipMemsetAsync(ws + y.scanTmp, 0, svs::workspace_bytes<2>(tiles), st));
+    const svs::TileScan<2> ts = svs::make_tile_scan<2>(ws + y.scanTmp, tiles);
+    hipLaunchKernelGGL(k_merge_emit, dim3(tiles < 2048u ? tiles : 2048u), dim3(svs::kThreads), 0, st, L, numSeeds, (const uint32_t*)good,
+                       (const uint32_t*)memberCnt, matches, members, counts, (const int*)bad, ts);
+  } else {
+    hipLaunchKernelGGL(k_merge_no_seeds, dim3(1), dim3(1), 0, st, (const int*)bad, counts);
   }
-  hipLaunchKernelGGL(k_merge_totals, dim3(1), dim3(1), 0, st, (const uint32_t*)good, (const uint32_t*)memberCnt, (const uint32_t*)mmOff,
-                     (const uint32_t*)memOff, numSeeds, counts);
-  if (rounds_host) *rounds_host = roundsTotal;
   SSRLCV_LAUNCH_CHECK();
   return SSRLCV_OK;
 }

@@ -265,13 +265,14 @@ class MatchFactory {
       ptr::device<unsigned char> mergeWs((long)mergeBytes);
       ptr::device<MultiMatch> mm_d((long)totalMatches);
       ptr::device<uint2> mem_d((long)(2 * totalMatches));
-      ptr::device<uint32_t> counts_d(2);
+      ptr::device<uint32_t> counts_d(4);
       HipSafeCall(ssrlcv_hip_merge_matches((uint32_t)V, numFeatures.data(), (uint32_t)pairCounts.size(), pairCounts.data(),
                                            reinterpret_cast<const ssrlcv_uint2_pair*>(allPairs.get()), mergeWs.get(), mergeBytes,
                                            reinterpret_cast<ssrlcv_multimatch*>(mm_d.get()),
-                                           reinterpret_cast<ssrlcv_uint2*>(mem_d.get()), counts_d.get(), nullptr, nullptr));
-      uint32_t counts[2] = {0, 0};
+                                           reinterpret_cast<ssrlcv_uint2*>(mem_d.get()), counts_d.get(), nullptr));
+      uint32_t counts[4] = {0, 0, 0, 0};  // {matches, members, input status, rounds}; the copy synchronises the (asynchronous) merge
       HipSafeCall(ssrlcv_hip_memcpy(counts, counts_d.get(), sizeof counts, 1));
+      if (counts[2]) HipSafeCall(SSRLCV_ERR_INVALID_ARG);  // a malformed pair list (cannot come out of the matcher)
       const uint32_t nmm = counts[0], nmem = counts[1];
       logger.info.printf("total matches found in set = %d", (int)nmm);
       matchSet.matches = ptr::value<Unity<MultiMatch>>(nullptr, (unsigned long)nmm, cpu);

@@ -179,85 +179,93 @@ class PointCloudFactory {
   }
 
   // ---- filters between triangulation and BA (src/Pipeline.cu:297-352) ----------------
+  // Round 4: on the device.  Upstream copies bundles and errors to the host, loops over them there and builds a new
+  // MatchSet on the host; here bundles, the error triangulation, the statistical cutoff (ssrlcv_hip_error_sample_cutoff:
+  // the host's sequential float sums), the cutoff triangulation and the rebuild (ssrlcv_hip_filter_matchset) are queued
+  // back to back and two counts come back.  Results and the MatchSet's final memory state (cpu) are upstream's.
  private:
-  // shared tail of linearCutoffFilter / deterministicStatisticalFilter: drop the bundles flagged invalid and rebuild
-  // the MatchSet (2-view: re-indexed {2, 2k}; N-view: running index), src/PointCloudFactory.cu:3118-3274, :3517-3644
-  void dropInvalidBundles(MatchSet* matchSet, BundleSet& bundleSet, bool twoView, bool returnIfNoneBad) {
-    unsigned long nb = bundleSet.bundles->size();
-    Bundle* b = bundleSet.bundles->host.get();
-    unsigned long bad_bundles = 0, bad_lines = 0;
-    for (unsigned long k = 0; k < nb; ++k)
-      if (b[k].invalid) { bad_bundles++; bad_lines += b[k].numLines; }
-    if (returnIfNoneBad && !bad_bundles) return;
-    if (!(matchSet->matches->size() - bad_bundles)) return;
-    if (!twoView && !(matchSet->keyPoints->size() - bad_lines)) return;
-    ptr::value<Unity<KeyPoint>> oldKp = matchSet->keyPoints;
-    unsigned long newKp = twoView ? 2 * (matchSet->matches->size() - bad_bundles) : matchSet->keyPoints->size() - bad_lines;
-    unsigned long newMt = matchSet->matches->size() - bad_bundles;
-    matchSet->keyPoints = ptr::value<Unity<KeyPoint>>(nullptr, newKp, cpu);
-    matchSet->matches = ptr::value<Unity<MultiMatch>>(nullptr, newMt, cpu);
-    KeyPoint* src = oldKp->host.get();
-    KeyPoint* dst = matchSet->keyPoints->host.get();
-    MultiMatch* mm = matchSet->matches->host.get();
-    if (twoView) {
-      int k_adjust = 0;
-      for (unsigned long k = 0; k < nb; ++k)
-        if (!b[k].invalid) {
-          dst[2 * k_adjust] = src[2 * k];
-          dst[2 * k_adjust + 1] = src[2 * k + 1];
-          mm[k_adjust] = {2, 2 * k_adjust};
-          k_adjust++;
-        }
+  // kind 0: linearCutoffFilter(cutoff); kind 1: deterministicStatisticalFilter(sigma, sampleJump)
+  void filterOnDevice(MatchSet* matchSet, std::vector<ptr::value<Image>>& images, int kind, float cutoff, float sigma, int sampleJump) {
+    const bool twoView = images.size() == 2;
+    const uint32_t nb = (uint32_t)matchSet->matches->size(), nk = (uint32_t)matchSet->keyPoints->size();
+    matchSet->matches->transferMemoryTo(gpu);
+    matchSet->keyPoints->transferMemoryTo(gpu);
+    auto* mm = reinterpret_cast<const ssrlcv_multimatch*>(matchSet->matches->device.get());
+    auto* kp = reinterpret_cast<const ssrlcv_keypoint*>(matchSet->keyPoints->device.get());
+    ptr::device<ssrlcv_bundle> bundles((long)nb);
+    ptr::device<ssrlcv_line> lines((long)nk);
+    if (!images.at(0)->isPushbroom) {
+      std::vector<ssrlcv_camera> cams;
+      cameras_of(images, cams);
+      ptr::device<ssrlcv_camera> cams_d((long)cams.size());
+      HipSafeCall(ssrlcv_hip_memcpy(cams_d.get(), cams.data(), cams.size() * sizeof(ssrlcv_camera), 0));
+      HipSafeCall(ssrlcv_hip_generate_bundles(mm, kp, nb, cams_d.get(), (uint32_t)cams.size(), bundles.get(), lines.get(), nullptr));
+      HipSafeCall(ssrlcv_hip_device_synchronize());  // cams_d goes out of scope
     } else {
-      int k_adjust = 0, k_bundle = 0, k_keypnt = 0;
-      for (unsigned long k = 0; k < nb; ++k) {
-        unsigned int k_lines = b[k].numLines;
-        if (!b[k].invalid) {
-          mm[k_bundle] = {k_lines, k_adjust};
-          for (unsigned int j = 0; j < k_lines; ++j) dst[k_adjust + j] = src[k_keypnt + j];
-          k_adjust += (int)k_lines;
-          k_bundle++;
-        }
-        k_keypnt += (int)k_lines;
-      }
+      std::vector<ssrlcv_pushbroom> pbs(images.size());
+      for (size_t i = 0; i < images.size(); ++i) std::memcpy(&pbs[i], &images[i]->pushbroom, sizeof(ssrlcv_pushbroom));
+      ptr::device<ssrlcv_pushbroom> pbs_d((long)pbs.size());
+      HipSafeCall(ssrlcv_hip_memcpy(pbs_d.get(), pbs.data(), pbs.size() * sizeof(ssrlcv_pushbroom), 0));
+      HipSafeCall(ssrlcv_hip_generate_pushbroom_bundles(mm, kp, nb, pbs_d.get(), (uint32_t)pbs.size(), bundles.get(), lines.get(), nullptr));
+      HipSafeCall(ssrlcv_hip_device_synchronize());
     }
+    ptr::device<float> errors((long)nb), cut_d(1);
+    DevFloat sum;
+    auto tri = [&](const float* cut) {
+      if (twoView) HipSafeCall(ssrlcv_hip_triangulate2(lines.get(), bundles.get(), nb, nullptr, errors.get(), cut, sum.p.get(), nullptr));
+      else HipSafeCall(ssrlcv_hip_triangulateN(lines.get(), bundles.get(), nb, nullptr, errors.get(), cut, sum.p.get(), 0, nullptr));
+    };
+    if (kind == 0) {
+      HipSafeCall(ssrlcv_hip_memcpy(cut_d.get(), &cutoff, sizeof(float), 0));
+      tri(cut_d.get());
+    } else {
+      const float zero = 0.0f;  // the initial triangulation runs its cutoff overload with a cutoff of 0 (:3110-3118)
+      HipSafeCall(ssrlcv_hip_memcpy(cut_d.get(), &zero, sizeof(float), 0));
+      tri(cut_d.get());
+      HipSafeCall(ssrlcv_hip_error_sample_cutoff(errors.get(), nb, (uint32_t)sampleJump, sigma, cut_d.get(), nullptr));
+      tri(cut_d.get());
+    }
+    const size_t wsBytes = ssrlcv_hip_filter_workspace_bytes(nb);
+    ptr::device<unsigned char> ws((long)wsBytes);
+    ptr::value<Unity<MultiMatch>> mmOut(nullptr, (unsigned long)nb, gpu);
+    ptr::value<Unity<KeyPoint>> kpOut(nullptr, (unsigned long)nk, gpu);
+    ptr::device<uint32_t> counts_d(3);
+    HipSafeCall(ssrlcv_hip_filter_matchset(bundles.get(), kp, nb, reinterpret_cast<ssrlcv_multimatch*>(mmOut->device.get()),
+                                           reinterpret_cast<ssrlcv_keypoint*>(kpOut->device.get()), counts_d.get(), ws.get(), wsBytes, nullptr));
+    uint32_t counts[3] = {0, 0, 0};
+    HipSafeCall(ssrlcv_hip_memcpy(counts, counts_d.get(), sizeof counts, 1));
+    HipCheckError();
+    // upstream's generateBundles leaves the MatchSet on the host
+    matchSet->matches->transferMemoryTo(cpu);
+    matchSet->keyPoints->transferMemoryTo(cpu);
+    matchSet->matches->clear(gpu);
+    matchSet->keyPoints->clear(gpu);
+    const uint32_t kept = counts[0], keptKp = counts[1];
+    const bool returnIfNoneBad = kind == 0 || !twoView;  // :3236-3239 and :3543; the two-view statistical form rebuilds regardless
+    if (returnIfNoneBad && kept == nb) return;
+    if (kept == 0 || (!twoView && keptKp == 0)) return;   // "filtering is too aggressive, all points would be removed"
+    ptr::value<Unity<MultiMatch>> newMm(nullptr, (unsigned long)kept, gpu);
+    ptr::value<Unity<KeyPoint>> newKp(nullptr, (unsigned long)keptKp, gpu);
+    HipSafeCall(ssrlcv_hip_memcpy(newMm->device.get(), mmOut->device.get(), sizeof(MultiMatch) * kept, 2));
+    HipSafeCall(ssrlcv_hip_memcpy(newKp->device.get(), kpOut->device.get(), sizeof(KeyPoint) * keptKp, 2));
+    newMm->transferMemoryTo(cpu);
+    newMm->clear(gpu);
+    newKp->transferMemoryTo(cpu);
+    newKp->clear(gpu);
+    matchSet->matches = newMm;
+    matchSet->keyPoints = newKp;
   }
 
  public:
   // src/PointCloudFactory.cu:3500-3644
   void linearCutoffFilter(MatchSet* matchSet, std::vector<ptr::value<Image>> images, float cutoff) {
     if (cutoff < 0.0) return;
-    float linearError = 0.0, linearErrorCutoff = cutoff;
-    BundleSet bundleSet = generateBundles(matchSet, images);
-    ptr::value<Unity<float>> errors(nullptr, matchSet->matches->size(), cpu);
-    if (images.size() == 2) twoViewTriangulate(bundleSet, errors, &linearError, &linearErrorCutoff);
-    else nViewTriangulate(bundleSet, errors, &linearError, &linearErrorCutoff);
-    dropInvalidBundles(matchSet, bundleSet, images.size() == 2, true);
+    filterOnDevice(matchSet, images, 0, cutoff, 0.0f, 1);
   }
   // src/PointCloudFactory.cu:3070-3275: cutoff = sigma * stddev of every (1/sampleSize)-th error (mean NOT added)
   void deterministicStatisticalFilter(MatchSet* matchSet, std::vector<ptr::value<Image>> images, float sigma, float sampleSize) {
     if (sampleSize > 1.0 || sampleSize < 0.0) return;
-    int sampleJump = (int)(1 / sampleSize);
-    float linearError = 0.0, linearErrorCutoff = 0.0;
-    BundleSet bundleSet = generateBundles(matchSet, images);
-    ptr::value<Unity<float>> errors(nullptr, matchSet->matches->size(), cpu);
-    const bool twoView = images.size() == 2;
-    if (twoView) twoViewTriangulate(bundleSet, errors, &linearError, &linearErrorCutoff);
-    else nViewTriangulate(bundleSet, errors, &linearError, &linearErrorCutoff);
-    size_t sample_size = (int)(errors->size() - (errors->size() % sampleJump)) / sampleJump;
-    float sample_sum = 0;
-    for (size_t k = 0; k < sample_size; k++) sample_sum += errors->host.get()[k * sampleJump];
-    float sample_mean = sample_sum / sample_size;
-    float squared_sum = 0;
-    for (size_t k = 0; k < sample_size; k++) {
-      float e = errors->host.get()[k * sampleJump];
-      squared_sum += (e - sample_mean) * (e - sample_mean);
-    }
-    float variance = squared_sum / sample_size;
-    linearErrorCutoff = sigma * sqrtf(variance);
-    if (twoView) twoViewTriangulate(bundleSet, errors, &linearError, &linearErrorCutoff);
-    else nViewTriangulate(bundleSet, errors, &linearError, &linearErrorCutoff);
-    dropInvalidBundles(matchSet, bundleSet, twoView, !twoView);
+    filterOnDevice(matchSet, images, 1, 0.0f, sigma, (int)(1 / sampleSize));
   }
 
   // f(cameras) for K parameter sets in one launch; params_host = K x (6 * images) floats

@@ -271,6 +271,37 @@ def oracle_triangulate(lib, nview, bundles, lines, want_errors=False, cutoff=Non
     return pts, errs, total
 
 
+def oracle_filter(lib, mm, kp, cams, kind, cutoff=None, sigma=None, sample_size=None):
+    """linearCutoffFilter (kind "linear", src/PointCloudFactory.cu:3500-3644) or deterministicStatisticalFilter (kind
+    "statistical", :3070-3275) on a MatchSet, restated on the oracle's pieces -> (MultiMatch, KeyPoint) after the filter."""
+    nview = len(cams) > 2
+    bundles, lines, _ = oracle_bundles(lib, mm, kp, cams)
+    lib.oracle_sample_cutoff.restype = ctypes.c_float
+    if kind == "linear":
+        if cutoff < 0.0:
+            return mm, kp
+        oracle_triangulate(lib, nview, bundles, lines, want_errors=True, cutoff=cutoff)
+        only_if_bad = True
+    else:
+        if sample_size > 1.0 or sample_size < 0.0:
+            return mm, kp
+        jump = int(1 / sample_size)
+        _, errs, _ = oracle_triangulate(lib, nview, bundles, lines, want_errors=True, cutoff=0.0)
+        cut = lib.oracle_sample_cutoff(P(errs), ctypes.c_uint32(len(errs)), ctypes.c_uint32(jump), ctypes.c_float(sigma))
+        oracle_triangulate(lib, nview, bundles, lines, want_errors=True, cutoff=cut)
+        only_if_bad = nview
+    bad = int((bundles["invalid"] != 0).sum())
+    bad_lines = int(bundles["numLines"][bundles["invalid"] != 0].sum())
+    if only_if_bad and not bad:
+        return mm, kp
+    if len(mm) - bad == 0 or (nview and len(kp) - bad_lines == 0):
+        return mm, kp      # "filtering is too aggressive": upstream leaves the MatchSet alone
+    mm_out, kp_out = np.zeros(len(mm), MULTIMATCH), np.zeros(len(kp), KEYPOINT)
+    counts = np.zeros(3, np.uint32)
+    lib.oracle_filter_matchset(ctypes.c_uint32(len(mm)), P(bundles), P(kp), P(mm_out), P(kp_out), P(counts))
+    return mm_out[:counts[0]].copy(), kp_out[:counts[1]].copy()
+
+
 class OracleSift:
     """Staged access to the oracle's scale space for kernel-level parity tests."""
 

@@ -140,3 +140,71 @@ def test_pushbroom_bundles_match_oracle(capi, oracle_lib):
     assert np.array_equal(H.bits(gl["vec"]), H.bits(ol["vec"]))
     assert np.array_equal(H.bits(gl["pnt"]), H.bits(ol["pnt"]))
     assert np.array_equal(capi.to_host(b_d, H.BUNDLE, nb)["index"], mm["index"])
+
+
+# ---- filters between triangulation and BA on the device (csrc/filter.hip) ------------------------------------------------
+@pytest.mark.parametrize("n,jump", [(1, 10), (9, 10), (10, 10), (1023, 10), (13534, 10), (21177, 10), (100000, 3), (1 << 20, 10),
+                                    (3100000, 10), (5000, 1)])
+def test_sample_cutoff_is_the_hosts_sequential_sum(capi, oracle_lib, n, jump):
+    """sigma x std of every jump-th error: the device chain must be the host loop's float sums bit for bit
+    (src/PointCloudFactory.cu:3121-3156)."""
+    import torch
+    rng = np.random.default_rng(n + jump)
+    errs = (rng.random(n).astype(np.float32) ** 4 * np.float32(50.0)).astype(np.float32)   # skewed, like squared line gaps
+    oracle_lib.oracle_sample_cutoff.restype = ctypes.c_float
+    want = np.float32(oracle_lib.oracle_sample_cutoff(H.P(errs), ctypes.c_uint32(n), ctypes.c_uint32(jump), ctypes.c_float(3.0)))
+    got = capi.error_sample_cutoff(torch.from_numpy(errs).cuda(), n, jump, 3.0).cpu().numpy()[0]
+    if n < jump:
+        assert np.isnan(got) and np.isnan(want)   # an empty sample: 0 / 0 on both sides
+    else:
+        assert got.view(np.uint32) == want.view(np.uint32), (got, want)
+
+
+@pytest.mark.parametrize("n,maxlines,pbad", [(1, 2, 0.0), (5, 2, 1.0), (1000, 2, 0.3), (1024, 5, 0.5), (70000, 2, 0.02), (300000, 8, 0.66),
+                                             (1 << 20, 3, 0.001)])
+def test_filter_matchset_equals_the_host_rebuild(capi, oracle_lib, n, maxlines, pbad):
+    """ssrlcv_hip_filter_matchset (one pass, three running sums by decoupled look-back) against the reference's host loop
+    (src/PointCloudFactory.cu:3253-3268) on random flag patterns and bundle sizes, from one tile to hundreds."""
+    rng = np.random.default_rng(n)
+    bundles = np.zeros(n, H.BUNDLE)
+    bundles["numLines"] = rng.integers(2, maxlines + 1, n)
+    bundles["index"] = np.concatenate([[0], np.cumsum(bundles["numLines"])[:-1]])
+    bundles["invalid"] = rng.random(n) < pbad
+    nk = int(bundles["numLines"].sum())
+    kp = np.zeros(nk, H.KEYPOINT)
+    kp["parentId"] = rng.integers(0, 8, nk)
+    kp["loc"] = rng.random((nk, 2)).astype(np.float32) * 4096
+    mm_o, kp_o, cnt_o = np.zeros(n, H.MULTIMATCH), np.zeros(nk, H.KEYPOINT), np.zeros(3, np.uint32)
+    oracle_lib.oracle_filter_matchset(ctypes.c_uint32(n), H.P(bundles), H.P(kp), H.P(mm_o), H.P(kp_o), H.P(cnt_o))
+    mm_d, kp_d, counts = capi.filter_matchset(capi.to_dev(bundles), capi.to_dev(kp), n, nk)
+    got = counts.cpu().numpy().astype(np.uint32)
+    assert np.array_equal(got, cnt_o), (got, cnt_o)
+    mm_g = capi.to_host(mm_d, H.MULTIMATCH, int(got[0]))
+    kp_g = capi.to_host(kp_d, H.KEYPOINT, int(got[1]))
+    assert np.array_equal(mm_g["numKeyPoints"], mm_o["numKeyPoints"][:got[0]]) and np.array_equal(mm_g["index"], mm_o["index"][:got[0]])
+    assert np.array_equal(kp_g["parentId"], kp_o["parentId"][:got[1]]) and np.array_equal(kp_g["loc"], kp_o["loc"][:got[1]])
+
+
+@pytest.mark.parametrize("view,after", [("Pipeline2View", 13308), ("Pipeline3View", 21099)])
+def test_device_filters_reproduce_the_stage1_fixtures(capi, oracle_lib, view, after):
+    """doFiltering's sequence (src/Pipeline.cu:305-340) through pipeline.apply_filters on the device copies of the
+    reference's stage-0 MatchSet -> the reference's stage-1 MatchSet, every key point and index; equal to the oracle's
+    filters step by step."""
+    from ssrlcv_amd import pipeline
+    v = H.load_view(view)
+    mm, kp, cams = v["mm0"], v["kp0"], v["cameras"]
+    dev = {}
+    mm_f, kp_f = pipeline.apply_filters(mm, kp, dev, cams, pipeline.REFERENCE_FILTERS)
+    assert len(mm_f) == after == len(v["mm1"])
+    assert np.array_equal(mm_f["numKeyPoints"], v["mm1"]["numKeyPoints"]) and np.array_equal(mm_f["index"], v["mm1"]["index"])
+    assert np.array_equal(kp_f["parentId"], v["kp1"]["parentId"]) and np.array_equal(kp_f["loc"], v["kp1"]["loc"])
+    # the device copies left for the triangulation are the same arrays
+    assert np.array_equal(capi.to_host(dev["matches"], H.MULTIMATCH, after)["index"], v["mm1"]["index"])
+    # and the filtered cloud is the reference's stage-1 cloud, bit for bit
+    b_d, l_d = capi.generate_bundles(dev["matches"], dev["keypoints"], after, capi.to_dev(cams), len(cams), len(kp_f))
+    pts_d, _, _ = capi.triangulate(l_d, b_d, after, nview=len(cams) > 2)
+    assert np.array_equal(pts_d.cpu().numpy().reshape(-1, 3).view(np.uint32), v["points1"].view(np.uint32))
+    # a single statistical step against the oracle's
+    mo, ko = H.oracle_filter(oracle_lib, mm, kp, cams, "statistical", sigma=2.0, sample_size=0.25)
+    mg, kg = pipeline.apply_filters(mm, kp, {}, cams, [("statistical", 2.0, 0.25)])
+    assert len(mo) < len(mm) and np.array_equal(mg["index"], mo["index"]) and np.array_equal(kg["loc"], ko["loc"])
