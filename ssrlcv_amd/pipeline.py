@@ -421,7 +421,8 @@ def reconstruct(pixel_tensors_all, cameras, seed_features=None, epsilon=25.0, de
     cloud = triangulate(mm, kp, cameras, nview=num_images > 2, pushbroom=pushbroom, dev=dev)
     torch.cuda.synchronize()
     ws.tick("triangulate", t)
-    out = {"features": feats, "pairs": pair_all, "matches": mm, "keypoints": kp, "points": cloud, "matches_unfiltered": unfiltered}
+    out = {"features": feats, "pairs": pair_all, "matches": mm, "keypoints": kp, "points": cloud, "matches_unfiltered": unfiltered,
+           "device": dev}   # device copies of the MatchSet ("matches", "keypoints"), e.g. for further apply_filters steps
     if ba and pushbroom is None:
         t = time.perf_counter()
         out["ba_sums"], out["ba_bundles"] = ba_error_sweep(mm, kp, cameras)
