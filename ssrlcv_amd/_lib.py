@@ -39,7 +39,7 @@ EXPORTED = [
     "ssrlcv_hip_pose_lm_terms", "ssrlcv_hip_pose_cost",
     "ssrlcv_projection_matrix_host", "ssrlcv_hip_match_workspace_bytes", "ssrlcv_hip_seed_distances_u8x128",
     "ssrlcv_hip_match_u8x128", "ssrlcv_hip_compact_matches", "ssrlcv_hip_compact_matches_async", "ssrlcv_hip_keypoints_from_members",
-    "ssrlcv_hip_matchset_from_matches", "ssrlcv_merge_matches_host", "ssrlcv_merge_matches_host_mode", "ssrlcv_host_free",
+    "ssrlcv_hip_matchset_from_matches", "ssrlcv_merge_matches_host", "ssrlcv_merge_matches_host_mode", "ssrlcv_host_free", "ssrlcv_assign_pairs_host",
     "ssrlcv_hip_merge_workspace_bytes", "ssrlcv_hip_merge_matches",
     "ssrlcv_hip_error_sample_cutoff", "ssrlcv_hip_filter_workspace_bytes", "ssrlcv_hip_filter_matchset",
     "ssrlcv_hip_convert_to_bw", "ssrlcv_hip_u8_to_f32", "ssrlcv_hip_upsample2x", "ssrlcv_hip_upsample2x_u8", "ssrlcv_hip_bin2x",

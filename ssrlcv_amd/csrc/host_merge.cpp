@@ -320,4 +320,29 @@ int ssrlcv_merge_matches_host(uint32_t numImages, const uint32_t* numFeatures, u
 
 void ssrlcv_host_free(void* p) { std::free(p); }
 
+// The pair table of the sharded generateMatchesExhaustive: which rank matches image pair p (pairs
+// in upstream's order (0,1),(0,2)..(1,2).., src/MatchFactory.cu:924-936).  The cost of a pair is nq x nt distance
+// evaluations, known on every rank once the feature counts are exchanged; longest-processing-time-first -- pairs by
+// descending cost (ties by pair index) each go to the least loaded rank (ties to the lowest rank) -- is deterministic, so
+// every rank derives the same table.  ONE definition for the Python driver (ssrlcv_amd/dist.py) and the C++ one
+// (host/Distributed.hpp).
+int ssrlcv_assign_pairs_host(uint32_t numImages, const uint32_t* numFeatures, uint32_t world, uint32_t* owners_out) {
+  if (numImages < 2 || !numFeatures || world == 0 || !owners_out) return SSRLCV_ERR_INVALID_ARG;
+  std::vector<unsigned long long> cost;
+  for (uint32_t i = 0; i + 1 < numImages; ++i)
+    for (uint32_t j = i + 1; j < numImages; ++j) cost.push_back((unsigned long long)numFeatures[i] * numFeatures[j]);
+  std::vector<uint32_t> order(cost.size());
+  for (uint32_t p = 0; p < order.size(); ++p) order[p] = p;
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+  std::vector<unsigned long long> load(world, 0ull);
+  for (uint32_t p : order) {
+    uint32_t r = 0;
+    for (uint32_t k = 1; k < world; ++k)
+      if (load[k] < load[r]) r = k;
+    owners_out[p] = r;
+    load[r] += cost[p];
+  }
+  return SSRLCV_OK;
+}
+
 }  // extern "C"

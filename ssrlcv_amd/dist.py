@@ -10,8 +10,10 @@ collectives are the two exchanges the flow really has:
               deterministic on every rank (ssrlcv_hip_merge_matches on the device; merge_matches below is the host form).
 
 Arrays have different lengths per rank, so each exchange is one small size collective (with a single device-to-host
-copy of the size vector) followed by one all-gather into a flat buffer padded to the largest rank (payloads are tens
-to hundreds of MB: the feature exchange of eight 4096^2 views moves 8 x 240 MB, ~10 ms on 7 x 153 GB/s xGMI links).
+copy of the size vector) followed by every rank's bytes at their exact size -- one broadcast per rank into its segment
+of a flat buffer, all in flight (round 3 padded an all-gather to the largest rank; the shares differ several-fold).
+Payloads are tens to hundreds of MB: the feature exchange of eight 4096^2 views moves 8 x 240 MB, ~10 ms on 7 x 153 GB/s
+xGMI links.
 
 This module holds only the sharding / exchange logic; compute calls go through ssrlcv_amd.capi (HIP C ABI).
 """
@@ -39,17 +41,21 @@ def assign_pairs(num_features, world):
     """Stage B, balanced: the cost of pair (i, j) is nq * nt distance evaluations, known on every rank once the feature
     arrays are exchanged.  Longest-processing-time-first: pairs by descending cost (ties by pair index) each go to the
     least loaded rank (ties to the lowest rank) -- deterministic, so every rank derives the same table.  With six pairs
-    on four ranks round-robin gives two ranks two pairs each whatever their sizes.  -> owner rank per pair index."""
-    pairs = pair_list(len(num_features))
-    cost = [int(num_features[i]) * int(num_features[j]) for i, j in pairs]
-    order = sorted(range(len(pairs)), key=lambda p: (-cost[p], p))
-    load = [0] * world
-    owner = [0] * len(pairs)
-    for p in order:
-        r = min(range(world), key=lambda k: (load[k], k))
-        owner[p] = r
-        load[r] += cost[p]
-    return owner
+    on four ranks round-robin gives two ranks two pairs each whatever their sizes.  -> owner rank per pair index.
+    The table is computed by the library (ssrlcv_assign_pairs_host, csrc/host_merge.cpp: host code, no GPU): one
+    definition for this driver and the C++ one (host/Distributed.hpp)."""
+    import ctypes
+    from . import _lib
+    lib = _lib.load()
+    V = len(num_features)
+    if V < 2:
+        return []
+    nf = (ctypes.c_uint32 * V)(*[int(x) for x in num_features])
+    owners = (ctypes.c_uint32 * (V * (V - 1) // 2))()
+    rc = lib.ssrlcv_assign_pairs_host(ctypes.c_uint32(V), nf, ctypes.c_uint32(int(world)), owners)
+    if rc != 0:
+        raise ValueError("ssrlcv_assign_pairs_host: status %d" % rc)
+    return [int(o) for o in owners]
 
 
 def bundle_range(num_bundles, world, rank):
@@ -77,11 +83,25 @@ def all_reduce_sum(t, group=None):
     return t
 
 
+def _gather_segments(segments, flat, group=None):
+    """Fills `flat` (1-D uint8 on the backend's device): segment r = flat[offsets[r] : offsets[r] + sizes[r]] is broadcast
+    from rank r.  Exact sizes on the wire -- one broadcast per rank, all in flight -- instead of an all-gather padded to
+    the largest rank: the shares differ several-fold (a rank's features, or its LPT-assigned pairs)."""
+    works = []
+    for r, (off, size) in enumerate(segments):
+        if size:
+            works.append(dist.broadcast(flat[off: off + size], src=r if group is None else dist.get_global_rank(group, r),
+                                        group=group, async_op=True))
+    for w in works:
+        w.wait()
+
+
 def all_gather_bytes(local, group=None):
     """All-gather of variable-length uint8 tensors.  `local` is a 1-D uint8 tensor on the backend's device (CUDA for
     nccl, CPU for gloo).  Returns a list with one tensor per rank.  One count all-gather (a single D2H copy of the
-    world-sized count vector) and one payload all-gather into a flat buffer padded to the largest rank."""
+    world-sized count vector), then every rank's bytes at their exact size (no padding to the largest rank)."""
     world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
     home = local.device
     dev = _comm_device(home, group)
     local = local.to(dev)
@@ -89,16 +109,14 @@ def all_gather_bytes(local, group=None):
     counts_t = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(counts_t, n, group=group)
     counts = counts_t.tolist()
-    mx = max(max(counts), 1)
-    if local.numel() == mx:
-        padded = local
-    else:
-        padded = torch.zeros(mx, dtype=torch.uint8, device=dev)
-        padded[: local.numel()] = local
-    flat = torch.empty(world * mx, dtype=torch.uint8, device=dev)
-    dist.all_gather_into_tensor(flat, padded, group=group)
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    flat = torch.empty(max(offs[-1], 1), dtype=torch.uint8, device=dev)
+    flat[offs[rank]: offs[rank] + counts[rank]] = local
+    _gather_segments([(offs[r], counts[r]) for r in range(world)], flat, group)
     flat = flat.to(home)
-    return [flat[r * mx: r * mx + c] for r, c in enumerate(counts)]
+    return [flat[offs[r]: offs[r] + counts[r]] for r in range(world)]
 
 
 def exchange_keyed(local_items, num_keys, owner_fn, group=None):
@@ -125,18 +143,19 @@ def exchange_keyed(local_items, num_keys, owner_fn, group=None):
     dist.all_reduce(sizes, op=dist.ReduceOp.SUM, group=group)
     sizes = sizes.tolist()
     per_rank = [sum(sizes[k] for k in range(num_keys) if owner_fn(k, world) == r) for r in range(world)]
-    mx = max(max(per_rank), 1)
-    payload = torch.zeros(mx, dtype=torch.uint8, device=dev)
-    off = 0
+    offs = [0]
+    for c in per_rank:
+        offs.append(offs[-1] + c)
+    flat = torch.empty(max(offs[-1], 1), dtype=torch.uint8, device=dev)
+    off = offs[rank]
     for k in mine:
-        payload[off: off + sizes[k]] = local_items[k].reshape(-1).to(dev)
+        flat[off: off + sizes[k]] = local_items[k].reshape(-1).to(dev)
         off += sizes[k]
-    flat = torch.empty(world * mx, dtype=torch.uint8, device=dev)
-    dist.all_gather_into_tensor(flat, payload, group=group)
+    _gather_segments([(offs[r], per_rank[r]) for r in range(world)], flat, group)   # exact sizes, no padding
     flat = flat.to(home)
     out = [None] * num_keys
     for r in range(world):
-        off = r * mx
+        off = offs[r]
         for k in range(num_keys):
             if owner_fn(k, world) == r:
                 out[k] = flat[off: off + sizes[k]]

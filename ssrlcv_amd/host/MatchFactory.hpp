@@ -121,6 +121,7 @@ class MatchFactory {
     seedFeatures = nullptr;
   }
   void setSeedFeatures(ptr::value<Unity<Feature<T>>> seedFeatures) { this->seedFeatures = seedFeatures; }
+  bool hasSeedFeatures() const { return seedFeatures != nullptr; }
 
   // src/MatchFactory.cu:315-346
   ptr::value<Unity<float>> getSeedDistances(ptr::value<Unity<Feature<T>>> features) {
@@ -232,6 +233,17 @@ class MatchFactory {
         totalMatches += matchIndices.back()->size();
       }
     }
+    return assembleMatchSet(images, features, matchIndices, totalMatches);
+  }
+
+  // The host half of generateMatchesExhaustive (src/MatchFactory.cu:938-1028) from the validated uint2_pair arrays of
+  // every image pair in upstream's pair order: the merge and the KeyPoint table.  Public because the sharded driver
+  // (host/Distributed.hpp) arrives here with pair arrays it matched on several GPUs and exchanged.
+  MatchSet assembleMatchSet(std::vector<ptr::value<Image>>& images, std::vector<ptr::value<Unity<Feature<T>>>>& features,
+                            std::vector<ptr::value<Unity<uint2_pair>>>& matchIndices, unsigned long long totalMatches) {
+    MatchSet matchSet;
+    matchSet.keyPoints = nullptr;
+    matchSet.matches = nullptr;
     if (totalMatches == 0) {
       logger.err << "There were no matches found in the set of images, likely due to unreasonable threshold";
       logger.err << "exiting...";

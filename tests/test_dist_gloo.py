@@ -135,3 +135,23 @@ def test_pair_assignment_is_balanced_and_deterministic():
         assert max(load) - min(load) <= max(cost)
     # equal sizes on four ranks: the two ranks that take a second pair are decided by the tie rule, not by chance
     assert sd.assign_pairs([1000] * 4, 4) == [0, 1, 2, 3, 0, 1]
+
+
+def test_pair_table_is_longest_processing_time_first():
+    from ssrlcv_amd import dist as sd
+    """ssrlcv_assign_pairs_host (the one definition behind dist.assign_pairs and host/Distributed.hpp) against the rule
+    written out: pairs by descending cost nq x nt (ties by pair index), each to the least loaded rank (ties to the lowest)."""
+    rng = np.random.default_rng(3)
+    for trial in range(200):
+        V = int(rng.integers(2, 10))
+        world = int(rng.integers(1, 9))
+        nf = [int(x) for x in rng.integers(0, 5, V)] if trial % 3 == 0 else [int(x) for x in rng.integers(1000, 3000000, V)]
+        pairs = sd.pair_list(V)
+        cost = [nf[i] * nf[j] for i, j in pairs]
+        load, want = [0] * world, [0] * len(pairs)
+        for p in sorted(range(len(pairs)), key=lambda p: (-cost[p], p)):
+            r = min(range(world), key=lambda k: (load[k], k))
+            want[p] = r
+            load[r] += cost[p]
+        assert sd.assign_pairs(nf, world) == want, (nf, world)
+    assert sd.assign_pairs([5], 4) == []

@@ -120,6 +120,26 @@ def test_reference_stage_flow_through_class_api(tmp_path, views):
         assert np.abs(adj - pts).max() <= 5e-4
 
 
+@pytest.mark.gpu
+def test_sharded_generate_matches_exhaustive_in_cpp(tmp_path):
+    """host/Distributed.hpp: generateMatchesExhaustiveSharded -- RCCL (ncclAllReduce of the counts, grouped ncclBroadcast of
+    the feature and pair arrays) called directly on Unity<T>::device pointers, pairs by the library's LPT table -- at
+    world size 1 (RCCL refuses two ranks on one device and the box has one): equal to the single-GPU
+    generateMatchesExhaustive entry for entry, which is the reference's golden 3-view MatchSet."""
+    d = str(tmp_path)
+    _prepare_pipeline_dir(d, 3)
+    build_binary()
+    exe = os.path.join(H.ROOT, "ssrlcv_amd", "host", "_build", "sharded_match_test")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([exe, d, "3"], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0 and "sharded ok" in out.stdout and "sharded == single: 21177" in out.stdout, out.stdout + out.stderr
+    gv = H.load_view("Pipeline3View")
+    kp, _, _ = read_uty(os.path.join(d, "200_N6ssrlcv8KeyPointE.uty"), H.KEYPOINT)
+    mm, _, _ = read_uty(os.path.join(d, "200_N6ssrlcv10MultiMatchE.uty"), H.MULTIMATCH)
+    assert np.array_equal(mm["index"], gv["mm0"]["index"]) and np.array_equal(mm["numKeyPoints"], gv["mm0"]["numKeyPoints"])
+    assert np.array_equal(kp["parentId"], gv["kp0"]["parentId"]) and np.array_equal(kp["loc"], gv["kp0"]["loc"])
+
+
 def _filter_numpy(lib, mm, kp, cams, nview):
     """doFiltering restated with numpy + oracle primitives (test-side checker):
     linearCutoffFilter(100) [2-view only] then deterministicStatisticalFilter(3 sigma, 10 %)."""
