@@ -25,6 +25,7 @@
 #include <chrono>
 #include <cstdio>
 #include <vector>
+#include "dev_switch.h"
 #include "ssrlcv_hip.h"
 
 namespace {
@@ -171,7 +172,7 @@ int ssrlcv_merge_matches_host_mode(uint32_t numImages, const uint32_t* numFeatur
   mem.clear();
   L.V = numImages;
   const uint32_t V = numImages;
-  static const bool timing = std::getenv("SSRLCV_MERGE_TIMING") != nullptr;
+  static const bool timing = svdev::env("SSRLCV_MERGE_TIMING") != nullptr;
   auto t0 = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
     if (!timing) return;
@@ -304,7 +305,7 @@ int ssrlcv_merge_matches_host(uint32_t numImages, const uint32_t* numFeatures, u
   // measured at 9-22 ms right after it; with a team of 16 the merge itself jittered between 10 and 180 ms).  So the
   // default is the sequential walk; SSRLCV_MERGE_THREADS=<n> enables the parallel one where the cores are really there.
   static const int threads = [] {
-    if (const char* e = std::getenv("SSRLCV_MERGE_THREADS")) return std::atoi(e) > 0 ? std::atoi(e) : 1;
+    if (const char* e = svdev::env("SSRLCV_MERGE_THREADS")) return std::atoi(e) > 0 ? std::atoi(e) : 1;
     return 1;
   }();
   if (threads <= 1)

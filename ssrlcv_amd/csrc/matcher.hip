@@ -30,6 +30,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include "compact.h"
+#include "dev_switch.h"
 #include "device_math.h"
 #include "spatial_sort.h"
 #include "ssrlcv_hip.h"
@@ -570,7 +571,7 @@ int run_match(const ssrlcv_sift_feature* query, uint32_t nq, const ssrlcv_sift_f
     if (rc) return rc;
   }
   // Integer formulation (matcher_i8.inc) by default; SSRLCV_MATCH_F16=1 selects the fp16 one (same results).
-  static const bool useF16 = getenv("SSRLCV_MATCH_F16") != nullptr;
+  static const bool useF16 = svdev::env("SSRLCV_MATCH_F16") != nullptr;
   if (useF16) {
     hipLaunchKernelGGL(k_pack, dim3((L.nq_pad * 16 + 255) / 256), dim3(256), 0, st, query, nq, L.nq_pad, 0, permQ, pq, nqv,
                        (ssrlcv_float2*)nullptr);

@@ -20,6 +20,7 @@
 #include <new>
 #include <stdlib.h>
 #include <string.h>
+#include "dev_switch.h"
 #include "device_math.h"
 #include "sift_plan.h"
 #include "ssrlcv_hip.h"
@@ -1405,7 +1406,7 @@ int launch_dogx(const float* const levels[svp::kGauss], const float* levelMinMax
   a.w = (int)w;
   a.h = (int)h;
   a.minAbs = minAbs;
-  static const int forceNpx = getenv("SSRLCV_DOGX_NPX") ? atoi(getenv("SSRLCV_DOGX_NPX")) : 0;
+  static const int forceNpx = svdev::env("SSRLCV_DOGX_NPX") ? atoi(svdev::env("SSRLCV_DOGX_NPX")) : 0;
   bool aligned16 = (w & 3) == 0, aligned8 = (w & 1) == 0;
   for (int b = first; b <= last; ++b) {
     aligned16 = aligned16 && (reinterpret_cast<size_t>(levels[b]) & 15) == 0;
@@ -1451,7 +1452,7 @@ int launch_dogx(const float* const levels[svp::kGauss], const float* levelMinMax
 // u8src (nullable): the convolution's input is the 2x upsample of this u8 image (w/2 x h/2) and `in` is not read; only
 // honoured where upsample_fusable() says so (row-staged VALU kernel on full, aligned strips)
 bool upsample_fusable(uint32_t w, uint32_t h, int taps) {
-  static const bool off = getenv("SSRLCV_NO_UPSAMPLE_FUSION") != nullptr || getenv("SSRLCV_GAUSS_MFMA") != nullptr;
+  static const bool off = svdev::env("SSRLCV_NO_UPSAMPLE_FUSION") != nullptr || svdev::env("SSRLCV_GAUSS_MFMA") != nullptr;
   return !off && taps / 2 <= 8 && w % kTX == 0 && (w & 3) == 0 && (h & 1) == 0;
 }
 
@@ -1501,15 +1502,15 @@ void launch_valu(ConvArgs a, int RT, uint32_t firstColumn, hipStream_t st) {
 // overwrite them in place.  (The first level of octave 0 -- u8 upsample in the loader -- was built on this kernel too:
 // bit-identical, and the stage took the same 1.76-1.77 ms as with k_gauss_strip<6, true>; not kept.)
 int& rm_mask() {
-  static int m = getenv("SSRLCV_GAUSS_RM") ? atoi(getenv("SSRLCV_GAUSS_RM")) : (4 | 8 | 16);
+  static int m = svdev::env("SSRLCV_GAUSS_RM") ? atoi(svdev::env("SSRLCV_GAUSS_RM")) : (4 | 8 | 16);
   return m;
 }
 size_t& rm_min_px() {
-  static size_t v = getenv("SSRLCV_GAUSS_RM_MINPX") ? (size_t)atoll(getenv("SSRLCV_GAUSS_RM_MINPX")) : ((size_t)1 << 24);
+  static size_t v = svdev::env("SSRLCV_GAUSS_RM_MINPX") ? (size_t)atoll(svdev::env("SSRLCV_GAUSS_RM_MINPX")) : ((size_t)1 << 24);
   return v;
 }
 int& rm_rows() {
-  static int r = getenv("SSRLCV_GAUSS_RM_ROWS") ? atoi(getenv("SSRLCV_GAUSS_RM_ROWS")) : 0;
+  static int r = svdev::env("SSRLCV_GAUSS_RM_ROWS") ? atoi(svdev::env("SSRLCV_GAUSS_RM_ROWS")) : 0;
   return r;
 }
 
@@ -1532,7 +1533,7 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
   a.rowsPerBlock = h;
   a.binOut = nullptr;
   if (binned) *binned = false;
-  static const bool noBinFold = getenv("SSRLCV_NO_BIN_FUSION") != nullptr;
+  static const bool noBinFold = svdev::env("SSRLCV_NO_BIN_FUSION") != nullptr;
   const bool canBin = binOut && !noBinFold && (w & 3) == 0 && (h & 1) == 0 && (reinterpret_cast<size_t>(binOut) & 7) == 0;
 #ifdef SSRLCV_LAB
   a.stamps = g_lab_stamps;
@@ -1552,15 +1553,15 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
   // -- the band wastes (16 + 2R - taps) / (16 + 2R) of the matrix pipe, more than half at R = 6, and the VALU kernel is
   // within 12 % of copy speed there.  Default: MFMA from 23 taps up.  SSRLCV_GAUSS_VALU=1 / SSRLCV_GAUSS_MFMA=1 force
   // one of them for every radius.
-  static const bool forceValu = getenv("SSRLCV_GAUSS_VALU") != nullptr, forceMfma = getenv("SSRLCV_GAUSS_MFMA") != nullptr;
-  static const int mfmaMinR = getenv("SSRLCV_GAUSS_MFMA_MINR") ? atoi(getenv("SSRLCV_GAUSS_MFMA_MINR")) : 11;
+  static const bool forceValu = svdev::env("SSRLCV_GAUSS_VALU") != nullptr, forceMfma = svdev::env("SSRLCV_GAUSS_MFMA") != nullptr;
+  static const int mfmaMinR = svdev::env("SSRLCV_GAUSS_MFMA_MINR") ? atoi(svdev::env("SSRLCV_GAUSS_MFMA_MINR")) : 11;
   const bool useMfma = forceMfma || (!forceValu && !u8src && RT >= mfmaMinR);
   // small levels (<= 1024^2): the tile kernel (no marching).  Measured inside build_dog on a 4096^2 image (octave 3 =
   // 1024^2, octave 2 = 2048^2): marching kernels everywhere 2.079 ms, tile kernel for octave 3 2.065, for octaves 2 and
   // 3 2.133 (a 2048^2 level is 1024 tiles, four rounds of one-per-CU blocks).  SSRLCV_GAUSS_TILE_MAXPX=<pixels> moves
   // the threshold (0 = never).  Levels with a side below 64 pixels always go here: it is the one kernel that mirrors with
   // the reference's modulo (the marching kernels reflect once, which needs a side of at least 2R).
-  static const size_t tileMaxPx = getenv("SSRLCV_GAUSS_TILE_MAXPX") ? (size_t)atoll(getenv("SSRLCV_GAUSS_TILE_MAXPX")) : ((size_t)1 << 20);
+  static const size_t tileMaxPx = svdev::env("SSRLCV_GAUSS_TILE_MAXPX") ? (size_t)atoll(svdev::env("SSRLCV_GAUSS_TILE_MAXPX")) : ((size_t)1 << 20);
   const bool tiny = w < 64 || h < 64;
   if (tiny || (!u8src && !forceValu && (size_t)w * h <= tileMaxPx)) {
     if (u8src) return SSRLCV_ERR_INVALID_ARG;
@@ -1639,7 +1640,7 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
   // against 0.608 / 0.673 / 0.771 ms per 16384^2 level at 23 / 33 / 47 taps), but octaves >= 1 run beside the DoG pass
   // of the previous octave, whose resident blocks keep the big ones off the CUs: the narrow strips are used for the
   // smaller levels (build_dog 2.57 -> 2.48 ms per 4096^2 image).  SSRLCV_GAUSS_WIDE=1 / SSRLCV_GAUSS_NARROW=1 force one.
-  static const bool forceWide = getenv("SSRLCV_GAUSS_WIDE") != nullptr, forceNarrow = getenv("SSRLCV_GAUSS_NARROW") != nullptr;
+  static const bool forceWide = svdev::env("SSRLCV_GAUSS_WIDE") != nullptr, forceNarrow = svdev::env("SSRLCV_GAUSS_NARROW") != nullptr;
   const bool wide = R > 24 || forceWide || (!forceNarrow && (size_t)w * h >= ((size_t)1 << 25));
   const uint32_t tw = wide ? 256u : 128u;
   const bool mfmaOk = useMfma && (w & 3) == 0 && (reinterpret_cast<size_t>(in) & 15) == 0 && (reinterpret_cast<size_t>(out) & 15) == 0 &&
@@ -1702,7 +1703,7 @@ PlanAsync* plan_async(const ssrlcv_sift_plan* plan) {
   std::lock_guard<std::mutex> lock(mu);
   if (plan->asyncState == 0) {
     plan->asyncState = -1;
-    if (!getenv("SSRLCV_SIFT_SERIAL")) {
+    if (!svdev::env("SSRLCV_SIFT_SERIAL")) {
       PlanAsync* a = new (std::nothrow) PlanAsync();
       bool ok = a != nullptr;
       auto mk = [&](hipEvent_t& e) { ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
@@ -1717,7 +1718,7 @@ PlanAsync* plan_async(const ssrlcv_sift_plan* plan) {
           Side pr{nullptr, nullptr, nullptr};
           int least = 0, greatest = 0;
           (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-          const int tablePrio = getenv("SSRLCV_SIDE_LOW_PRIORITY") ? least : 0;
+          const int tablePrio = svdev::env("SSRLCV_SIDE_LOW_PRIORITY") ? least : 0;
           ok = hipStreamCreateWithFlags(&pr.chain, hipStreamNonBlocking) == hipSuccess &&
                hipStreamCreateWithPriority(&pr.table, hipStreamNonBlocking, tablePrio) == hipSuccess &&
                hipStreamCreateWithFlags(&pr.chain2, hipStreamNonBlocking) == hipSuccess;
@@ -2057,9 +2058,9 @@ struct DogSchedule {
   unsigned waves;
   DogSchedule() {
     split = 0;
-    if (const char* e = getenv("SSRLCV_DOG_SPLIT")) split = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = svdev::env("SSRLCV_DOG_SPLIT")) split = atoi(e) != 0 ? 1 : 0;
     waves = 14336;
-    if (const char* e = getenv("SSRLCV_DOGX_WAVES")) waves = (unsigned)atoi(e) > 0 ? (unsigned)atoi(e) : 14336;
+    if (const char* e = svdev::env("SSRLCV_DOGX_WAVES")) waves = (unsigned)atoi(e) > 0 ? (unsigned)atoi(e) : 14336;
   }
 };
 }  // namespace
@@ -2077,8 +2078,8 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
   svp::PlanAsync* as = svp::plan_async(plan);
   hipStream_t sd = as ? as->table : st;
   static const DogSchedule sched;
-  static const bool overlapOctaves = getenv("SSRLCV_NO_OCTAVE_OVERLAP") == nullptr;
-  static const int overlapFrom = getenv("SSRLCV_OCTAVE_OVERLAP_FROM") ? atoi(getenv("SSRLCV_OCTAVE_OVERLAP_FROM")) : 2;
+  static const bool overlapOctaves = svdev::env("SSRLCV_NO_OCTAVE_OVERLAP") == nullptr;
+  static const int overlapFrom = svdev::env("SSRLCV_OCTAVE_OVERLAP_FROM") ? atoi(svdev::env("SSRLCV_OCTAVE_OVERLAP_FROM")) : 2;
   hipLaunchKernelGGL(k_init_minmax, dim3(1), dim3(64), 0, st, mmAll, pairs);
   // S1+S2: u8 -> f32 + one 2x upsample (startingOctave = -1)
   float* in = (float*)(ws + plan->off_in0);

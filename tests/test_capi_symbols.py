@@ -95,3 +95,24 @@ def test_sift_plan_layout_is_host_only():
     wide = SiftParams(2, 0.8, 1.5, 64.0, 0)
     assert lib.ssrlcv_sift_plan_create(ctypes.c_uint32(1024), ctypes.c_uint32(1024), ctypes.byref(wide),
                                        ctypes.byref(plan)) == -4
+
+
+def test_release_build_has_no_developer_switches():
+    """`make release` (csrc/Makefile, -DSSRLCV_RELEASE): the same exports, and none of the SSRLCV_* switch names of the
+    developer build survive in it -- svdev::env() (csrc/dev_switch.h) is a constant nullptr there, so a caller's environment
+    cannot choose a code path of the drop-in library."""
+    import subprocess
+    from ssrlcv_amd import _lib
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "ssrlcv_amd", "csrc"), "release"])
+    rel = os.path.join(ROOT, "ssrlcv_amd", "libssrlcv_hip_release.so")
+    lib = ctypes.CDLL(rel)
+    for name in _lib.EXPORTED:
+        assert hasattr(lib, name), name
+    blob = open(rel, "rb").read()
+    dev = open(os.path.join(ROOT, "ssrlcv_amd", "libssrlcv_hip.so"), "rb").read()
+    for name in (b"SSRLCV_GAUSS_VALU", b"SSRLCV_DOGX_NPX", b"SSRLCV_MATCH_F16", b"SSRLCV_SIFT_SERIAL", b"SSRLCV_MERGE_THREADS"):
+        assert name in dev and name not in blob, name
+    # no raw getenv of a switch is left in the hot-path sources
+    for f in ("pyramid.hip", "keypoints.hip", "matcher.hip", "merge.hip", "filter.hip", "pointcloud.hip", "pose.hip", "host_merge.cpp"):
+        src = open(os.path.join(ROOT, "ssrlcv_amd", "csrc", f)).read()
+        assert not re.search(r'(?<![A-Za-z_:])getenv\(', src), f

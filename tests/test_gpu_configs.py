@@ -349,6 +349,34 @@ print("F16 OK")
 """
 
 
+_RELEASE_SCRIPT = r"""
+import os, sys, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import helpers as H
+from ssrlcv_amd import capi, _lib
+assert _lib.LIB_PATH.endswith("libssrlcv_hip_release.so")
+lib = H.oracle()
+img = H.synthetic_image(320, 256, seed=5)
+plan = capi.SiftPlan(320, 256)
+plan.extract(capi.to_dev(img))
+g, o = plan.features_host(H.FEATURE), H.oracle_sift(lib, img)
+assert len(g) == len(o) and len(g) > 50
+H.assert_features_equal(g, o)
+print("RELEASE OK", len(g))
+"""
+
+
+def test_release_build_ignores_the_environment_and_is_bit_exact():
+    """libssrlcv_hip_release.so (csrc/Makefile `release`: the developer switches compiled out) in a child process whose
+    environment sets switches that would change the DEVELOPER build's code path: the features equal the oracle's."""
+    rel = os.path.join(ROOT, "ssrlcv_amd", "libssrlcv_hip_release.so")
+    if not os.path.exists(rel):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "ssrlcv_amd", "csrc"), "release"])
+    env = dict(os.environ, SSRLCV_HIP_LIB=rel, SSRLCV_GAUSS_VALU="1", SSRLCV_DOGX_NPX="1", SSRLCV_SIFT_SERIAL="1", SSRLCV_MATCH_F16="1")
+    r = subprocess.run([sys.executable, "-c", _RELEASE_SCRIPT % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RELEASE OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_fp16_mfma_matcher_is_bit_exact_too():
     """The matcher's fp16-MFMA formulation (v_mfma_f32_32x32x16_f16 with the norms carried as base-1024 digits; what
     the north star names) is selected once per process by SSRLCV_MATCH_F16=1, so it is exercised in a child process:
