@@ -116,3 +116,32 @@ def test_release_build_has_no_developer_switches():
     for f in ("pyramid.hip", "keypoints.hip", "matcher.hip", "merge.hip", "filter.hip", "pointcloud.hip", "pose.hip", "host_merge.cpp"):
         src = open(os.path.join(ROOT, "ssrlcv_amd", "csrc", f)).read()
         assert not re.search(r'(?<![A-Za-z_:])getenv\(', src), f
+
+
+def test_matcher_kernels_register_budget():
+    """The matcher kernels are built for fixed occupancies (__launch_bounds__): the compiler's resource report must stay
+    what the timings were taken with.  Brute force (four query tiles, two waves per SIMD): no scratch at all.  Band-culled
+    (one query tile, six waves per SIMD = 80 VGPRs): it spills 4 VGPRs = 20 bytes per lane, measured faster than five or
+    four waves per SIMD without a spill (match stage of the 4 x 4096^2 flow 23.7 ms against 24.5 / 24.3) -- more than
+    that would be a regression of the compiler or of the kernel."""
+    import subprocess
+    csrc = os.path.join(ROOT, "ssrlcv_amd", "csrc")
+    out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+                          "-fno-slp-vectorize", "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
+                          "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(csrc, "matcher.hip"), "-o", os.devnull],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    usage, name = {}, None
+    for line in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            usage[name] = {}
+        m = re.search(r"remark:\s+([A-Za-z \[\]/]+): (\d+)", line)
+        if m and name:
+            usage[name][m.group(1).strip()] = int(m.group(2))
+    brute = [v for k, v in usage.items() if "k_match_i8ILb0ELi4E" in k]
+    band = [v for k, v in usage.items() if "k_match_i8ILb1ELi1E" in k]
+    assert len(brute) == 1 and len(band) == 1, sorted(usage)
+    assert brute[0]["ScratchSize [bytes/lane]"] == 0 and brute[0]["VGPRs"] <= 256 and brute[0]["Occupancy [waves/SIMD]"] == 2
+    assert band[0]["ScratchSize [bytes/lane]"] <= 24 and band[0]["Occupancy [waves/SIMD]"] == 6, band[0]
