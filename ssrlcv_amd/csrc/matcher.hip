@@ -546,7 +546,10 @@ Layout make_layout(uint32_t nq, uint32_t nt) {
   L.off_permq = take((size_t)L.nq_pad * 4);
   L.off_permt = take((size_t)L.nt_pad * 4);
   L.off_tilebox = take((size_t)(L.nt_pad / 32) * sizeof(Box));
-  L.off_groupbox = take((size_t)((L.nt_pad / 32 + 31) / 32) * sizeof(Box));
+  {  // group boxes, and behind them the super-group boxes (32 groups each)
+    const size_t groups = (L.nt_pad / 32 + 31) / 32;
+    L.off_groupbox = take((groups + (groups + 31) / 32) * sizeof(Box));
+  }
   L.sort_bytes = svm::sort_scratch_bytes(nq > nt ? nq : nt);
   L.off_sort = take(L.sort_bytes);
   L.total = o;
@@ -607,6 +610,9 @@ int run_match(const ssrlcv_sift_feature* query, uint32_t nq, const ssrlcv_sift_f
     hipLaunchKernelGGL(k_tile_boxes, dim3((numTiles + 255) / 256), dim3(256), 0, st, lt, nt, numTiles, tileBox);
     hipLaunchKernelGGL(k_group_boxes, dim3((numGroups + 255) / 256), dim3(256), 0, st, tileBox, numTiles, numGroups,
                        groupBox);
+    const uint32_t numSuper = (numGroups + 31) / 32;  // the same union one level up, stored behind the group boxes
+    hipLaunchKernelGGL(k_group_boxes, dim3((numSuper + 255) / 256), dim3(256), 0, st, (const Box*)groupBox, numGroups, numSuper,
+                       groupBox + numGroups);
     // every wave walks all groups (most are rejected by one box test); target splits only while the grid is small
     const uint32_t qbBand = useF16 ? qblocks : L.nq_pad / kQPerBlock8Band;
     uint32_t splits = 1;

@@ -120,10 +120,9 @@ def test_release_build_has_no_developer_switches():
 
 def test_matcher_kernels_register_budget():
     """The matcher kernels are built for fixed occupancies (__launch_bounds__): the compiler's resource report must stay
-    what the timings were taken with.  Brute force (four query tiles, two waves per SIMD): no scratch at all.  Band-culled
-    (one query tile, six waves per SIMD = 80 VGPRs): it spills 4 VGPRs = 20 bytes per lane, measured faster than five or
-    four waves per SIMD without a spill (match stage of the 4 x 4096^2 flow 23.7 ms against 24.5 / 24.3) -- more than
-    that would be a regression of the compiler or of the kernel."""
+    what the timings were taken with -- no scratch in either.  Brute force: four query tiles, two waves per SIMD.
+    Band-culled: one query tile, five waves per SIMD (six spilled 4 registers in round 3 and 16 with round 4's third box
+    level, which cost more than the sixth wave brings)."""
     import subprocess
     csrc = os.path.join(ROOT, "ssrlcv_amd", "csrc")
     out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
@@ -144,4 +143,4 @@ def test_matcher_kernels_register_budget():
     band = [v for k, v in usage.items() if "k_match_i8ILb1ELi1E" in k]
     assert len(brute) == 1 and len(band) == 1, sorted(usage)
     assert brute[0]["ScratchSize [bytes/lane]"] == 0 and brute[0]["VGPRs"] <= 256 and brute[0]["Occupancy [waves/SIMD]"] == 2
-    assert band[0]["ScratchSize [bytes/lane]"] <= 24 and band[0]["Occupancy [waves/SIMD]"] == 6, band[0]
+    assert band[0]["ScratchSize [bytes/lane]"] == 0 and band[0]["Occupancy [waves/SIMD]"] == 5, band[0]
