@@ -401,12 +401,12 @@ static void refine_one(const octave_t* oc, o_sskeypoint* pkp) {
     inverse3(hess, hinv); /* on det == 0 hinv keeps its previous contents, like the reference */
     for (int r = 0; r < 3; ++r) { /* matrix_util.cu:63-71 multiply(A[3][3], B[3]) */
       float val = 0;
-      for (int c = 0; c < 3; ++c) val += hinv[r][c] * grad[c];
+      for (int c = 0; c < 3; ++c) val = fmaf(hinv[r][c], grad[c], val); /* nvcc's fused chain (oracle_math.h) */
       offset[r] = val;
     }
     for (int c = 0; c < 3; ++c) { /* matrix_util.cu:73-81 multiply(A[3], B[3][3]) */
       float val = 0;
-      for (int r = 0; r < 3; ++r) val += hess[r][c] * grad[r];
+      for (int r = 0; r < 3; ++r) val = fmaf(hess[r][c], grad[r], val);
       temp[c] = val;
     }
     if (fabsf(offset[0]) <= 0.5f && fabsf(offset[1]) <= 0.5f && fabsf(offset[2]) <= 0.5f) {

@@ -256,14 +256,14 @@ __global__ __launch_bounds__(256) void k_refine(const OctaveState* st, ssrlcv_ss
       for (int r = 0; r < 3; ++r) {
         float val = 0;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) val += hinv[r][c] * grad[c];
+        for (int c = 0; c < 3; ++c) val = __builtin_fmaf(hinv[r][c], grad[c], val);  // multiply(): nvcc's fused chain (device_math.h)
         offset[r] = val;
       }
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         float val = 0;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) val += hess[r][c] * grad[r];
+        for (int r = 0; r < 3; ++r) val = __builtin_fmaf(hess[r][c], grad[r], val);
         temp[c] = val;
       }
       if (fabsf(offset[0]) <= 0.5f && fabsf(offset[1]) <= 0.5f && fabsf(offset[2]) <= 0.5f) {
