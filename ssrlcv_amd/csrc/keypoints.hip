@@ -20,6 +20,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include "compact.h"
+#include "scan_lookback.h"
 #include "device_math.h"
 #include "sift_plan.h"
 #include "ssrlcv_hip.h"
@@ -59,6 +60,37 @@ __device__ __forceinline__ DogView dog_view(const LevelSet& L, int b) {
   v.mnDog = L.minmax[2 * b];
   v.rgDog = sv::make_divisor(L.minmax[2 * b + 1] - v.mnDog);
   return v;
+}
+
+// Where a kernel takes its DoG values from: the plan's workspace (Gaussian levels + constants, evaluated per sample) or
+// -- the per-kernel exports over a caller's own ScaleSpace (round 4, end of this file) -- materialised DoG images as
+// upstream holds them in Octave::blurs[b]->pixels at that point of its flow.
+struct PlanSource {
+  LevelSet L;
+  __device__ __forceinline__ DogView view(int b) const { return dog_view(L, b); }
+};
+struct MatView {
+  const float* p;
+  __device__ __forceinline__ float norm(size_t a) const { return p[a]; }
+};
+struct MatSource {
+  const float* const* px;  // device array of the octave's DoG level pointers
+  __device__ __forceinline__ MatView view(int b) const { return MatView{px[b]}; }
+};
+
+// flagEdges' test on one key point (src/FeatureFactory.cu:974-990): D = the view of the level it reads
+template <typename View>
+__device__ __forceinline__ bool edge_response_above(const View& D, const ssrlcv_sskeypoint& kp, int W, float thr) {
+  const int lx = (int)roundf(kp.loc.x), ly = (int)roundf(kp.loc.y);
+#define NS(yy, xx) D.norm((size_t)(yy) * W + (xx))
+  float h00 = -2.0f * NS(ly, lx);
+  float h11 = h00 + NS(ly + 1, lx) + NS(ly - 1, lx);
+  h00 += NS(ly, lx + 1) + NS(ly, lx - 1);
+  float h01 = (NS(ly + 1, lx + 1) - NS(ly - 1, lx + 1) - NS(ly + 1, lx - 1) + NS(ly - 1, lx - 1));
+#undef NS
+  float e = h00 + h11;
+  float det = (h00 * h11) - (h01 * h01);
+  return (e * e / det) > thr;
 }
 
 // ---- bookkeeping (one thread: the last block of the partition that precedes it, see compact.h last_block_post) ----------
@@ -159,18 +191,7 @@ __global__ __launch_bounds__(256) void k_flag_edges(const OctaveState* st, ssrlc
   int n = st->hasExtrema ? st->n : 0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const DogView D = dog_view(L, segment_of(st, i));
-    ssrlcv_sskeypoint kp = kps[i];
-    int lx = (int)roundf(kp.loc.x), ly = (int)roundf(kp.loc.y);
-    int W = L.w;
-#define NS(yy, xx) D.norm((size_t)(yy) * W + (xx))
-    float h00 = -2.0f * NS(ly, lx);
-    float h11 = h00 + NS(ly + 1, lx) + NS(ly - 1, lx);
-    h00 += NS(ly, lx + 1) + NS(ly, lx - 1);
-    float h01 = (NS(ly + 1, lx + 1) - NS(ly - 1, lx + 1) - NS(ly + 1, lx - 1) + NS(ly - 1, lx - 1));
-#undef NS
-    float e = h00 + h11;
-    float det = (h00 * h11) - (h01 * h01);
-    kps[i].discard = (uint8_t)((e * e / det) > thr);
+    kps[i].discard = (uint8_t)edge_response_above(D, kps[i], L.w, thr);
   }
 }
 
@@ -184,20 +205,7 @@ __global__ __launch_bounds__(256) void k_flag_noise_edges_window(const OctaveSta
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     ssrlcv_sskeypoint kp = kps[i];
     bool drop = fabsf(kp.intensity) < noiseThr;
-    {
-      const DogView D = dog_view(L, segment_of(st, i));
-      int lx = (int)roundf(kp.loc.x), ly = (int)roundf(kp.loc.y);
-      int W = L.w;
-#define NS(yy, xx) D.norm((size_t)(yy) * W + (xx))
-      float h00 = -2.0f * NS(ly, lx);
-      float h11 = h00 + NS(ly + 1, lx) + NS(ly - 1, lx);
-      h00 += NS(ly, lx + 1) + NS(ly, lx - 1);
-      float h01 = (NS(ly + 1, lx + 1) - NS(ly - 1, lx + 1) - NS(ly + 1, lx - 1) + NS(ly - 1, lx - 1));
-#undef NS
-      float e = h00 + h11;
-      float det = (h00 * h11) - (h01 * h01);
-      drop = drop || ((e * e / det) > edgeThr);
-    }
+    drop = drop || edge_response_above(dog_view(L, segment_of(st, i)), kp, L.w, edgeThr);
     float ww = kp.sigma * lambda / pixelWidth;
     drop = drop || (kp.loc.x - ww) < 0.0f || (kp.loc.y - ww) < 0.0f || (kp.loc.x + ww) >= (unsigned)(L.w - 1) ||
            (kp.loc.y + ww) >= (unsigned)(L.h - 1);
@@ -218,84 +226,89 @@ __global__ __launch_bounds__(256) void k_flag_window(const OctaveState* st, ssrl
 }
 
 // ---- S10: refineLocation (src/FeatureFactory.cu:892-967) -----------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_refine(const OctaveState* st, ssrlcv_sskeypoint* kps, LevelSet L, float sigmaMin,
-                                                float mult) {
-  int n = st->hasExtrema ? st->n : 0;
-  const int W = L.w, H = L.h;
-  const int numBlurs = svp::kDog;
-  for (int gi = blockIdx.x * 256 + threadIdx.x; gi < n; gi += gridDim.x * 256) {
-    ssrlcv_sskeypoint kp = kps[gi];
-    int lx = (int)roundf(kp.loc.x), ly = (int)roundf(kp.loc.y);
-    float hess[3][3], hinv[3][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
-    float grad[3], temp[3], offset[3] = {0.0f, 0.0f, 0.0f};
-    int bl = kp.blur;
-    for (int attempt = 0; attempt < 5; ++attempt) {
-      const DogView Dl = dog_view(L, bl - 1), Dm = dog_view(L, bl), Du = dog_view(L, bl + 1);
+// refineLocation on one key point (src/FeatureFactory.cu:892-967); src.view(b) = DoG level b as it is at that point
+template <typename Src>
+__device__ __forceinline__ void refine_one(ssrlcv_sskeypoint& kp, int W, int H, int numBlurs, float sigmaMin, float mult, const Src& src) {
+  int lx = (int)roundf(kp.loc.x), ly = (int)roundf(kp.loc.y);
+  float hess[3][3], hinv[3][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+  float grad[3], temp[3], offset[3] = {0.0f, 0.0f, 0.0f};
+  int bl = kp.blur;
+  for (int attempt = 0; attempt < 5; ++attempt) {
+    const auto Dl = src.view(bl - 1), Dm = src.view(bl), Du = src.view(bl + 1);
 #define PM(yy, xx) Dm.norm((size_t)(yy) * W + (xx))
 #define PL(yy, xx) Dl.norm((size_t)(yy) * W + (xx))
 #define PU(yy, xx) Du.norm((size_t)(yy) * W + (xx))
-      grad[0] = PM(ly, lx + 1) - PM(ly, lx - 1);
-      grad[1] = PM(ly + 1, lx) - PM(ly - 1, lx);
-      grad[2] = PU(ly, lx) - PL(ly, lx);
-      float centre = PM(ly, lx);
-      hess[0][0] = grad[0] - 2 * centre;
-      hess[0][1] = (PM(ly + 1, lx + 1) - PM(ly - 1, lx + 1) - PM(ly + 1, lx - 1) + PM(ly - 1, lx - 1)) / 4.0f;
-      hess[0][2] = (PU(ly, lx + 1) - PL(ly, lx + 1) - PU(ly, lx - 1) + PL(ly, lx - 1)) / 4.0f;
-      hess[1][0] = hess[0][1];
-      hess[1][1] = grad[1] - 2 * centre;
-      hess[1][2] = (PU(ly + 1, lx) - PL(ly + 1, lx) - PU(ly - 1, lx) + PL(ly - 1, lx)) / 4.0f;
-      hess[2][0] = hess[0][2];
-      hess[2][1] = hess[1][2];
-      hess[2][2] = grad[2] - 2 * centre;
+    grad[0] = PM(ly, lx + 1) - PM(ly, lx - 1);
+    grad[1] = PM(ly + 1, lx) - PM(ly - 1, lx);
+    grad[2] = PU(ly, lx) - PL(ly, lx);
+    float centre = PM(ly, lx);
+    hess[0][0] = grad[0] - 2 * centre;
+    hess[0][1] = (PM(ly + 1, lx + 1) - PM(ly - 1, lx + 1) - PM(ly + 1, lx - 1) + PM(ly - 1, lx - 1)) / 4.0f;
+    hess[0][2] = (PU(ly, lx + 1) - PL(ly, lx + 1) - PU(ly, lx - 1) + PL(ly, lx - 1)) / 4.0f;
+    hess[1][0] = hess[0][1];
+    hess[1][1] = grad[1] - 2 * centre;
+    hess[1][2] = (PU(ly + 1, lx) - PL(ly + 1, lx) - PU(ly - 1, lx) + PL(ly - 1, lx)) / 4.0f;
+    hess[2][0] = hess[0][2];
+    hess[2][1] = hess[1][2];
+    hess[2][2] = grad[2] - 2 * centre;
 #pragma unroll
-      for (int r = 0; r < 3; ++r)
+    for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) hess[r][c] *= -1.0f;
-      sv::inverse3(hess, hinv);
+      for (int c = 0; c < 3; ++c) hess[r][c] *= -1.0f;
+    sv::inverse3(hess, hinv);
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        float val = 0;
+    for (int r = 0; r < 3; ++r) {
+      float val = 0;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) val = __builtin_fmaf(hinv[r][c], grad[c], val);  // multiply(): nvcc's fused chain (device_math.h)
-        offset[r] = val;
-      }
+      for (int c = 0; c < 3; ++c) val = __builtin_fmaf(hinv[r][c], grad[c], val);  // multiply(): nvcc's fused chain (device_math.h)
+      offset[r] = val;
+    }
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        float val = 0;
+    for (int c = 0; c < 3; ++c) {
+      float val = 0;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) val = __builtin_fmaf(hess[r][c], grad[r], val);
-        temp[c] = val;
-      }
-      if (fabsf(offset[0]) <= 0.5f && fabsf(offset[1]) <= 0.5f && fabsf(offset[2]) <= 0.5f) {
-        kp.loc.x = (float)lx + offset[0];
-        kp.loc.y = (float)ly + offset[1];
-        lx = (int)roundf(kp.loc.x);
-        ly = (int)roundf(kp.loc.y);
-        kp.discard = (uint8_t)(lx <= 0 || ly <= 0 || lx >= W - 1 || ly >= H - 1);
-        if (kp.discard) break;
-        kp.intensity = PM(ly, lx) - (0.5f * ((temp[0] * grad[0]) + (temp[1] * grad[1]) + (temp[2] * grad[2])));
-        kp.sigma = sigmaMin * sv_powf(mult, ((float)bl + offset[2]));
-        if (fabsf(offset[2]) > 0.5) bl += (offset[2] > 0) ? 1 : -1;
-        break;
-      } else if (attempt == 4) {
+      for (int r = 0; r < 3; ++r) val = __builtin_fmaf(hess[r][c], grad[r], val);
+      temp[c] = val;
+    }
+    if (fabsf(offset[0]) <= 0.5f && fabsf(offset[1]) <= 0.5f && fabsf(offset[2]) <= 0.5f) {
+      kp.loc.x = (float)lx + offset[0];
+      kp.loc.y = (float)ly + offset[1];
+      lx = (int)roundf(kp.loc.x);
+      ly = (int)roundf(kp.loc.y);
+      kp.discard = (uint8_t)(lx <= 0 || ly <= 0 || lx >= W - 1 || ly >= H - 1);
+      if (kp.discard) break;
+      kp.intensity = PM(ly, lx) - (0.5f * ((temp[0] * grad[0]) + (temp[1] * grad[1]) + (temp[2] * grad[2])));
+      kp.sigma = sigmaMin * sv_powf(mult, ((float)bl + offset[2]));
+      if (fabsf(offset[2]) > 0.5) bl += (offset[2] > 0) ? 1 : -1;
+      break;
+    } else if (attempt == 4) {
+      kp.discard = 1;
+      break;
+    } else {
+      if (fabsf(offset[0]) > 0.5) lx += (offset[0] > 0) ? 1 : -1;
+      if (fabsf(offset[1]) > 0.5) ly += (offset[1] > 0) ? 1 : -1;
+      kp.loc.x = (float)lx;
+      kp.loc.y = (float)ly;
+      if (fabsf(offset[2]) > 0.5) bl += (offset[2] > 0) ? 1 : -1;
+      if (bl >= numBlurs - 1 || bl <= 0 || lx <= 0 || ly <= 0 || lx >= W - 1 || ly >= H - 1) {
         kp.discard = 1;
         break;
-      } else {
-        if (fabsf(offset[0]) > 0.5) lx += (offset[0] > 0) ? 1 : -1;
-        if (fabsf(offset[1]) > 0.5) ly += (offset[1] > 0) ? 1 : -1;
-        kp.loc.x = (float)lx;
-        kp.loc.y = (float)ly;
-        if (fabsf(offset[2]) > 0.5) bl += (offset[2] > 0) ? 1 : -1;
-        if (bl >= numBlurs - 1 || bl <= 0 || lx <= 0 || ly <= 0 || lx >= W - 1 || ly >= H - 1) {
-          kp.discard = 1;
-          break;
-        }
       }
+    }
 #undef PM
 #undef PL
 #undef PU
-    }
-    kp.blur = bl;
+  }
+  kp.blur = bl;
+}
+
+__global__ __launch_bounds__(256) void k_refine(const OctaveState* st, ssrlcv_sskeypoint* kps, LevelSet L, float sigmaMin,
+                                                float mult) {
+  int n = st->hasExtrema ? st->n : 0;
+  const PlanSource src{L};
+  for (int gi = blockIdx.x * 256 + threadIdx.x; gi < n; gi += gridDim.x * 256) {
+    ssrlcv_sskeypoint kp = kps[gi];
+    refine_one(kp, L.w, L.h, svp::kDog, sigmaMin, mult, src);
     kps[gi] = kp;
   }
 }
@@ -1436,6 +1449,398 @@ int ssrlcv_hip_sift_stage(const ssrlcv_sift_plan* plan, void* workspace, int sta
   book_features(plan, ws, numFeatures, caller);
   if (stage == 7) rc = stage_descriptors(plan, ws, features, caller);
   if (rc) return rc;
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
+}
+
+// =====================================================================================================================
+// Per-kernel entry points over the CALLER's buffers (round 4): one call per launch site of
+// FeatureFactory::ScaleSpace / SIFT_FeatureFactory, for a maintainer who keeps upstream's ScaleSpace objects (DoG images in
+// Octave::blurs[b]->pixels, Unity<SSKeyPoint> lists, extremaBlurIndices on the host) and swaps kernels one at a time.
+// These are the plain forms -- they read materialised DoG images and whole gradient arrays like the kernels they replace,
+// not the plan's fused workspace -- with the plan path's arithmetic: same device functions (refine_one,
+// edge_response_above, sv_math.h), the descriptor sums in the order-independent form of DESIGN.md section 2.
+}  // extern "C"
+namespace {
+// findExtrema (src/FeatureFactory.cu:847-882): non-strict 3x3x3 maximum / minimum; border pixels are not written
+__global__ __launch_bounds__(256) void k_x_find_extrema(int W, int H, const float* __restrict__ up, const float* __restrict__ mid,
+                                                        const float* __restrict__ low, int* __restrict__ extrema) {
+  const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (size_t)W * H) return;
+  const int x = (int)(id % W), y = (int)(id / W);
+  if (!(x > 0 && y > 0 && x < W - 1 && y < H - 1)) return;
+  const float v = mid[id];
+  float mx = -FLT_MAX, mn = FLT_MAX;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const size_t a = (size_t)(y + dy) * W + (x + dx);
+      mx = fmaxf(mx, fmaxf(low[a], fmaxf(mid[a], up[a])));
+      mn = fminf(mn, fminf(low[a], fminf(mid[a], up[a])));
+    }
+  extrema[id] = (mx == v || mn == v) ? (int)id : -1;
+}
+// fillExtrema (:883-890)
+__global__ __launch_bounds__(256) void k_x_fill_extrema(int n, int W, int octave, int blur, float sigma, const int* __restrict__ addr,
+                                                        const float* __restrict__ pixels, ssrlcv_sskeypoint* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int index = addr[i];
+  ssrlcv_sskeypoint kp;
+  kp.octave = octave;
+  kp.blur = blur;
+  kp.loc.x = (float)(index % W);
+  kp.loc.y = (float)(index / W);
+  kp.intensity = pixels[index];
+  kp.sigma = sigma;
+  kp.theta = -1.0f;
+  kp.discard = 0;
+  out[i] = kp;
+}
+__global__ __launch_bounds__(256) void k_x_flag_noise(uint32_t n, ssrlcv_sskeypoint* kps, float thr) {  // :968-973
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) kps[i].discard = (uint8_t)(fabsf(kps[i].intensity) < thr);
+}
+__global__ __launch_bounds__(256) void k_x_flag_edges(uint32_t n, uint32_t start, int W, ssrlcv_sskeypoint* kps, const float* pixels,
+                                                      float thr) {  // :974-990
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) kps[start + i].discard = (uint8_t)edge_response_above(MatView{pixels}, kps[start + i], W, thr);
+}
+__global__ __launch_bounds__(256) void k_x_check(uint32_t n, uint32_t start, int W, int H, float pixelWidth, float lambda,
+                                                 ssrlcv_sskeypoint* kps) {  // src/SIFT_FeatureFactory.cu:449-461: only ever SETS the flag
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const ssrlcv_sskeypoint kp = kps[start + i];
+  const float ww = kp.sigma * lambda / pixelWidth;
+  if ((kp.loc.x - ww) < 0.0f || (kp.loc.y - ww) < 0.0f || (kp.loc.x + ww) >= (unsigned)(W - 1) || (kp.loc.y + ww) >= (unsigned)(H - 1))
+    kps[start + i].discard = 1;
+}
+__global__ __launch_bounds__(256) void k_x_refine(uint32_t n, int W, int H, float sigmaMin, float mult, int numBlurs, MatSource src,
+                                                  ssrlcv_sskeypoint* kps) {  // :892-967
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  ssrlcv_sskeypoint kp = kps[i];
+  refine_one(kp, W, H, numBlurs, sigmaMin, mult, src);
+  kps[i] = kp;
+}
+// calculatePixelGradients (src/Image.cu:1583-1598): a border pixel takes the stencil of its inner neighbour
+__device__ __forceinline__ float2 x_gradient(const float* __restrict__ px, int W, int H, int x, int y) {
+  int xc0 = x + 1, xc1 = x - 1, yc0 = y + 1, yc1 = y - 1;
+  if (xc1 == -1) { xc0 += 1; xc1 += 1; }
+  else if (xc0 == W) { xc0 -= 1; xc1 -= 1; }
+  if (yc1 == -1) { yc0 += 1; yc1 += 1; }
+  else if (yc0 == H) { yc0 -= 1; yc1 -= 1; }
+  float2 g;
+  g.x = px[(size_t)y * W + xc0] - px[(size_t)y * W + xc1];
+  g.y = px[(size_t)yc0 * W + x] - px[(size_t)yc1 * W + x];
+  return g;
+}
+__global__ __launch_bounds__(256) void k_x_gradients(int W, int H, const float* __restrict__ px, float2* __restrict__ grad) {
+  const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (id < (size_t)W * H) grad[id] = x_gradient(px, W, H, (int)(id % W), (int)(id / W));
+}
+// computeThetas (src/FeatureFactory.cu:1004-1112): one thread per key point, the reference's own shape (its sequential
+// fmaf chain per bin is part of the result).  thetas / thetaNumbers: n x maxOrientations, -FLT_MAX / -1 = none.
+__global__ __launch_bounds__(64) void k_x_thetas(uint32_t n, uint32_t start, int W, int H, float pixelWidth, float lambda,
+                                                 const ssrlcv_sskeypoint* __restrict__ kps, const float2* __restrict__ grad,
+                                                 int* __restrict__ thetaNumbers, uint32_t maxO, float orientationThreshold,
+                                                 float* __restrict__ thetas) {
+  const uint32_t gi = blockIdx.x * 64 + threadIdx.x;
+  if (gi >= n) return;
+  const float pi = 3.1415927f;
+  const ssrlcv_sskeypoint kp = kps[start + gi];
+  const int regNumOrient = (int)(maxO > 8u ? 8u : maxO);
+  for (int i = 0; i < regNumOrient; ++i) { thetas[(size_t)gi * maxO + i] = -FLT_MAX; thetaNumbers[(size_t)gi * maxO + i] = -1; }
+  const float kx = kp.loc.x, ky = kp.loc.y;
+  const float windowWidth = ceilf(kp.sigma * 3.0f * lambda / pixelWidth);
+  const float minx = kx - windowWidth, miny = ky - windowWidth, maxx = kx + windowWidth, maxy = ky + windowWidth;
+  if (minx < 0.0f || miny < 0.0f || maxx >= (unsigned)(W - 1) || maxy >= (unsigned)(H - 1)) return;
+  float hist[36];
+  for (int i = 0; i < 36; ++i) hist[i] = 0.0f;
+  const float weight = 2.0f * lambda * lambda * kp.sigma * kp.sigma;
+  const float rad10 = pi / 18.0f;
+  for (float y = miny; y <= maxy; y += 1.0f) {
+    for (float x = minx; x <= maxx; x += 1.0f) {
+      const float2 g = grad[(size_t)llroundf(y) * W + (size_t)llroundf(x)];
+      const float tx = x - kx, ty = y - ky;
+      const float angle = fmodf(sv_atan2f(g.y, g.x) + (2.0f * pi), 2.0f * pi);
+      const int bin = (int)floorf(angle / rad10);
+      const float mag = sqrtf((g.x * g.x) + (g.y * g.y));
+      const float wgt = sv_expf(-((tx * tx) + (ty * ty)) / weight);
+      // dynamic index into the per-thread histogram: a select chain keeps it in registers
+#pragma unroll
+      for (int b = 0; b < 36; ++b)
+        if (b == bin) hist[b] = __builtin_fmaf(mag, wgt, hist[b]);
+    }
+  }
+  float maxHist = 0.0f;
+  for (int i = 0; i < 36; ++i)
+    if (hist[i] > maxHist) maxHist = hist[i];
+  maxHist *= orientationThreshold;
+  float bx[8], by[8];
+  for (int i = 0; i < 8; ++i) { bx[i] = 0.0f; by[i] = 0.0f; }
+  for (int b = 0; b < 36; ++b) {
+    const float hb = hist[b], hp = hist[b == 0 ? 35 : b - 1], hn = hist[b == 35 ? 0 : b + 1];
+    if (hb < maxHist || hb < hp || hb < hn || hb < bx[regNumOrient - 1]) continue;
+    float tx = hb;
+    float ty = (hp - hn) / (hp - (2.0f * hb) + hn);
+    ty *= (pi / 36.0f);
+    ty += (b * rad10);
+    ty = fmodf(ty + (2.0f * pi), 2.0f * pi);
+    for (int i = 0; i < regNumOrient; ++i) {
+      if (tx > bx[i]) {
+        for (int ii = i; ii < regNumOrient; ++ii) {
+          const float sx = bx[ii], sy = by[ii];
+          bx[ii] = tx;
+          by[ii] = ty;
+          tx = sx;
+          ty = sy;
+        }
+      }
+    }
+  }
+  for (int i = 0; i < regNumOrient; ++i) {
+    if (bx[i] != 0.0f) {
+      thetas[(size_t)gi * maxO + i] = by[i];
+      thetaNumbers[(size_t)gi * maxO + i] = (int)(start + gi);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_x_expand(uint32_t n, const ssrlcv_sskeypoint* __restrict__ in, ssrlcv_sskeypoint* __restrict__ out,
+                                                  const int* __restrict__ thetaAddresses, const float* __restrict__ thetas) {  // :1114-1122
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  ssrlcv_sskeypoint kp = in[thetaAddresses[i]];
+  kp.theta = thetas[i];
+  out[i] = kp;
+}
+// fillDescriptors (src/SIFT_FeatureFactory.cu:475-549): one wave per key point; the votes are the reference's expressions,
+// the 128 bins are summed as integers (vote x 2^k rounded half up: order independent), the norms as
+// balanced trees -- the definition k_descriptors and the oracle share.
+__global__ __launch_bounds__(64) void k_x_descriptors(uint32_t n, uint32_t start, int W, int H, float pixelWidth, float lambda,
+                                                      const ssrlcv_sskeypoint* __restrict__ kps, const float2* __restrict__ grad,
+                                                      ssrlcv_sift_feature* __restrict__ features) {
+  __shared__ unsigned s_bins[128];
+  const uint32_t gi = blockIdx.x;
+  if (gi >= n) return;
+  const int lane = threadIdx.x;
+  const float pi = 3.1415927f;
+  const ssrlcv_sskeypoint kp = kps[start + gi];
+  s_bins[lane] = 0u;
+  s_bins[lane + 64] = 0u;
+  __syncthreads();
+  const float kx = kp.loc.x, ky = kp.loc.y, theta = kp.theta;
+  const float windowWidth = ceilf(kp.sigma * lambda / pixelWidth);
+  const float binWidth = windowWidth / 2.0f, rad45 = pi / 4.0f;
+  const float c = sv_cosf(-theta), s = sv_sinf(-theta);
+  int boundExp;
+  (void)frexpf(1.4143f * ((windowWidth + 2.0f) * (windowWidth + 2.0f)), &boundExp);
+  const float voteScale = ldexpf(1.0f, 31 - boundExp);
+  const int iw = (int)windowWidth, side = 2 * iw + 1;
+  for (int sIdx = lane; sIdx < side * side; sIdx += 64) {
+    const float y = (float)(sIdx / side - iw), x = (float)(sIdx % side - iw);
+    const float cx = (x * c) + (y * s), cy = (-x * s) + (y * c);
+    if (fabsf(cx) > windowWidth || fabsf(cy) > windowWidth) continue;
+    const long long flat = llroundf(cy + ky) * (long long)W + llroundf(cx + kx);
+    float2 g;
+    g.x = g.y = 0.0f;
+    if (flat >= 0 && flat < (long long)W * H) g = grad[flat];
+    const float mag = sqrtf((g.x * g.x) + (g.y * g.y)) * sv_expf(-((cx * cx) + (cy * cy)) / (2.0f * windowWidth * windowWidth));
+    const float ang = fmodf(sv_atan2f(g.y, g.x) - theta + (2.0f * pi), 2.0f * pi);
+    for (int nx = 0; nx < 4; ++nx) {
+      for (int ny = 0; ny < 4; ++ny) {
+        float hx = ((float)nx * 0.5f - 0.75f) * windowWidth, hy = ((float)ny * 0.5f - 0.75f) * windowWidth;
+        const float rx = (hx * c) + (hy * s), ry = (-hx * s) + (hy * c);
+        hx = fabsf(rx - cx);
+        hy = fabsf(ry - cy);
+        if (hx <= binWidth && hy <= binWidth) {
+          hx = hx / binWidth;
+          hy = hy / binWidth;
+          for (int k = 0; k < 8; ++k) {
+            float angle = fabsf(ang - ((float)k * rad45));
+            if (angle < rad45) {
+              angle /= rad45;
+              const float temp = (1.0f - hx) * (1.0f - hy) * (1.0f - angle) * mag;
+              const float q = temp * voteScale, f = floorf(q);
+              atomicAdd(&s_bins[(nx * 4 + ny) * 8 + k], (unsigned)f + ((q - f) >= 0.5f ? 1u : 0u));
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // bins in [nx][ny][k] order: lane l holds elements l and l + 64; both norms as balanced trees (pairs 64 apart first)
+  float v0 = (float)s_bins[lane], v1 = (float)s_bins[lane + 64];
+  float sq = sqrtf(sv::wave_sum((v0 * v0) + (v1 * v1)));
+  v0 /= sq;
+  v1 /= sq;
+  v0 = v0 > 0.2f ? 0.2f : v0;
+  v1 = v1 > 0.2f ? 0.2f : v1;
+  sq = sqrtf(sv::wave_sum((v0 * v0) + (v1 * v1)));
+  ssrlcv_sift_feature* ft = features + gi;
+  // values[(ny * 4 + nx) * 8 + k] = bin[nx][ny][k]
+  {
+    const int e0 = lane, e1 = lane + 64;
+    const int nx0 = e0 >> 5, ny0 = (e0 >> 3) & 3, k0 = e0 & 7, nx1 = e1 >> 5, ny1 = (e1 >> 3) & 3, k1 = e1 & 7;
+    ft->values[(ny0 * 4 + nx0) * 8 + k0] = (uint8_t)roundf(255.0f * v0 / sq);
+    ft->values[(ny1 * 4 + nx1) * 8 + k1] = (uint8_t)roundf(255.0f * v1 / sq);
+  }
+  if (lane == 0) {
+    ft->theta = kp.theta;
+    ft->sigma = kp.sigma;
+    ft->loc.x = kp.loc.x * pixelWidth;
+    ft->loc.y = kp.loc.y * pixelWidth;
+  }
+}
+// thrust::remove / remove_if in place, order kept, one pass: a tile's kept elements land at or below where they were read,
+// inside the regions of tiles that loaded their elements before they published the aggregate this tile waited for
+template <typename T, typename Drop>
+__global__ __launch_bounds__(svs::kThreads) void k_x_remove_if(T* data, uint32_t n, Drop drop, uint32_t* __restrict__ count, svs::TileScan<1> ts) {
+  constexpr int ITEMS = 4;
+  constexpr uint32_t kTile = svs::kThreads * ITEMS;
+  for (uint32_t tile = svs::next_tile(ts.counter); tile < ts.numTiles; tile = svs::next_tile(ts.counter)) {
+    const uint32_t base = tile * kTile + threadIdx.x * ITEMS;
+    T v[ITEMS];
+    bool keep[ITEMS];
+    uint32_t mine[1] = {0};
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      keep[j] = false;
+      if (base + j < n) {
+        v[j] = data[base + j];
+        keep[j] = !drop(v[j]);
+      }
+      mine[0] += keep[j] ? 1u : 0u;
+    }
+    uint32_t excl[1], total[1], prefix[1];
+    svs::block_exclusive<1>(mine, excl, total);  // (its barriers: every element of the tile is in registers before a store)
+    svs::tile_prefix<1>(ts, tile, total, prefix);
+    uint32_t at = prefix[0] + excl[0];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j)
+      if (keep[j]) data[at++] = v[j];
+    if (tile == ts.numTiles - 1 && threadIdx.x == 0) *count = prefix[0] + total[0];
+  }
+}
+struct DropMinusOne { __device__ bool operator()(int v) const { return v == -1; } };
+struct DropFlagged { __device__ bool operator()(const ssrlcv_sskeypoint& k) const { return k.discard != 0; } };
+struct DropNegMax { __device__ bool operator()(float v) const { return v == -FLT_MAX; } };
+template <typename T, typename Drop>
+int x_remove_if(T* data, uint32_t n, uint32_t* count_dev, void* workspace, size_t workspaceBytes, hipStream_t st) {
+  if (!count_dev) return SSRLCV_ERR_INVALID_ARG;
+  if (n == 0) return (int)hipMemsetAsync(count_dev, 0, 4, st);
+  if (!data || !workspace) return SSRLCV_ERR_INVALID_ARG;
+  const uint32_t tiles = (n + svs::kThreads * 4 - 1) / (svs::kThreads * 4);
+  if (workspaceBytes < svs::workspace_bytes<1>(tiles)) return SSRLCV_ERR_WORKSPACE;
+  SSRLCV_HIP_TRY(hipMemsetAsync(workspace, 0, svs::workspace_bytes<1>(tiles), st));
+  hipLaunchKernelGGL((k_x_remove_if<T, Drop>), dim3(tiles < 2048u ? tiles : 2048u), dim3(svs::kThreads), 0, st, data, n, Drop(), count_dev,
+                     svs::make_tile_scan<1>(workspace, tiles));
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
+}
+inline unsigned xb(size_t n) { return (unsigned)((n + 255) / 256); }
+}  // namespace
+extern "C" {
+
+int ssrlcv_hip_find_extrema(uint32_t w, uint32_t h, const float* pixelsUpper, const float* pixelsMiddle, const float* pixelsLower,
+                            int* extrema, ssrlcv_stream_t stream) {
+  if (!pixelsUpper || !pixelsMiddle || !pixelsLower || !extrema || w < 3 || h < 3) return SSRLCV_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(k_x_find_extrema, dim3(xb((size_t)w * h)), dim3(256), 0, (hipStream_t)stream, (int)w, (int)h, pixelsUpper, pixelsMiddle,
+                     pixelsLower, extrema);
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
+}
+size_t ssrlcv_hip_compact_workspace_bytes(uint32_t n) { return svs::workspace_bytes<1>((n + svs::kThreads * 4 - 1) / (svs::kThreads * 4) + 1); }
+int ssrlcv_hip_compact_addresses(int* addresses, uint32_t n, uint32_t* count_dev, void* workspace, size_t workspaceBytes,
+                                 ssrlcv_stream_t stream) {
+  return x_remove_if<int, DropMinusOne>(addresses, n, count_dev, workspace, workspaceBytes, (hipStream_t)stream);
+}
+int ssrlcv_hip_compact_thetas(float* thetas, uint32_t n, uint32_t* count_dev, void* workspace, size_t workspaceBytes, ssrlcv_stream_t stream) {
+  return x_remove_if<float, DropNegMax>(thetas, n, count_dev, workspace, workspaceBytes, (hipStream_t)stream);
+}
+int ssrlcv_hip_compact_keypoints(ssrlcv_sskeypoint* keyPoints, uint32_t n, uint32_t* count_dev, void* workspace, size_t workspaceBytes,
+                                 ssrlcv_stream_t stream) {
+  return x_remove_if<ssrlcv_sskeypoint, DropFlagged>(keyPoints, n, count_dev, workspace, workspaceBytes, (hipStream_t)stream);
+}
+int ssrlcv_hip_fill_extrema(uint32_t numKeyPoints, uint32_t w, uint32_t h, int octave, int blur, float sigma, const int* extremaAddresses,
+                            const float* pixels, ssrlcv_sskeypoint* keyPoints, ssrlcv_stream_t stream) {
+  (void)h;
+  if (numKeyPoints == 0) return SSRLCV_OK;
+  if (!extremaAddresses || !pixels || !keyPoints || w == 0) return SSRLCV_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(k_x_fill_extrema, dim3(xb(numKeyPoints)), dim3(256), 0, (hipStream_t)stream, (int)numKeyPoints, (int)w, octave, blur, sigma,
+                     extremaAddresses, pixels, keyPoints);
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
+}
+int ssrlcv_hip_flag_noise(uint32_t numKeyPoints, ssrlcv_sskeypoint* keyPoints, float threshold, ssrlcv_stream_t stream) {
+  if (numKeyPoints == 0) return SSRLCV_OK;
+  if (!keyPoints) return SSRLCV_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(k_x_flag_noise, dim3(xb(numKeyPoints)), dim3(256), 0, (hipStream_t)stream, numKeyPoints, keyPoints, threshold);
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
+}
+int ssrlcv_hip_refine_location(uint32_t numKeyPoints, uint32_t w, uint32_t h, float sigmaMin, float blurSigmaMultiplier, uint32_t numBlurs,
+                               const float* const* pixels_dev, ssrlcv_sskeypoint* keyPoints, ssrlcv_stream_t stream) {
+  if (numKeyPoints == 0) return SSRLCV_OK;
+  if (!pixels_dev || !keyPoints || w < 3 || h < 3 || numBlurs < 3) return SSRLCV_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(k_x_refine, dim3(xb(numKeyPoints)), dim3(256), 0, (hipStream_t)stream, numKeyPoints, (int)w, (int)h, sigmaMin,
+                     blurSigmaMultiplier, (int)numBlurs, MatSource{pixels_dev}, keyPoints);
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
+}
+int ssrlcv_hip_flag_edges(uint32_t numKeyPoints, uint32_t startingIndex, uint32_t w, uint32_t h, ssrlcv_sskeypoint* keyPoints,
+                          const float* pixels, float threshold, ssrlcv_stream_t stream) {
+  (void)h;
+  if (numKeyPoints == 0) return SSRLCV_OK;
+  if (!keyPoints || !pixels || w < 3) return SSRLCV_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(k_x_flag_edges, dim3(xb(numKeyPoints)), dim3(256), 0, (hipStream_t)stream, numKeyPoints, startingIndex, (int)w, keyPoints,
+                     pixels, threshold);
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
+}
+int ssrlcv_hip_check_keypoints(uint32_t numKeyPoints, uint32_t keyPointIndex, uint32_t w, uint32_t h, float pixelWidth, float lambda,
+                               ssrlcv_sskeypoint* keyPoints, ssrlcv_stream_t stream) {
+  if (numKeyPoints == 0) return SSRLCV_OK;
+  if (!keyPoints) return SSRLCV_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(k_x_check, dim3(xb(numKeyPoints)), dim3(256), 0, (hipStream_t)stream, numKeyPoints, keyPointIndex, (int)w, (int)h, pixelWidth,
+                     lambda, keyPoints);
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
+}
+int ssrlcv_hip_pixel_gradients(uint32_t w, uint32_t h, const float* pixels, ssrlcv_float2* gradients, ssrlcv_stream_t stream) {
+  if (!pixels || !gradients || w < 2 || h < 2) return SSRLCV_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(k_x_gradients, dim3(xb((size_t)w * h)), dim3(256), 0, (hipStream_t)stream, (int)w, (int)h, pixels, (float2*)gradients);
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
+}
+int ssrlcv_hip_compute_thetas(uint32_t numKeyPoints, uint32_t keyPointIndex, uint32_t w, uint32_t h, float pixelWidth, float lambda,
+                              const ssrlcv_sskeypoint* keyPoints, const ssrlcv_float2* gradients, int* thetaNumbers, uint32_t maxOrientations,
+                              float orientationThreshold, float* thetas, ssrlcv_stream_t stream) {
+  if (numKeyPoints == 0) return SSRLCV_OK;
+  if (!keyPoints || !gradients || !thetaNumbers || !thetas || maxOrientations == 0 || maxOrientations > 8) return SSRLCV_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(k_x_thetas, dim3((numKeyPoints + 63) / 64), dim3(64), 0, (hipStream_t)stream, numKeyPoints, keyPointIndex, (int)w, (int)h,
+                     pixelWidth, lambda, keyPoints, (const float2*)gradients, thetaNumbers, maxOrientations, orientationThreshold, thetas);
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
+}
+int ssrlcv_hip_expand_keypoints(uint32_t numKeyPoints, const ssrlcv_sskeypoint* keyPointsIn, ssrlcv_sskeypoint* keyPointsOut,
+                                const int* thetaAddresses, const float* thetas, ssrlcv_stream_t stream) {
+  if (numKeyPoints == 0) return SSRLCV_OK;
+  if (!keyPointsIn || !keyPointsOut || !thetaAddresses || !thetas) return SSRLCV_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(k_x_expand, dim3(xb(numKeyPoints)), dim3(256), 0, (hipStream_t)stream, numKeyPoints, keyPointsIn, keyPointsOut, thetaAddresses,
+                     thetas);
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
+}
+int ssrlcv_hip_fill_descriptors(uint32_t numFeatures, uint32_t keyPointIndex, uint32_t w, uint32_t h, ssrlcv_sift_feature* features,
+                                float pixelWidth, float lambda, const ssrlcv_sskeypoint* keyPoints, const ssrlcv_float2* gradients,
+                                ssrlcv_stream_t stream) {
+  if (numFeatures == 0) return SSRLCV_OK;
+  if (!features || !keyPoints || !gradients) return SSRLCV_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(k_x_descriptors, dim3(numFeatures), dim3(64), 0, (hipStream_t)stream, numFeatures, keyPointIndex, (int)w, (int)h, pixelWidth,
+                     lambda, keyPoints, (const float2*)gradients, features);
   SSRLCV_LAUNCH_CHECK();
   return SSRLCV_OK;
 }
