@@ -137,7 +137,7 @@ def test_list_kernels_stage_by_stage(ctx, o):
     n = discard(kp_d, len(l4))
     l5, _ = _octave_slice(stages[5], o)
     _same(capi.to_host(kp_d, H.SSKEYPOINT, n), l5)
-    assert len(l1) < len(l0) and len(l5) > 0
+    assert len(l5) > 0 and (o != 0 or len(l1) < len(l0))
 
 
 @pytest.mark.parametrize("o", [0, 1])
