@@ -136,7 +136,7 @@ def bench_matcher(capi, torch, nq, nt, iters):
                                    "north star names: frac_of_fp16_peak is the same rate against that); "
                                    "sustained_peak_random_operands = the same instruction alone on random bytes "
                                    "(tools/mfma_i8_peak.hip: the part is power-limited there, 4.96 POP/s on zeros); "
-                                   "matrix-pipe busy cycles and clock: profiles/r03_matcher_pmc.txt"}}
+                                   "matrix-pipe busy cycles and clock: profiles/r04_matcher_pmc.txt"}}
 
 
 def bench_matcher_epipolar(capi, torch, n, size, iters):
@@ -325,8 +325,8 @@ def describe_roofline(ms_per_image, features, size):
     """Roofline of the key-point stage.  Its kernels are bound by vector-instruction issue (the sampling kernels) or move
     little data, so the stage is priced against the VALU issue peak with the wave-instruction count of the committed PMC
     reduction (instructions per feature do not depend on the run; the time does), and its algorithmic bytes against HBM
-    beside it.  Per-kernel fractions come from the PMC run's own image and time (profiles/r03_describe_pmc.json)."""
-    path = os.path.join(ROOT, "profiles", "r03_describe_pmc.json")
+    beside it.  Per-kernel fractions come from the PMC run's own image and time (profiles/r04_describe_pmc.json)."""
+    path = os.path.join(ROOT, "profiles", "r04_describe_pmc.json")
     out = {"ms_per_image": ms_per_image, "features_per_image": features,
            "ns_per_feature": ms_per_image * 1e6 / max(features, 1),
            "kernels": "flag-byte compaction, k_refine, k_flag_*, list partitions, k_polar, k_thetas, k_desc_consts, k_descriptors "
@@ -350,7 +350,7 @@ def describe_roofline(ms_per_image, features, size):
                                                         "valu_frac": None if v.get("valu_frac") is None else round(v["valu_frac"], 3),
                                                         "hbm_frac": None if v.get("hbm_frac") is None else round(v["hbm_frac"], 3)}
                                                     for k, v in pmc.get("per_kernel", {}).items()},
-                        "pmc_source": "profiles/r03_describe_pmc.json @ %s (its own image: %d features)" % (pmc.get("commit"), pmc.get("features_per_image", 0))})
+                        "pmc_source": "profiles/r04_describe_pmc.json @ %s (its own image: %d features)" % (pmc.get("commit"), pmc.get("features_per_image", 0))})
     return out
 
 
@@ -481,12 +481,12 @@ def main():
     line = None
     if rank == 0:
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r03_pyramid_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r04_pyramid_traffic.json")
         if W == 4096 and H_ == 4096 and os.path.exists(tpath):
             # HBM bytes of the pyramid stage per image from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the stage
             # benchmark (collected off-line: counters cannot be read from inside the timed run)
             tj = json.load(open(tpath))
-            traffic, traffic_src = tj["pyramid_stage_bytes_per_image"], "profiles/r03_pyramid_traffic.json @ %s" % tj.get("commit")
+            traffic, traffic_src = tj["pyramid_stage_bytes_per_image"], "profiles/r04_pyramid_traffic.json @ %s" % tj.get("commit")
         pixels_per_step = world * args.images * W * H_
         value = pixels_per_step * args.steps / dt / 1e6
         # Algorithmic bytes of the stage.  `frac` is priced on SURVEY.md 8(d)'s / BASELINE.md section 4's own figure,

@@ -322,11 +322,53 @@ def ba_parameter_sets(cameras2, h_lin=1e-5, h_step=(1e-4, 1e-4, 1e-4, 1e-5, 1e-5
     return np.stack(sets)
 
 
-def ba_error_sweep(mm, kp, cameras, pair=(0, 1), params=None):
+def _ba_subset_device(dev, n_mm, pair, world, rank):
+    """The 2-view bundles of `pair` out of the device copy of the MatchSet, this rank's share of them, as a 2-camera
+    MatchSet on the device (torch index arithmetic: plumbing, no host round trip of the arrays).
+    -> (MultiMatch bytes, KeyPoint bytes, bundles of this rank, bundles of the pair)"""
+    mm_i = dev["matches"][: 8 * n_mm].view(torch.int32).view(-1, 2)          # {numKeyPoints, index}
+    kp_i = dev["keypoints"].view(torch.int32).view(-1, 4)                     # {parentId, pad, loc.x, loc.y}
+    idx = mm_i[:, 1].long()
+    two = (mm_i[:, 0] == 2)
+    idx2 = torch.where(two, idx, torch.zeros_like(idx))
+    sel = two & (kp_i[idx2, 0] == pair[0]) & (kp_i[torch.clamp(idx2 + 1, max=kp_i.shape[0] - 1), 0] == pair[1])
+    rows = torch.nonzero(sel).view(-1)
+    total = int(rows.numel())
+    lo, hi = sd.bundle_range(total, world, rank)
+    rows = rows[lo:hi]
+    n = hi - lo
+    sub_kp = torch.zeros((2 * n, 4), dtype=torch.int32, device=kp_i.device)
+    if n:
+        first = idx[rows]
+        sub_kp[0::2] = kp_i[first]
+        sub_kp[1::2] = kp_i[first + 1]
+        sub_kp[0::2, 0] = 0
+        sub_kp[1::2, 0] = 1
+    sub_mm = torch.empty((n, 2), dtype=torch.int32, device=kp_i.device)
+    sub_mm[:, 0] = 2
+    sub_mm[:, 1] = 2 * torch.arange(n, dtype=torch.int32, device=kp_i.device)
+    return sub_mm.view(torch.uint8).view(-1), sub_kp.view(torch.uint8).view(-1), n, total
+
+
+def ba_error_sweep(mm, kp, cameras, pair=(0, 1), params=None, dev=None):
     """f(params_k) = sum of squared skew-line gaps of the 2-view bundles of `pair`, for all K parameter sets: this rank's
     bundle range in one launch (ssrlcv_hip_ba_sweep2), then all-reduce(sum) over the ranks.  Returns a K-vector on the
-    device (identical on every rank up to the float all-reduce)."""
+    device (identical on every rank up to the float all-reduce).  `dev`: the device copies of the MatchSet left by
+    build_match_set / apply_filters; with them the pair's bundles are selected on the device."""
     world, rank = _world()
+    if dev and "matches" in dev and "keypoints" in dev and len(mm):
+        cams2 = cameras[[pair[0], pair[1]]].copy()
+        if params is None:
+            params = ba_parameter_sets(cams2)
+        K = len(params)
+        sub_mm_d, sub_kp_d, n, total = _ba_subset_device(dev, len(mm), pair, world, rank)
+        sums = torch.zeros(K, dtype=torch.float32, device="cuda")
+        if n:
+            sums = capi.ba_sweep2(sub_mm_d, sub_kp_d, n, capi.to_dev(cams2), 2,
+                                  torch.from_numpy(np.ascontiguousarray(params, np.float32)).cuda(), K)
+        if world > 1:
+            sd.all_reduce_sum(sums)
+        return sums, total
     two = np.nonzero(mm["numKeyPoints"] == 2)[0]
     if len(two):
         first = kp["parentId"][mm["index"][two]]
@@ -425,7 +467,7 @@ def reconstruct(pixel_tensors_all, cameras, seed_features=None, epsilon=25.0, de
            "device": dev}   # device copies of the MatchSet ("matches", "keypoints"), e.g. for further apply_filters steps
     if ba and pushbroom is None:
         t = time.perf_counter()
-        out["ba_sums"], out["ba_bundles"] = ba_error_sweep(mm, kp, cameras)
+        out["ba_sums"], out["ba_bundles"] = ba_error_sweep(mm, kp, cameras, dev=dev)
         torch.cuda.synchronize()
         ws.tick("ba_sweep", t)
     return out

@@ -75,6 +75,7 @@ def test_config3_four_view_4096_flow(capi):
     assert sums.shape == (612,) and np.isfinite(sums).all() and res["ba_bundles"] > 10000
     two = np.nonzero(mm["numKeyPoints"] == 2)[0]
     two = two[(kp["parentId"][mm["index"][two]] == 0) & (kp["parentId"][mm["index"][two] + 1] == 1)]
+    assert res["ba_bundles"] == len(two)        # the flow selects the pair's bundles on the device (round 4)
     sub_mm = np.zeros(len(two), H.MULTIMATCH)
     sub_mm["numKeyPoints"], sub_mm["index"] = 2, 2 * np.arange(len(two))
     sub_kp = np.zeros(2 * len(two), H.KEYPOINT)
