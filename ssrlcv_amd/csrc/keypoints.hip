@@ -1267,6 +1267,90 @@ OctaveSet make_set(const ssrlcv_sift_plan* plan, char* ws, uint32_t* unitBlocks)
   return set;
 }
 
+// ---- expandKeyPoints + the two thrust::remove calls in front of it (src/FeatureFactory.cu:594-611) in ONE pass (round 4).
+// Element e = i * maxO + j is "orientation j of key point i"; it is kept when j < thetaCnt[i] and lands at its rank among
+// the kept ones -- the list is sorted by blur segment and the order is kept, so the output is grouped by segment like
+// upstream's per-blur loop builds it.  Rounds 1-3 ran the generic count -> scan -> scatter partition (three launches per
+// octave between k_thetas and k_descriptors); here a tile takes its prefix by decoupled look-back (scan_lookback.h).
+// The new extremaBlurIndices need no counting: idx'[s] = the number of kept elements in front of segment s = the running
+// offset of the thread that meets element idx[s] * maxO.  The bookkeeping runs in the last block to leave.
+struct ExpandCtl {
+  uint32_t* segStart;  // [kDog] offset + 1 of the first element of every segment (0 = not met: the segment starts at the end)
+  uint32_t* total;     // kept elements
+  uint32_t* done;      // blocks that have left
+};
+__global__ __launch_bounds__(svs::kThreads) void k_expand_orient(OctaveState* st, const ssrlcv_sskeypoint* __restrict__ src,
+                                                                 ssrlcv_sskeypoint* __restrict__ dst, const float* __restrict__ thetas,
+                                                                 const uint32_t* __restrict__ thetaCnt, uint32_t maxO, uint32_t cap,
+                                                                 svs::TileScan<1> ts, ExpandCtl ctl) {
+  constexpr int ITEMS = 4;
+  constexpr uint32_t kTile = svs::kThreads * ITEMS;
+  // read BEFORE anything of this launch can rewrite the state (the bookkeeping below waits for every block)
+  const uint32_t n = st->hasExtrema && st->n > 0 ? (uint32_t)st->n : 0u;
+  const uint32_t elems = n * maxO;
+  const uint32_t tiles = (elems + kTile - 1) / kTile;  // <= ts.numTiles (sized for the capacity)
+  uint32_t segFirst[svp::kDog];
+#pragma unroll
+  for (int k = 0; k < svp::kDog; ++k) segFirst[k] = (uint32_t)st->idx[k] * maxO;
+  for (uint32_t tile = svs::next_tile(ts.counter); tile < tiles; tile = svs::next_tile(ts.counter)) {
+    const uint32_t base = tile * kTile + threadIdx.x * ITEMS;
+    bool keep[ITEMS];
+    uint32_t mine[1] = {0};
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      const uint32_t e = base + j, i = e / maxO;
+      keep[j] = e < elems && (e - i * maxO) < thetaCnt[i];
+      mine[0] += keep[j] ? 1u : 0u;
+    }
+    uint32_t excl[1], total[1], prefix[1];
+    svs::block_exclusive<1>(mine, excl, total);
+    svs::tile_prefix<1>(ts, tile, total, prefix);
+    uint32_t at = prefix[0] + excl[0];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      const uint32_t e = base + j;
+      if (e < elems) {
+#pragma unroll
+        for (int k = 0; k < svp::kDog; ++k)
+          if (segFirst[k] == e) ctl.segStart[k] = at + 1u;
+      }
+      if (keep[j]) {
+        if (at < cap) {
+          const uint32_t i = e / maxO;
+          ssrlcv_sskeypoint kp = src[i];
+          kp.theta = thetas[(size_t)i * svp::kMaxOrient + (e - i * maxO)];
+          dst[at] = kp;
+        }
+        ++at;
+      }
+    }
+    if (tile == tiles - 1 && threadIdx.x == 0) *ctl.total = prefix[0] + total[0];
+  }
+  // bookkeeping (book_orient's): after EVERY block has left its loop -- a block that starts late must still read the old n
+  __shared__ bool s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    s_last = atomicAdd(ctl.done, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (s_last && threadIdx.x == 0) {
+    __threadfence();
+    if (st->hasExtrema) {
+      const uint32_t total = __hip_atomic_load(ctl.total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int b = 0; b < svp::kDog; ++b) {
+        const uint32_t enc = __hip_atomic_load(&ctl.segStart[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t start = enc ? enc - 1u : total;  // a segment nobody met lies behind the last element
+        st->idx[b] = (int)(start < cap ? start : cap);
+      }
+      uint32_t kept = total;
+      if (kept > cap) { st->overflow = 1; kept = cap; }  // truncated: what lies past cap was not written
+      st->n = (int)kept;
+      if (kept == 0) st->hasExtrema = 0;
+    }
+  }
+}
+
 // computeKeyPointOrientations (src/FeatureFactory.cu:540-632) for all octaves: gradient tables (unless the caller built
 // them on a side stream already), one orientation launch, the expansion of every key point into its orientations
 int stage_orientations(const ssrlcv_sift_plan* plan, char* ws, hipStream_t caller, svp::PlanAsync* as, bool polarDone) {
@@ -1306,25 +1390,23 @@ int stage_orientations(const ssrlcv_sift_plan* plan, char* ws, hipStream_t calle
     ssrlcv_sskeypoint* dst = (ssrlcv_sskeypoint*)(ws + (plan->listInB[o] ? oc.off_kpA : oc.off_kpB));
     const float* thetas = set.thetas[o];
     const uint32_t* thetaCnt = set.thetaCnt[o];
-    auto keyfn = [=] __device__(uint32_t e2) -> uint32_t {
-      uint32_t i = e2 / maxO, j = e2 - i * maxO;
-      if (!cst->hasExtrema || (int)i >= cst->n) return 0u;
-      if (j >= thetaCnt[i]) return 0u;
-      return 1u << segment_of(cst, (int)i);
-    };
-    auto emit = [=] __device__(uint32_t e2, int, uint32_t d) {
-      if (d >= cap) return;
-      uint32_t i = e2 / maxO, j = e2 - i * maxO;
-      ssrlcv_sskeypoint kp = src[i];
-      kp.theta = thetas[(size_t)i * svp::kMaxOrient + j];
-      dst[d] = kp;
-    };
-    uint32_t* totals = nullptr;
-    OctaveState* sto = states + o;
-    auto post = [=] __device__(const uint32_t* tot) { book_orient(sto, tot, cap); };
-    hipError_t e = svc::partition<svp::kDog, 8>(cap * maxO, keyfn, emit, (uint32_t*)(ws + oc.off_part), &totals, es,
-                                                &states[o].n, maxO, post);
-    if (e != hipSuccess) return (int)e;
+    (void)cst;
+    {
+      // scan descriptors + control words live in the octave's partition scratch
+      const uint32_t capTiles = (cap * maxO + svs::kThreads * 4 - 1) / (svs::kThreads * 4);
+      char* part = ws + oc.off_part;
+      const size_t scanBytes = svs::workspace_bytes<1>(capTiles);
+      SSRLCV_HIP_TRY(hipMemsetAsync(part, 0, scanBytes + 64, es));
+      ExpandCtl ctl;
+      ctl.segStart = (uint32_t*)(part + scanBytes);
+      ctl.total = ctl.segStart + svp::kDog;
+      ctl.done = ctl.total + 1;
+      // a grid for the usual list lengths (a tenth of the capacity), persistent over the tiles
+      unsigned blocks = capTiles / 8 + 1;
+      blocks = blocks > 1024u ? 1024u : blocks;
+      hipLaunchKernelGGL(k_expand_orient, dim3(blocks), dim3(svs::kThreads), 0, es, states + o, src, dst, thetas, thetaCnt, maxO, cap,
+                         svs::make_tile_scan<1>(part, capTiles), ctl);
+    }
     plan->listInB[o] ^= 1;
   }
   if (as) {
