@@ -226,59 +226,302 @@ __device__ __forceinline__ bool passes_prefilter(const Geom& g, ssrlcv_float2 t,
 
 // ---- band culling (modes 1 / 2) ---------------------------------------------------------------------------------------
 // The reference evaluates the prefilter per (query, target) pair and skips the distance when it fails; a brute-force
-// MFMA pass computes every distance first.  With both feature sets in spatial order (spatial_sort.hip) a 32-target tile
-// has a small bounding box, and a whole tile (or a group of 32 tiles) can be skipped when no query of the wave has a
-// band that touches the box.  The test is conservative (margins for the rounding of the per-pair test, NaN geometry
-// counts as a hit), the per-pair prefilter still runs on every surviving candidate, so results are unchanged.
-struct Box { float x0, y0, x1, y1; };
+// MFMA pass computes every distance first.  Here a whole 32-target tile (a group of 32 tiles, a super-group of 32
+// groups) is skipped when no query of the wave has a band that can reach it.  The test is conservative (margins for
+// every rounding involved, non-finite geometry counts as a hit) and the per-pair prefilter still runs on every
+// surviving candidate, so results are unchanged; what the order of the two sets decides is only how much is culled.
+//
+// Round 4: the frame of the pair.  Both sets used to be ordered by (64-pixel image-row strip, x).  A wave's 32 queries
+// then sit in a 20 x 64 pixel patch of the QUERY image, their bands -- near-parallel segments of the target image --
+// spread over up to 64 pixels across the band direction, and a target tile is 64 pixels across as well: the wave computed
+// every target within ~90 pixels of its bands where a query accepts 25 (epsilon), three of four candidates failed the
+// per-pair test in the epilogue's slow path.  Now
+//   * u = the dominant direction of the queries' bands in the target image (axial mean, k_band_direction); the frame
+//     (w, v) = (u . p, u_perp . p) has w along the bands and v across them;
+//   * targets are ordered by (v strip of kStrip pixels, w): a tile is kStrip pixels across the bands and long along them;
+//   * queries are ordered by WHERE THEIR BAND LIES in that frame (v strip of the band's centre, then its w), not by where
+//     they are in their own image: the 32 bands of a wave nearly coincide;
+//   * boxes and bands are compared in the frame: a band is the line v = vc + slope (w - wc), |w - wc| <= hw, thickened by
+//     `half` (BandR, formed in double precision from the Geom of the exact test), a box is centre + half extents, and the
+//     test is 8 vector instructions with no per-test margin arithmetic (the margins are folded into hw / half / the boxes).
+// With horizontal epipolar lines (the bench scenes) this equals 16-pixel row strips, which alone took the match stage of
+// the 4 x 4096^2 flow from 22.4 to 14.6 ms; the frame makes that independent of the direction of the baseline.
+struct Frame {        // device-resident, written by k_band_direction / k_target_keys
+  float ux, uy;       // unit vector along the bands (target image)
+  int wminI, wmaxI, vminI, vmaxI;  // order-preserving integer images of the targets' frame bounds (ord_of)
+};
+struct BandR { float wc, hw, slope, vc, half, pad0, pad1, pad2; };  // 32 bytes
+struct Box { float wc, vc, hw, hv; };                                // centre and half extents in the frame
+
+__device__ __forceinline__ int ord_of(float f) {  // monotone float -> int
+  int i = __builtin_bit_cast(int, f);
+  return i >= 0 ? i : (int)(0x80000000u - (unsigned)i);
+}
+__device__ __forceinline__ float of_ord(int i) {
+  return __builtin_bit_cast(float, i >= 0 ? i : (int)(0x80000000u - (unsigned)i));
+}
+__device__ __forceinline__ bool finite_f(float x) { return fabsf(x) <= FLT_MAX; }
+
+#ifndef SSRLCV_BAND_STRIP
+#define SSRLCV_BAND_STRIP 16.0f
+#endif
+
+// u from the axial mean of the band directions: sum of (cos 2a, sin 2a) over a sample of the queries.  One block; the
+// summation order is fixed, so u is reproducible.  forceDeg < 1e9 (developer builds, tests): take that direction instead.
+__global__ __launch_bounds__(1024) void k_band_direction(const Geom* __restrict__ geomU, uint32_t nq, int mode, float forceDeg,
+                                                         Frame* __restrict__ frame) {
+  __shared__ double s_c[1024], s_s[1024];
+  double c2 = 0.0, s2 = 0.0;
+  const uint32_t stride = (nq + 4095u) / 4096u;  // at most 4096 samples: four per thread (one block: latency, not work)
+  for (uint32_t i = threadIdx.x * (stride ? stride : 1); i < nq; i += 1024u * (stride ? stride : 1)) {
+    const Geom g = geomU[i];
+    double dx, dy;  // a vector along the band
+    if (mode == 2) { dx = g.hi_x; dy = -(double)g.lo_x; }
+    else if (g.vertical != 0.0f) { dx = 0.0; dy = 1.0; }
+    else { dx = 1.0; dy = g.slope; }
+    const double n2 = dx * dx + dy * dy;
+    if (n2 > 0.0 && n2 < 1e300) {  // (false for NaN / inf)
+      c2 += (dx * dx - dy * dy) / n2;
+      s2 += 2.0 * dx * dy / n2;
+    }
+  }
+  s_c[threadIdx.x] = c2;
+  s_s[threadIdx.x] = s2;
+  __syncthreads();
+  for (unsigned o = 512; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { s_c[threadIdx.x] += s_c[threadIdx.x + o]; s_s[threadIdx.x] += s_s[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double a = 0.5 * atan2(s_s[0], s_c[0]);  // atan2(0, 0) = 0: no dominant direction -> the image rows
+    if (forceDeg < 1e9f) a = (double)forceDeg * (3.14159265358979323846 / 180.0);
+    float ux = (float)cos(a), uy = (float)sin(a);
+    if (!finite_f(ux) || !finite_f(uy)) { ux = 1.0f; uy = 0.0f; }
+    frame->ux = ux;
+    frame->uy = uy;
+    frame->wminI = frame->vminI = 0x7fffffff;
+    frame->wmaxI = frame->vmaxI = (int)0x80000000;
+  }
+}
+
+// (strip << 16) | position: both clamped to 16 bits around an offset of 32 768 (frame coordinates of any image up to
+// 23 000 pixels on a side fit; beyond, keys saturate -- any order is correct, only culling suffers).  NaN -> 0.
+__device__ __forceinline__ uint32_t frame_key(float w, float v, float invStrip) {
+  const float vs = fminf(fmaxf(floorf(v * invStrip) + 32768.0f, 0.0f), 65535.0f);
+  const float wp = fminf(fmaxf(floorf(w) + 32768.0f, 0.0f), 65535.0f);
+  return ((uint32_t)vs << 16) | (uint32_t)wp;
+}
+
+// sort keys of the targets; mode 2 (infinite bands) also needs the bounds of the target set in the frame: per-block
+// reduction + 4 atomics per block (same-address atomics serialise at ~50 ns: one set per WAVE cost 1.3 ms for 413 000 targets)
+__global__ __launch_bounds__(256) void k_target_keys(const ssrlcv_sift_feature* __restrict__ feats, uint32_t n, Frame* __restrict__ frame,
+                                                     float invStrip, int wantBounds, uint32_t* __restrict__ keys,
+                                                     uint32_t* __restrict__ iota) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  const float ux = frame->ux, uy = frame->uy;
+  int w0 = 0x7fffffff, w1 = (int)0x80000000, v0 = 0x7fffffff, v1 = (int)0x80000000;
+  if (i < n) {
+    const ssrlcv_float2 l = feats[i].loc;
+    const float w = ux * l.x + uy * l.y, v = ux * l.y - uy * l.x;
+    keys[i] = frame_key(w, v, invStrip);
+    iota[i] = i;
+    if (finite_f(w) && finite_f(v)) { w0 = w1 = ord_of(w); v0 = v1 = ord_of(v); }
+  }
+  if (!wantBounds) return;  // (uniform)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    w0 = min(w0, __shfl_xor(w0, o, 64)); w1 = max(w1, __shfl_xor(w1, o, 64));
+    v0 = min(v0, __shfl_xor(v0, o, 64)); v1 = max(v1, __shfl_xor(v1, o, 64));
+  }
+  __shared__ int s_b[4][4];
+  if ((threadIdx.x & 63) == 0) {
+    const int wv = threadIdx.x >> 6;
+    s_b[wv][0] = w0; s_b[wv][1] = w1; s_b[wv][2] = v0; s_b[wv][3] = v1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; ++k) {
+      w0 = min(w0, s_b[k][0]); w1 = max(w1, s_b[k][1]); v0 = min(v0, s_b[k][2]); v1 = max(v1, s_b[k][3]);
+    }
+    if (w0 <= w1) {
+      atomicMin(&frame->wminI, w0); atomicMax(&frame->wmaxI, w1);
+      atomicMin(&frame->vminI, v0); atomicMax(&frame->vmaxI, v1);
+    }
+  }
+}
+
+// The band of one query in the frame, from the Geom its exact per-pair test uses.  Real-number derivation (the frame map
+// is LINEAR in the float values ux, uy taken as exact): a point that passes the test is (x, L(x) + e) with
+// lo_x <= x <= hi_x, |e| <= epsilon, L(x) = slope (x - left_x) + left_y.  With A = ux + uy slope, B = ux slope - uy:
+//   w = A x + Cw + uy e,  v = B x + Cv + ux e   =>   v = s' (w - wc) + vc + e (ux - s' uy),  s' = B / A,
+// so the band is the image of the centre segment, `half` = epsilon |ux - s' uy| thick in v, and
+// |w - wc| <= |A| (hi_x - lo_x) / 2 + |uy| epsilon.  A band nearly across the frame (|A| small: an outlier of the pair's
+// geometry) and the reference's `vertical` case (a rectangle) are bounded by their frame-aligned hull instead (slope 0).
+// Margins: 0.25 px absolute (the exact test's own float rounding at image-sized coordinates), 1e-5 of every magnitude
+// that enters the test (huge coordinates), and the conversion to float.  Non-finite input -> a band that meets
+// everything (the per-pair test passes on NaN); lo_x > hi_x (padding rows) -> a band that meets nothing.
+__device__ BandR make_bandr(const Geom& g, int mode, float epsilon, float uxf, float uyf, float targetRadius) {
+  BandR r;
+  r.pad0 = r.pad1 = r.pad2 = 0.0f;
+  const float kInf = __builtin_inff();
+  auto meets_all = [&]() { r.wc = 0.0f; r.hw = kInf; r.slope = 0.0f; r.vc = 0.0f; r.half = kInf; };
+  const double ux = uxf, uy = uyf, e = fabs((double)epsilon);
+  if (!(fabsf(epsilon) <= FLT_MAX)) { meets_all(); return r; }
+  if (mode == 2) {  // a x + b y + c = 0 as (lo_x, hi_x, left_x): |y + (a x + c) / b| <= epsilon, all x
+    const double a = g.lo_x, b = g.hi_x, c = g.left_x;
+    if (!(fabs(a) <= 1e300) || !(fabs(b) <= 1e300) || !(fabs(c) <= 1e300) || b == 0.0) { meets_all(); return r; }
+    const double s = -a / b, y0 = -c / b;
+    const double A = ux + uy * s, B = ux * s - uy;
+    if (!(fabs(A) >= 0.05 * sqrt(1.0 + s * s))) { meets_all(); return r; }  // an infinite band across the frame
+    const double sp = B / A;
+    const double vc = ux * y0 - sp * (uy * y0);  // the image of (0, y0), moved along the line to w = 0
+    const double gm = 1e-5 * (fabs(y0) * (1.0 + fabs(s)) + fabs(vc)) + 1e-5 * (fabs(s) + fabs(sp)) * (double)targetRadius;
+    r.wc = 0.0f; r.hw = kInf; r.slope = (float)sp; r.vc = (float)vc;
+    r.half = (float)(e * fabs(ux - sp * uy) + 0.25 + gm);
+    if (!finite_f(r.slope) || !finite_f(r.vc) || !finite_f(r.half)) meets_all();
+    return r;
+  }
+  const double lo = g.lo_x, hi = g.hi_x;
+  if (!(fabs(lo) <= 1e300) || !(fabs(hi) <= 1e300)) { meets_all(); return r; }
+  if (lo > hi) { r.wc = 0.0f; r.hw = -kInf; r.slope = 0.0f; r.vc = 0.0f; r.half = 0.0f; return r; }
+  double w0, v0, w1, v1, sp = 0.0, half, mag;
+  bool hull = false;
+  if (g.vertical != 0.0f) {  // the rectangle [lo, hi] x [top, bottom] (both already widened by epsilon)
+    const double t = g.top, bt = g.bottom;
+    if (!(fabs(t) <= 1e300) || !(fabs(bt) <= 1e300)) { meets_all(); return r; }
+    const double cw[4] = {ux * lo + uy * t, ux * lo + uy * bt, ux * hi + uy * t, ux * hi + uy * bt};
+    const double cv[4] = {ux * t - uy * lo, ux * bt - uy * lo, ux * t - uy * hi, ux * bt - uy * hi};
+    w0 = fmin(fmin(cw[0], cw[1]), fmin(cw[2], cw[3])); w1 = fmax(fmax(cw[0], cw[1]), fmax(cw[2], cw[3]));
+    v0 = fmin(fmin(cv[0], cv[1]), fmin(cv[2], cv[3])); v1 = fmax(fmax(cv[0], cv[1]), fmax(cv[2], cv[3]));
+    mag = fabs(lo) + fabs(hi) + fabs(t) + fabs(bt);
+    const double gm = 1e-5 * mag;
+    r.wc = (float)(0.5 * (w0 + w1)); r.hw = (float)(0.5 * (w1 - w0) + 1e-3 + gm);
+    r.slope = 0.0f;
+    r.vc = (float)(0.5 * (v0 + v1)); r.half = (float)(0.5 * (v1 - v0) + 0.25 + gm);
+    if (!finite_f(r.wc) || !finite_f(r.vc)) meets_all();
+    return r;
+  }
+  const double s = g.slope, xl = g.left_x, yl = g.left_y;
+  if (!(fabs(s) <= 1e300) || !(fabs(xl) <= 1e300) || !(fabs(yl) <= 1e300)) { meets_all(); return r; }
+  const double ylo = s * (lo - xl) + yl, yhi = s * (hi - xl) + yl;
+  w0 = ux * lo + uy * ylo; v0 = ux * ylo - uy * lo;
+  w1 = ux * hi + uy * yhi; v1 = ux * yhi - uy * hi;
+  const double A = ux + uy * s, B = ux * s - uy;
+  mag = fabs(lo) + fabs(hi) + fabs(xl) + fabs(yl) + fabs(ylo) + fabs(yhi);
+  const double gm = 1e-5 * mag;
+  if (fabs(A) >= 0.05 * sqrt(1.0 + s * s)) {
+    sp = B / A;
+    half = e * fabs(ux - sp * uy) + 0.25 + gm;
+  } else {
+    hull = true;
+    half = 0.5 * fabs(v1 - v0) + e * fabs(ux) + 0.25 + gm;
+  }
+  r.wc = (float)(0.5 * (w0 + w1));
+  r.hw = (float)(0.5 * fabs(w1 - w0) + e * fabs(uy) + 1e-3 + gm);
+  r.slope = hull ? 0.0f : (float)sp;
+  r.vc = (float)(0.5 * (v0 + v1));
+  r.half = (float)half;
+  if (!finite_f(r.wc) || !finite_f(r.vc) || !finite_f(r.slope) || !(r.half == r.half) || !(r.hw == r.hw)) meets_all();
+  return r;
+}
+
+__device__ __forceinline__ float target_radius(const Frame* frame) {  // max |w|, |v| over the finite targets (0 if none)
+  const int a = frame->wminI, b = frame->wmaxI, c = frame->vminI, d = frame->vmaxI;
+  if (a > b) return 0.0f;
+  return fmaxf(fmaxf(fabsf(of_ord(a)), fabsf(of_ord(b))), fmaxf(fabsf(of_ord(c)), fabsf(of_ord(d))));
+}
+
+// sort keys of the queries: the strip of the band's centre across the frame, then its position along it.  An infinite
+// band (mode 2) is placed by its v at the middle of the target set.
+__global__ __launch_bounds__(256) void k_query_keys(const Geom* __restrict__ geomU, uint32_t nq, int mode, float epsilon,
+                                                    const Frame* __restrict__ frame, float invStrip,
+                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ iota) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nq) return;
+  const BandR r = make_bandr(geomU[i], mode, epsilon, frame->ux, frame->uy, target_radius(frame));
+  float w = r.wc, v = r.vc;
+  if (mode == 2 && frame->wminI <= frame->wmaxI) {
+    const float wm = 0.5f * (of_ord(frame->wminI) + of_ord(frame->wmaxI));
+    v = fmaf(r.slope, wm - r.wc, r.vc);
+    w = r.slope * 4096.0f;  // near-equal lines side by side
+  }
+  keys[i] = frame_key(w, v, invStrip);
+  iota[i] = i;
+}
+
+// bands of the packed query rows (geom is in packed order, rows nq .. nq_pad hold k_geom's padding)
+__global__ __launch_bounds__(256) void k_bandr(const Geom* __restrict__ geom, uint32_t nq, uint32_t nq_pad, int mode, float epsilon,
+                                               const Frame* __restrict__ frame, BandR* __restrict__ bandr) {
+  const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= nq_pad) return;
+  BandR r;
+  if (q < nq) {
+    r = make_bandr(geom[q], mode, epsilon, frame->ux, frame->uy, target_radius(frame));
+  } else {
+    r.wc = 0.0f; r.hw = -__builtin_inff(); r.slope = 0.0f; r.vc = 0.0f; r.half = 0.0f;
+    r.pad0 = r.pad1 = r.pad2 = 0.0f;
+  }
+  bandr[q] = r;
+}
+
+// min / max form while a box is being formed; centre form in memory.  The centre form is inflated by the rounding of the
+// frame map (1e-6 of |x| + |y|) and of its own arithmetic, so that |w - wc| <= hw, |v - vc| <= hv hold for the real-number
+// images of the targets.
+struct BoxMM { float w0, v0, w1, v1, mag; bool all; };
+__device__ __forceinline__ Box to_box(const BoxMM& m) {
+  Box b;
+  if (m.all) { b.wc = 0.0f; b.vc = 0.0f; b.hw = FLT_MAX; b.hv = FLT_MAX; return b; }
+  if (m.w0 > m.w1) { b.wc = 0.0f; b.vc = 0.0f; b.hw = -FLT_MAX; b.hv = -FLT_MAX; return b; }  // empty: meets nothing finite
+  const float slack = 1e-3f + 2e-6f * m.mag;
+  b.wc = 0.5f * m.w0 + 0.5f * m.w1; b.hw = fminf((0.5f * m.w1 - 0.5f * m.w0) + slack, FLT_MAX);
+  b.vc = 0.5f * m.v0 + 0.5f * m.v1; b.hv = fminf((0.5f * m.v1 - 0.5f * m.v0) + slack, FLT_MAX);
+  return b;
+}
 
 __global__ __launch_bounds__(256) void k_tile_boxes(const ssrlcv_float2* __restrict__ locT, uint32_t nt, uint32_t numTiles,
-                                                    Box* __restrict__ tileBox) {
+                                                    const Frame* __restrict__ frame, Box* __restrict__ tileBox) {
   uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t >= numTiles) return;
-  Box b = {FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX};
+  const float ux = frame->ux, uy = frame->uy;
+  BoxMM m = {FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, 0.0f, false};
   for (uint32_t j = 0; j < 32; ++j) {
     uint32_t f = t * 32 + j;
     if (f < nt) {
-      ssrlcv_float2 l = locT[f];
-      b.x0 = fminf(b.x0, l.x); b.y0 = fminf(b.y0, l.y); b.x1 = fmaxf(b.x1, l.x); b.y1 = fmaxf(b.y1, l.y);
+      const ssrlcv_float2 l = locT[f];
+      const float w = ux * l.x + uy * l.y, v = ux * l.y - uy * l.x;
       // a NaN coordinate makes the per-pair test pass (see passes_prefilter): such a tile must never be culled
-      if (!(l.x == l.x) || !(l.y == l.y)) { b.x0 = -FLT_MAX; b.y0 = -FLT_MAX; b.x1 = FLT_MAX; b.y1 = FLT_MAX; break; }
+      if (!finite_f(l.x) || !finite_f(l.y) || !finite_f(w) || !finite_f(v)) { m.all = true; break; }
+      m.w0 = fminf(m.w0, w); m.w1 = fmaxf(m.w1, w); m.v0 = fminf(m.v0, v); m.v1 = fmaxf(m.v1, v);
+      m.mag = fmaxf(m.mag, fabsf(l.x) + fabsf(l.y));
     }
   }
-  tileBox[t] = b;
+  tileBox[t] = to_box(m);
 }
 __global__ __launch_bounds__(256) void k_group_boxes(const Box* __restrict__ tileBox, uint32_t numTiles, uint32_t numGroups,
                                                      Box* __restrict__ groupBox) {
   uint32_t g = blockIdx.x * 256 + threadIdx.x;
   if (g >= numGroups) return;
-  Box b = {FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX};
+  BoxMM m = {FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, 0.0f, false};
   for (uint32_t j = 0; j < 32; ++j) {
     uint32_t t = g * 32 + j;
     if (t < numTiles) {
-      Box tb = tileBox[t];
-      b.x0 = fminf(b.x0, tb.x0); b.y0 = fminf(b.y0, tb.y0); b.x1 = fmaxf(b.x1, tb.x1); b.y1 = fmaxf(b.y1, tb.y1);
+      const Box tb = tileBox[t];
+      if (tb.hw < 0.0f) continue;  // empty
+      if (tb.hw >= FLT_MAX || tb.hv >= FLT_MAX) { m.all = true; break; }
+      m.w0 = fminf(m.w0, tb.wc - tb.hw); m.w1 = fmaxf(m.w1, tb.wc + tb.hw);
+      m.v0 = fminf(m.v0, tb.vc - tb.hv); m.v1 = fmaxf(m.v1, tb.vc + tb.hv);
+      m.mag = fmaxf(m.mag, fabsf(tb.wc) + tb.hw + fabsf(tb.vc) + tb.hv);
     }
   }
-  groupBox[g] = b;
+  groupBox[g] = to_box(m);
 }
 
-// false only when no target inside `b` can pass passes_prefilter(g, ., epsilon, mode)
-__device__ __forceinline__ bool band_hits_box(const Geom& g, const Box& b, float epsilon, int mode) {
-  if (mode == 2) {
-    const float p0 = -1 * ((g.lo_x * b.x0) + g.left_x) / g.hi_x, p1 = -1 * ((g.lo_x * b.x1) + g.left_x) / g.hi_x;
-    const float m = 0.25f + 1e-5f * (fabsf(p0) + fabsf(p1));
-    const float lo = fminf(p0, p1) - epsilon - m, hi = fmaxf(p0, p1) + epsilon + m;
-    if (!(p0 == p0) || !(p1 == p1)) return true;
-    return !(lo > b.y1 || hi < b.y0);
-  }
-  if (b.x1 < g.lo_x || b.x0 > g.hi_x) return false;  // the per-pair x test, exact; false for NaN bounds
-  if (g.vertical != 0.0f) return !(g.top > b.y1 || g.bottom < b.y0);
-  const float xa = fmaxf(g.lo_x, b.x0), xb = fminf(g.hi_x, b.x1);
-  const float ya = g.slope * (xa - g.left_x) + g.left_y, yb = g.slope * (xb - g.left_x) + g.left_y;
-  if (!(ya == ya) || !(yb == yb)) return true;
-  const float m = 0.25f + 1e-5f * (fabsf(ya) + fabsf(yb));
-  return !(fminf(ya, yb) - epsilon - m > b.y1 || fmaxf(ya, yb) + epsilon + m < b.y0);
+// false only when no target inside `b` can pass passes_prefilter for the query of band `g` (see make_bandr).  NaN -> true.
+__device__ __forceinline__ bool band_hits_box(const BandR& g, const Box& b) {
+  const float d = b.wc - g.wc;
+  if (fabsf(d) > b.hw + g.hw) return false;
+  const float dv = fmaf(g.slope, d, g.vc) - b.vc;
+  return !(fabsf(dv) > fmaf(fabsf(g.slope), b.hw, g.half + b.hv));
 }
 
 __device__ __forceinline__ unsigned long long make_key(float dist, uint32_t f) {
@@ -297,7 +540,7 @@ __global__ __launch_bounds__(256, SSRLCV_MATCH_WPS) void k_match(const _Float16*
                                                   uint32_t tilesPerSplit, int mode, float epsilon, float absThreshold,
                                                   unsigned long long* __restrict__ bestKey,
                                                   const uint32_t* __restrict__ permT, const Box* __restrict__ tileBox,
-                                                  const Box* __restrict__ groupBox) {
+                                                  const Box* __restrict__ groupBox, const BandR* __restrict__ bandr) {
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned col = lane & 31, kgrp = lane >> 5;
   const uint32_t qbase = (blockIdx.x * kWaves + wave) * (kQT * 32);
@@ -333,6 +576,11 @@ __global__ __launch_bounds__(256, SSRLCV_MATCH_WPS) void k_match(const _Float16*
   if (BAND) {
 #pragma unroll
     for (int qt = 0; qt < (BAND ? kQT : 1); ++qt) gq[qt] = geom[qbase + qt * 32 + col];
+  }
+  BandR gr_[BAND ? kQT : 1];  // the same bands in the pair's frame, for the box tests
+  if (BAND) {
+#pragma unroll
+    for (int qt = 0; qt < (BAND ? kQT : 1); ++qt) gr_[qt] = bandr[qbase + qt * 32 + col];
   }
   auto epilogue = [&](uint32_t tt, int qt, const floatx16& acc) {
     float m0 = min3(acc[0], acc[1], acc[2]);
@@ -400,7 +648,7 @@ __global__ __launch_bounds__(256, SSRLCV_MATCH_WPS) void k_match(const _Float16*
       const Box gb = groupBox[gr];
       bool gh = false;
 #pragma unroll
-      for (int qt = 0; qt < (BAND ? kQT : 1); ++qt) gh = gh || band_hits_box(gq[qt], gb, epsilon, mode);
+      for (int qt = 0; qt < (BAND ? kQT : 1); ++qt) gh = gh || band_hits_box(gr_[qt], gb);
       if (!__any(gh)) continue;
       uint32_t t1 = (gr + 1) * 32;
       if (t1 > tile1) t1 = tile1;
@@ -409,7 +657,7 @@ __global__ __launch_bounds__(256, SSRLCV_MATCH_WPS) void k_match(const _Float16*
         unsigned need = 0;
 #pragma unroll
         for (int qt = 0; qt < (BAND ? kQT : 1); ++qt)
-          if (__any(band_hits_box(gq[qt], tb, epsilon, mode))) need |= 1u << qt;
+          if (__any(band_hits_box(gr_[qt], tb))) need |= 1u << qt;
         if (!need) continue;
         half8 a[kKSteps];
         load_tile(tt, a);
@@ -523,7 +771,7 @@ __global__ __launch_bounds__(256) void k_seed_finalize(const unsigned long long*
 struct Layout {
   uint32_t nq_pad, nt_pad;
   size_t off_pq, off_pt, off_nq, off_nt, off_lt, off_geom, off_key, off_scratch, off_permq, off_permt, off_tilebox, off_groupbox,
-      off_sort, sort_bytes, total;
+      off_bandr, off_frame, off_sort, sort_bytes, total;
 };
 
 Layout make_layout(uint32_t nq, uint32_t nt) {
@@ -550,6 +798,8 @@ Layout make_layout(uint32_t nq, uint32_t nt) {
     const size_t groups = (L.nt_pad / 32 + 31) / 32;
     L.off_groupbox = take((groups + (groups + 31) / 32) * sizeof(Box));
   }
+  L.off_bandr = take((size_t)L.nq_pad * sizeof(BandR));
+  L.off_frame = take(sizeof(Frame));
   L.sort_bytes = svm::sort_scratch_bytes(nq > nt ? nq : nt);
   L.off_sort = take(L.sort_bytes);
   L.total = o;
@@ -557,7 +807,7 @@ Layout make_layout(uint32_t nq, uint32_t nt) {
 }
 
 int run_match(const ssrlcv_sift_feature* query, uint32_t nq, const ssrlcv_sift_feature* target, uint32_t nt, int mode,
-              const ssrlcv_match_params* p, float absThreshold, char* ws, const Layout& L, hipStream_t st) {
+              const ssrlcv_match_params* p, float absThreshold, char* ws, const Layout& L, hipStream_t st, bool seedOnly = false) {
   _Float16* pq = (_Float16*)(ws + L.off_pq);
   _Float16* pt = (_Float16*)(ws + L.off_pt);
   float* nqv = (float*)(ws + L.off_nq);
@@ -567,11 +817,40 @@ int run_match(const ssrlcv_sift_feature* query, uint32_t nq, const ssrlcv_sift_f
   const bool band = mode != 0;
   uint32_t* permQ = band ? (uint32_t*)(ws + L.off_permq) : nullptr;
   uint32_t* permT = band ? (uint32_t*)(ws + L.off_permt) : nullptr;
+  Frame* frame = (Frame*)(ws + L.off_frame);
+  BandR* bandr = (BandR*)(ws + L.off_bandr);
+  float* F9 = (float*)(ws + L.off_scratch);
+  if (mode == 2) SSRLCV_HIP_TRY(hipMemcpyAsync(F9, p->fundamental, 9 * sizeof(float), hipMemcpyHostToDevice, st));
+  auto launch_geom = [&](const uint32_t* perm) {
+    if (mode == 1)
+      hipLaunchKernelGGL(k_geom, dim3((L.nq_pad + 255) / 256), dim3(256), 0, st, query, nq, L.nq_pad, perm, p->queryCamera,
+                         p->targetProjection[0], p->targetProjection[1], p->targetProjection[2], p->epsilon, p->delta, geom);
+    if (mode == 2)
+      hipLaunchKernelGGL(k_geom_fundamental, dim3((L.nq_pad + 255) / 256), dim3(256), 0, st, query, nq, L.nq_pad, perm,
+                         (const float*)F9, geom);
+  };
   if (band) {
-    int rc = svm::sort_by_location(query, nq, permQ, ws + L.off_sort, L.sort_bytes, st);
-    if (rc) return rc;
-    rc = svm::sort_by_location(target, nt, permT, ws + L.off_sort, L.sort_bytes, st);
-    if (rc) return rc;
+    // the frame of the pair and the two orders (see "band culling"): bands of the queries in caller order -> u ->
+    // targets by (strip across u, position along u) -> queries by where their band lies
+    static const float forceDeg = svdev::env("SSRLCV_BAND_DIR") ? (float)atof(svdev::env("SSRLCV_BAND_DIR")) : 1e30f;
+    static const float stripT = svdev::env("SSRLCV_BAND_STRIP") ? (float)atof(svdev::env("SSRLCV_BAND_STRIP")) : SSRLCV_BAND_STRIP;
+    static const float stripQ = svdev::env("SSRLCV_BAND_STRIP_Q") ? (float)atof(svdev::env("SSRLCV_BAND_STRIP_Q")) : stripT;
+    launch_geom(nullptr);
+    hipLaunchKernelGGL(k_band_direction, dim3(1), dim3(1024), 0, st, (const Geom*)geom, nq, mode, forceDeg, frame);
+    if (nt) {
+      const svm::SortBuffers sb = svm::sort_buffers(ws + L.off_sort, nt);
+      hipLaunchKernelGGL(k_target_keys, dim3((nt + 255) / 256), dim3(256), 0, st, target, nt, frame, 1.0f / stripT,
+                         mode == 2 ? 1 : 0, sb.keys, sb.iota);
+      int rc = svm::sort_filled_keys(nt, permT, ws + L.off_sort, L.sort_bytes, st);
+      if (rc) return rc;
+    }
+    if (nq) {
+      const svm::SortBuffers sb = svm::sort_buffers(ws + L.off_sort, nq);
+      hipLaunchKernelGGL(k_query_keys, dim3((nq + 255) / 256), dim3(256), 0, st, (const Geom*)geom, nq, mode, p->epsilon,
+                         (const Frame*)frame, 1.0f / stripQ, sb.keys, sb.iota);
+      int rc = svm::sort_filled_keys(nq, permQ, ws + L.off_sort, L.sort_bytes, st);
+      if (rc) return rc;
+    }
   }
   // Integer formulation (matcher_i8.inc) by default; SSRLCV_MATCH_F16=1 selects the fp16 one (same results).
   static const bool useF16 = svdev::env("SSRLCV_MATCH_F16") != nullptr;
@@ -587,19 +866,11 @@ int run_match(const ssrlcv_sift_feature* query, uint32_t nq, const ssrlcv_sift_f
                        (uint8_t*)pt, (int*)(ws + L.off_nt), lt);
   }
   SSRLCV_HIP_TRY(hipMemsetAsync(keys, 0xff, (size_t)L.nq_pad * 8, st));
-  float eps = 0.0f;
-  if (mode == 1) {
-    eps = p->epsilon;
-    hipLaunchKernelGGL(k_geom, dim3((L.nq_pad + 255) / 256), dim3(256), 0, st, query, nq, L.nq_pad, permQ, p->queryCamera,
-                       p->targetProjection[0], p->targetProjection[1], p->targetProjection[2], p->epsilon, p->delta, geom);
-  }
-  if (mode == 2) {
-    eps = p->epsilon;
-    float* F9 = (float*)(ws + L.off_scratch);
-    SSRLCV_HIP_TRY(hipMemcpyAsync(F9, p->fundamental, 9 * sizeof(float), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_geom_fundamental, dim3((L.nq_pad + 255) / 256), dim3(256), 0, st, query, nq, L.nq_pad, permQ, F9,
-                       geom);
-  }
+  const float eps = mode != 0 ? p->epsilon : 0.0f;
+  launch_geom(permQ);  // (packed order; no-op in mode 0)
+  if (band)
+    hipLaunchKernelGGL(k_bandr, dim3((L.nq_pad + 255) / 256), dim3(256), 0, st, (const Geom*)geom, nq, L.nq_pad, mode, eps,
+                       (const Frame*)frame, bandr);
   uint32_t qblocks = L.nq_pad / (useF16 ? kQPerBlock : kQPerBlock8);
   uint32_t numTiles = L.nt_pad / 32;
   const int* ntn = (const int*)(ws + L.off_nt);
@@ -607,7 +878,8 @@ int run_match(const ssrlcv_sift_feature* query, uint32_t nq, const ssrlcv_sift_f
     Box* tileBox = (Box*)(ws + L.off_tilebox);
     Box* groupBox = (Box*)(ws + L.off_groupbox);
     const uint32_t numGroups = (numTiles + 31) / 32;
-    hipLaunchKernelGGL(k_tile_boxes, dim3((numTiles + 255) / 256), dim3(256), 0, st, lt, nt, numTiles, tileBox);
+    hipLaunchKernelGGL(k_tile_boxes, dim3((numTiles + 255) / 256), dim3(256), 0, st, lt, nt, numTiles, (const Frame*)frame,
+                       tileBox);
     hipLaunchKernelGGL(k_group_boxes, dim3((numGroups + 255) / 256), dim3(256), 0, st, tileBox, numTiles, numGroups,
                        groupBox);
     const uint32_t numSuper = (numGroups + 31) / 32;  // the same union one level up, stored behind the group boxes
@@ -620,11 +892,11 @@ int run_match(const ssrlcv_sift_feature* query, uint32_t nq, const ssrlcv_sift_f
     uint32_t tilesPerSplit = ((numGroups + splits - 1) / splits) * 32;
     if (useF16)
       hipLaunchKernelGGL(k_match<true>, dim3(qblocks, splits), dim3(256), 0, st, pq, pt, nqv, lt, geom, nq, nt,
-                         tilesPerSplit, mode, eps, absThreshold, keys, permT, tileBox, groupBox);
+                         tilesPerSplit, mode, eps, absThreshold, keys, permT, tileBox, groupBox, (const BandR*)bandr);
     else
       hipLaunchKernelGGL((k_match_i8<true, kQT8Band>), dim3(qbBand, splits), dim3(256), 0, st, (const uint8_t*)pq, (const uint8_t*)pt,
                          (const int*)nqv, ntn, lt, geom, nq, nt, tilesPerSplit, mode, eps, absThreshold, keys, permT,
-                         tileBox, groupBox);
+                         tileBox, groupBox, (const BandR*)bandr);
   } else {
     // split the target range until the grid has >= 1024 blocks (4 per CU) or tiles run out
     uint32_t splits = 1;
@@ -633,11 +905,15 @@ int run_match(const ssrlcv_sift_feature* query, uint32_t nq, const ssrlcv_sift_f
     if (useF16)
       hipLaunchKernelGGL(k_match<false>, dim3(qblocks, splits), dim3(256), 0, st, pq, pt, nqv, lt, geom, nq, nt,
                          tilesPerSplit, mode, eps, absThreshold, keys, (const uint32_t*)nullptr, (const Box*)nullptr,
-                         (const Box*)nullptr);
+                         (const Box*)nullptr, (const BandR*)nullptr);
+    else if (seedOnly)  // minimum distance only (getSeedDistances)
+      hipLaunchKernelGGL((k_match_i8<false, kQT8Brute, true>), dim3(qblocks, splits), dim3(256), 0, st, (const uint8_t*)pq,
+                         (const uint8_t*)pt, (const int*)nqv, ntn, lt, geom, nq, nt, tilesPerSplit, mode, eps, absThreshold, keys,
+                         (const uint32_t*)nullptr, (const Box*)nullptr, (const Box*)nullptr, (const BandR*)nullptr);
     else
       hipLaunchKernelGGL((k_match_i8<false, kQT8Brute>), dim3(qblocks, splits), dim3(256), 0, st, (const uint8_t*)pq, (const uint8_t*)pt,
                          (const int*)nqv, ntn, lt, geom, nq, nt, tilesPerSplit, mode, eps, absThreshold, keys,
-                         (const uint32_t*)nullptr, (const Box*)nullptr, (const Box*)nullptr);
+                         (const uint32_t*)nullptr, (const Box*)nullptr, (const Box*)nullptr, (const BandR*)nullptr);
   }
   SSRLCV_LAUNCH_CHECK();
   return SSRLCV_OK;
@@ -727,7 +1003,7 @@ int ssrlcv_hip_seed_distances_u8x128(const ssrlcv_sift_feature* query, uint32_t 
   Layout L = make_layout(numQuery, numSeed);
   if (workspaceBytes < L.total) return SSRLCV_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  int rc = run_match(query, numQuery, seed, numSeed, 0, nullptr, FLT_MAX, (char*)workspace, L, st);
+  int rc = run_match(query, numQuery, seed, numSeed, 0, nullptr, FLT_MAX, (char*)workspace, L, st, true);
   if (rc) return rc;
   hipLaunchKernelGGL(k_seed_finalize, dim3((numQuery + 255) / 256), dim3(256), 0, st,
                      (const unsigned long long*)((char*)workspace + L.off_key), numQuery, out);

@@ -3,12 +3,16 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
-#include "ssrlcv_types.h"
 
 namespace svm {
-// bytes of scratch sort_by_location needs for n features (pure host arithmetic)
+// bytes of scratch sort_filled_keys needs for n elements (pure host arithmetic)
 size_t sort_scratch_bytes(uint32_t n);
-// perm[0..n): indices of `feats` ordered by (64-pixel row strip, x); asynchronous on `stream`
-int sort_by_location(const ssrlcv_sift_feature* feats, uint32_t n, uint32_t* perm, void* scratch, size_t scratchBytes,
-                     hipStream_t stream);
+// the two arrays inside `scratch` the caller fills (on `stream`) before sort_filled_keys: keys[n] and iota[n] = 0 .. n-1
+struct SortBuffers {
+  uint32_t* keys;
+  uint32_t* iota;
+};
+SortBuffers sort_buffers(void* scratch, uint32_t n);
+// perm[0..n) = iota reordered by ascending key (stable); asynchronous on `stream`
+int sort_filled_keys(uint32_t n, uint32_t* perm, void* scratch, size_t scratchBytes, hipStream_t stream);
 }  // namespace svm
