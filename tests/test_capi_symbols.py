@@ -139,8 +139,10 @@ def test_matcher_kernels_register_budget():
         m = re.search(r"remark:\s+([A-Za-z \[\]/]+): (\d+)", line)
         if m and name:
             usage[name][m.group(1).strip()] = int(m.group(2))
-    brute = [v for k, v in usage.items() if "k_match_i8ILb0ELi4E" in k]
-    band = [v for k, v in usage.items() if "k_match_i8ILb1ELi1E" in k]
-    assert len(brute) == 1 and len(band) == 1, sorted(usage)
+    brute = [v for k, v in usage.items() if "k_match_i8ILb0ELi4ELb0E" in k]
+    seed = [v for k, v in usage.items() if "k_match_i8ILb0ELi4ELb1E" in k]  # the min-only variant of getSeedDistances
+    band = [v for k, v in usage.items() if "k_match_i8ILb1ELi1ELb0E" in k]
+    assert len(brute) == 1 and len(band) == 1 and len(seed) == 1, sorted(usage)
     assert brute[0]["ScratchSize [bytes/lane]"] == 0 and brute[0]["VGPRs"] <= 256 and brute[0]["Occupancy [waves/SIMD]"] == 2
+    assert seed[0]["ScratchSize [bytes/lane]"] == 0 and seed[0]["Occupancy [waves/SIMD]"] == 2
     assert band[0]["ScratchSize [bytes/lane]"] == 0 and band[0]["Occupancy [waves/SIMD]"] == 5, band[0]
