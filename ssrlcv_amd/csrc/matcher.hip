@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include "compact.h"
 #include "dev_switch.h"
@@ -994,6 +995,24 @@ extern "C" {
 size_t ssrlcv_hip_match_workspace_bytes(uint32_t numQuery, uint32_t numTarget) {
   return make_layout(numQuery, numTarget).total;
 }
+
+#ifdef SSRLCV_MATCH_STATS
+// developer builds with -DSSRLCV_MATCH_STATS only (not declared in the header): reads and clears the walk counters
+int ssrlcv_dbg_match_stats(unsigned long long* out12) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out12, HIP_SYMBOL(g_match_stats), 12 * sizeof(unsigned long long));
+  unsigned long long z[12] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_match_stats), z, sizeof(z));
+  float f[8];
+  (void)hipMemcpyFromSymbol(f, HIP_SYMBOL(g_match_fstats), sizeof(f));
+  if (f[4] > 0.0f)
+    printf("bands per wave: spread of wc %.1f px, of vc %.1f px; mean half-length %.1f px, half-thickness %.1f px; %.0f waves, %.0f lanes without a finite band\n",
+           f[0] / f[4], f[1] / f[4], f[2] / f[4], f[3] / f[4], f[4], f[5]);
+  float zf[8] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_match_fstats), zf, sizeof(zf));
+  return 0;
+}
+#endif
 
 int ssrlcv_hip_seed_distances_u8x128(const ssrlcv_sift_feature* query, uint32_t numQuery, const ssrlcv_sift_feature* seed,
                                      uint32_t numSeed, float* out, void* workspace, size_t workspaceBytes,

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import helpers as H  # noqa: E402
 
 H.limit_openmp()
-from ssrlcv_amd import pipeline  # noqa: E402
+from ssrlcv_amd import capi, pipeline  # noqa: E402
 import scene  # noqa: E402
 
 ap = argparse.ArgumentParser()
@@ -35,5 +35,15 @@ for _ in range(args.iters):
     torch.cuda.synchronize()
     times.append((time.perf_counter() - t0) * 1e3)
 times.sort()
+lib = capi.LIB
+if hasattr(lib, "ssrlcv_dbg_match_stats"):  # a -DSSRLCV_MATCH_STATS build (SSRLCV_HIP_LIB=ssrlcv_amd/libssrlcv_hip_stats.so)
+    import ctypes
+    out = (ctypes.c_ulonglong * 12)()
+    lib.ssrlcv_dbg_match_stats(out)  # clear
+    pipeline.match_pairs(feats, cams, seed, 25.0, 5.0, mode=1, ws=ws)
+    lib.ssrlcv_dbg_match_stats(out)
+    names = ["super tests", "group tests", "tile tests", "chains", "slow chains", "candidate rows", "lane candidates (acc)",
+             "lane candidates (exact v)", "passing"]
+    print("walk counters of one match stage: " + ", ".join("%s %.3f M" % (n, out[i] / 1e6) for i, n in enumerate(names)))
 print("match stage (%d pairs, features %s): min %.2f median %.2f ms; %d matches" % (
     len(pairs), [f.numel() // 152 for f in feats], times[0], times[len(times) // 2], sum(p.numel() // 16 for p in pairs.values())))
