@@ -479,8 +479,10 @@ __device__ __forceinline__ Box to_box(const BoxMM& m) {
   return b;
 }
 
+// tilePar (nullable, integer formulation): bit j = parity of |t'|^2 of the tile's row j (the slow path's exact distance)
 __global__ __launch_bounds__(256) void k_tile_boxes(const ssrlcv_float2* __restrict__ locT, uint32_t nt, uint32_t numTiles,
-                                                    const Frame* __restrict__ frame, Box* __restrict__ tileBox) {
+                                                    const Frame* __restrict__ frame, Box* __restrict__ tileBox,
+                                                    const int* __restrict__ normT, uint32_t* __restrict__ tilePar) {
   uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t >= numTiles) return;
   const float ux = frame->ux, uy = frame->uy;
@@ -497,6 +499,11 @@ __global__ __launch_bounds__(256) void k_tile_boxes(const ssrlcv_float2* __restr
     }
   }
   tileBox[t] = to_box(m);
+  if (tilePar) {
+    uint32_t par = 0;
+    for (uint32_t j = 0; j < 32; ++j) par |= ((uint32_t)normT[t * 32 + j] & 1u) << j;  // (rows exist up to nt_pad)
+    tilePar[t] = par;
+  }
 }
 __global__ __launch_bounds__(256) void k_group_boxes(const Box* __restrict__ tileBox, uint32_t numTiles, uint32_t numGroups,
                                                      Box* __restrict__ groupBox) {
@@ -772,7 +779,7 @@ __global__ __launch_bounds__(256) void k_seed_finalize(const unsigned long long*
 struct Layout {
   uint32_t nq_pad, nt_pad;
   size_t off_pq, off_pt, off_nq, off_nt, off_lt, off_geom, off_key, off_scratch, off_permq, off_permt, off_tilebox, off_groupbox,
-      off_bandr, off_frame, off_sort, sort_bytes, total;
+      off_bandr, off_frame, off_tilepar, off_sort, sort_bytes, total;
 };
 
 Layout make_layout(uint32_t nq, uint32_t nt) {
@@ -801,6 +808,7 @@ Layout make_layout(uint32_t nq, uint32_t nt) {
   }
   L.off_bandr = take((size_t)L.nq_pad * sizeof(BandR));
   L.off_frame = take(sizeof(Frame));
+  L.off_tilepar = take((size_t)(L.nt_pad / 32) * 4);
   L.sort_bytes = svm::sort_scratch_bytes(nq > nt ? nq : nt);
   L.off_sort = take(L.sort_bytes);
   L.total = o;
@@ -879,8 +887,9 @@ int run_match(const ssrlcv_sift_feature* query, uint32_t nq, const ssrlcv_sift_f
     Box* tileBox = (Box*)(ws + L.off_tilebox);
     Box* groupBox = (Box*)(ws + L.off_groupbox);
     const uint32_t numGroups = (numTiles + 31) / 32;
+    uint32_t* tilePar = (uint32_t*)(ws + L.off_tilepar);
     hipLaunchKernelGGL(k_tile_boxes, dim3((numTiles + 255) / 256), dim3(256), 0, st, lt, nt, numTiles, (const Frame*)frame,
-                       tileBox);
+                       tileBox, useF16 ? (const int*)nullptr : ntn, useF16 ? (uint32_t*)nullptr : tilePar);
     hipLaunchKernelGGL(k_group_boxes, dim3((numGroups + 255) / 256), dim3(256), 0, st, tileBox, numTiles, numGroups,
                        groupBox);
     const uint32_t numSuper = (numGroups + 31) / 32;  // the same union one level up, stored behind the group boxes
@@ -897,7 +906,7 @@ int run_match(const ssrlcv_sift_feature* query, uint32_t nq, const ssrlcv_sift_f
     else
       hipLaunchKernelGGL((k_match_i8<true, kQT8Band>), dim3(qbBand, splits), dim3(256), 0, st, (const uint8_t*)pq, (const uint8_t*)pt,
                          (const int*)nqv, ntn, lt, geom, nq, nt, tilesPerSplit, mode, eps, absThreshold, keys, permT,
-                         tileBox, groupBox, (const BandR*)bandr);
+                         tileBox, groupBox, (const BandR*)bandr, (const uint32_t*)tilePar);
   } else {
     // split the target range until the grid has >= 1024 blocks (4 per CU) or tiles run out
     uint32_t splits = 1;
@@ -910,11 +919,13 @@ int run_match(const ssrlcv_sift_feature* query, uint32_t nq, const ssrlcv_sift_f
     else if (seedOnly)  // minimum distance only (getSeedDistances)
       hipLaunchKernelGGL((k_match_i8<false, kQT8Brute, true>), dim3(qblocks, splits), dim3(256), 0, st, (const uint8_t*)pq,
                          (const uint8_t*)pt, (const int*)nqv, ntn, lt, geom, nq, nt, tilesPerSplit, mode, eps, absThreshold, keys,
-                         (const uint32_t*)nullptr, (const Box*)nullptr, (const Box*)nullptr, (const BandR*)nullptr);
+                         (const uint32_t*)nullptr, (const Box*)nullptr, (const Box*)nullptr, (const BandR*)nullptr,
+                         (const uint32_t*)nullptr);
     else
       hipLaunchKernelGGL((k_match_i8<false, kQT8Brute>), dim3(qblocks, splits), dim3(256), 0, st, (const uint8_t*)pq, (const uint8_t*)pt,
                          (const int*)nqv, ntn, lt, geom, nq, nt, tilesPerSplit, mode, eps, absThreshold, keys,
-                         (const uint32_t*)nullptr, (const Box*)nullptr, (const Box*)nullptr, (const BandR*)nullptr);
+                         (const uint32_t*)nullptr, (const Box*)nullptr, (const Box*)nullptr, (const BandR*)nullptr,
+                         (const uint32_t*)nullptr);
   }
   SSRLCV_LAUNCH_CHECK();
   return SSRLCV_OK;
