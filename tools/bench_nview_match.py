@@ -45,5 +45,6 @@ if hasattr(lib, "ssrlcv_dbg_match_stats"):  # a -DSSRLCV_MATCH_STATS build (SSRL
     names = ["super tests", "group tests", "tile tests", "chains", "slow chains", "candidate rows", "lane candidates (acc)",
              "lane candidates (exact v)", "passing"]
     print("walk counters of one match stage: " + ", ".join("%s %.3f M" % (n, out[i] / 1e6) for i, n in enumerate(names)))
+    print("most chains of one wave %d; waves with > 500 chains %d, > 2000 chains %d" % (out[9], out[10], out[11]))
 print("match stage (%d pairs, features %s): min %.2f median %.2f ms; %d matches" % (
     len(pairs), [f.numel() // 152 for f in feats], times[0], times[len(times) // 2], sum(p.numel() // 16 for p in pairs.values())))

@@ -17,7 +17,30 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--nq", type=int, default=629559)
 ap.add_argument("--ns", default="1116,4096,16384")
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--scene", action="store_true", help="real features of a rendered 4096^2 view against the fixture's seed set")
 args = ap.parse_args()
+if args.scene:
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import scene
+    from ssrlcv_amd import pipeline
+    imgs, cams, _, _ = scene.pinhole_views(3, 4096)
+    plan = capi.SiftPlan(4096, 4096)
+    plan.extract(imgs[2])
+    nq = plan.count()
+    feats = plan.features
+    seed, _ = H.load_seed_features()
+    sd = capi.to_dev(seed)
+    ws = capi.match_workspace(nq, len(seed))
+    for rep in range(2):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            out = capi.seed_distances(feats, nq, sd, len(seed), ws)
+        e1.record()
+        torch.cuda.synchronize()
+    print("scene: nq %d ns %d: %.3f ms per call" % (nq, len(seed), e0.elapsed_time(e1) / args.iters))
+    sys.exit(0)
 rng = np.random.default_rng(5)
 
 
