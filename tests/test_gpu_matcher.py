@@ -1,5 +1,9 @@
 """GPU parity: the MFMA 128-D matcher (C ABI; int8 formulation by default, the fp16 one in tests/test_gpu_configs.py) vs
 the CPU oracle -- indices and distances bit-exact."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
@@ -205,6 +209,39 @@ def test_band_culling_is_conservative_on_degenerate_geometry(capi, oracle_lib):
             g2 = capi.to_host(out_d, H.UINT2_PAIR, len(q))
             o2 = H.oracle_match_pairs(oracle_lib, 2, 3, q, 7, t, None, F.reshape(-1), eps, 0.0, None, REL, 3e7)
             assert np.array_equal(g2["a"], o2["a"]) and np.array_equal(g2["b"], o2["b"])
+
+
+def test_fundamental_constrained_steep_and_degenerate_lines(capi, oracle_lib):
+    """F matrices whose epipolar lines are steep, nearly vertical, exactly vertical for some queries (b = 0: the
+    reference's quotient is inf / NaN there) or fan out from an epipole inside the image: the bands are then far from
+    the frame's direction, bounded by their hulls or not at all, and the result must still be the oracle's."""
+    q = random_features(1500, 41, hi=48)
+    t = random_features(2500, 42, hi=48)
+    q["loc"][:40, 0] = 512.0  # with Fs[2] these queries get b = 0 exactly
+    Fs = [np.array([[0.0, -1e-4, 0.9], [1e-4, 0.0, -0.05], [-400.0, 30.0, 100.0]], np.float32),    # steep lines
+          np.array([[0.0, 0.0, 1.0], [0.0, 0.0, 1e-4], [-500.0, 0.0, 0.0]], np.float32),            # x = const (+ tiny slope)
+          np.array([[0.0, 0.0, 1.0], [1.0, 0.0, -512.0], [-300.0, -1.0, 900.0]], np.float32),       # b = x - 512: zero for some
+          np.array([[0.0, -1.0, 500.0], [1.0, 0.0, -500.0], [-500.0, 500.0, 0.0]], np.float32)]     # epipole at (500, 500)
+    for F in Fs:
+        for eps in (2.0, 30.0):
+            params = capi.make_match_params(2, 3, 7, eps, 0.0, 0.9, 3e7, fundamental=F)
+            out_d = capi.match(capi.to_dev(q), len(q), capi.to_dev(t), len(t), params, capi.OUT_UINT2_PAIR)
+            g = capi.to_host(out_d, H.UINT2_PAIR, len(q))
+            o = H.oracle_match_pairs(oracle_lib, 2, 3, q, 7, t, None, F.reshape(-1), eps, 0.0, None, 0.9, 3e7)
+            assert np.array_equal(g["a"], o["a"]) and np.array_equal(g["b"], o["b"])
+
+
+@pytest.mark.parametrize("direction,strip", [("37", "5"), ("90", "64"), ("-63.5", "1"), ("180", "16")])
+def test_band_frame_is_only_an_order(direction, strip):
+    """The frame of the band-culled modes (matcher.hip "band culling": direction u of the bands, strips across it) decides
+    what is culled, never what is found.  A developer build lets the environment force u and the strip width; the
+    oracle-parity tests of the culled modes are repeated in a child process with the frame turned away from the bands
+    (37, 90, -63.5 degrees: bands steep or across the frame) and with strips of 1 to 64 pixels."""
+    env = dict(os.environ, SSRLCV_BAND_DIR=direction, SSRLCV_BAND_STRIP=strip)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "double_constrained or fundamental_constrained or conservative_on_degenerate"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_compact_matches_is_stable(capi):
