@@ -378,6 +378,42 @@ def test_release_build_ignores_the_environment_and_is_bit_exact():
     assert r.returncode == 0 and "RELEASE OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+_F16_SCENE_SCRIPT = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import helpers as H
+from ssrlcv_amd import pipeline
+d = np.load(%(npz)r)
+feats = [torch.from_numpy(d["f%%d" %% i]).cuda() for i in range(3)]
+pairs = pipeline.match_pairs(feats, d["cams"].view(H.CAMERA), None, 25.0, 5.0, mode=1)
+np.savez(%(out)r, **{"p%%d" %% k: v.cpu().numpy() for k, v in pairs.items()})
+print("F16 SCENE OK")
+"""
+
+
+def test_band_culled_pairs_at_size_equal_the_fp16_kernels(tmp_path):
+    """Three 2048^2 scene views, the three double-constrained pair matches: the default kernel (int8 MFMA; hit groups
+    from the middle of the band outwards, one tile in flight by LDS-DMA, shared bounds) against the fp16 kernel's plain
+    walk of the same boxes (SSRLCV_MATCH_F16=1, a child process).  Two independent walks and epilogues, real band
+    geometry, ~10^5 features per view: every validated pair list must be identical."""
+    import scene
+    from ssrlcv_amd import pipeline
+    imgs, cams, _, _ = scene.pinhole_views(3, 2048)
+    res = pipeline.reconstruct(imgs, cams, seed_features=None, mode=1)
+    feats = res["features"]
+    pairs = pipeline.match_pairs(feats, cams, None, 25.0, 5.0, mode=1)
+    assert sum(v.numel() // 16 for v in pairs.values()) > 50000
+    npz, out = str(tmp_path / "feats.npz"), str(tmp_path / "pairs.npz")
+    np.savez(npz, cams=cams.view(np.uint8), **{"f%d" % i: f.cpu().numpy() for i, f in enumerate(feats)})
+    env = dict(os.environ, SSRLCV_MATCH_F16="1")
+    r = subprocess.run([sys.executable, "-c", _F16_SCENE_SCRIPT % {"root": ROOT, "npz": npz, "out": out}], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "F16 SCENE OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    other = np.load(out)
+    for k, v in pairs.items():
+        assert np.array_equal(v.cpu().numpy(), other["p%d" % k]), "pair %d" % k
+
+
 def test_fp16_mfma_matcher_is_bit_exact_too():
     """The matcher's fp16-MFMA formulation (v_mfma_f32_32x32x16_f16 with the norms carried as base-1024 digits; what
     the north star names) is selected once per process by SSRLCV_MATCH_F16=1, so it is exercised in a child process:
