@@ -229,6 +229,14 @@ def compact_matches_async(out_kind, matches_d, n, workspace, count_d):
                                                c_sz(workspace.numel()), stream_ptr()))
 
 
+def sort_keys(keys_d, n):
+    """perm (int32 CUDA tensor of n uint32) ordering 0 .. n-1 by ascending (keys[i], i) -- the sort of the band-culled modes"""
+    ws = dev_bytes(int(LIB.ssrlcv_hip_sort_workspace_bytes(c_u32(n))))
+    perm = torch.empty(max(n, 1), dtype=torch.int32, device="cuda")
+    check(LIB.ssrlcv_hip_sort_keys_u32(ptr(keys_d), c_u32(n), ptr(perm), ptr(ws), c_sz(ws.numel()), stream_ptr()))
+    return perm[:n]
+
+
 def keypoints_from_members(members_d, n, feature_tensors):
     """KeyPoint{image, location} of every {image, feature} member, gathered on the device -> uint8 tensor (16 B each)."""
     V = len(feature_tensors)

@@ -316,8 +316,7 @@ __device__ __forceinline__ uint32_t frame_key(float w, float v, float invStrip) 
 // sort keys of the targets; mode 2 (infinite bands) also needs the bounds of the target set in the frame: per-block
 // reduction + 4 atomics per block (same-address atomics serialise at ~50 ns: one set per WAVE cost 1.3 ms for 413 000 targets)
 __global__ __launch_bounds__(256) void k_target_keys(const ssrlcv_sift_feature* __restrict__ feats, uint32_t n, Frame* __restrict__ frame,
-                                                     float invStrip, int wantBounds, uint32_t* __restrict__ keys,
-                                                     uint32_t* __restrict__ iota) {
+                                                     float invStrip, int wantBounds, uint32_t* __restrict__ keys) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   const float ux = frame->ux, uy = frame->uy;
   int w0 = 0x7fffffff, w1 = (int)0x80000000, v0 = 0x7fffffff, v1 = (int)0x80000000;
@@ -325,7 +324,6 @@ __global__ __launch_bounds__(256) void k_target_keys(const ssrlcv_sift_feature* 
     const ssrlcv_float2 l = feats[i].loc;
     const float w = ux * l.x + uy * l.y, v = ux * l.y - uy * l.x;
     keys[i] = frame_key(w, v, invStrip);
-    iota[i] = i;
     if (finite_f(w) && finite_f(v)) { w0 = w1 = ord_of(w); v0 = v1 = ord_of(v); }
   }
   if (!wantBounds) return;  // (uniform)
@@ -436,7 +434,7 @@ __device__ __forceinline__ float target_radius(const Frame* frame) {  // max |w|
 // band (mode 2) is placed by its v at the middle of the target set.
 __global__ __launch_bounds__(256) void k_query_keys(const Geom* __restrict__ geomU, uint32_t nq, int mode, float epsilon,
                                                     const Frame* __restrict__ frame, float invStrip,
-                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ iota) {
+                                                    uint32_t* __restrict__ keys) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= nq) return;
   const BandR r = make_bandr(geomU[i], mode, epsilon, frame->ux, frame->uy, target_radius(frame));
@@ -447,7 +445,6 @@ __global__ __launch_bounds__(256) void k_query_keys(const Geom* __restrict__ geo
     w = r.slope * 4096.0f;  // near-equal lines side by side
   }
   keys[i] = frame_key(w, v, invStrip);
-  iota[i] = i;
 }
 
 // bands of the packed query rows (geom is in packed order, rows nq .. nq_pad hold k_geom's padding)
@@ -849,14 +846,14 @@ int run_match(const ssrlcv_sift_feature* query, uint32_t nq, const ssrlcv_sift_f
     if (nt) {
       const svm::SortBuffers sb = svm::sort_buffers(ws + L.off_sort, nt);
       hipLaunchKernelGGL(k_target_keys, dim3((nt + 255) / 256), dim3(256), 0, st, target, nt, frame, 1.0f / stripT,
-                         mode == 2 ? 1 : 0, sb.keys, sb.iota);
+                         mode == 2 ? 1 : 0, sb.keys);
       int rc = svm::sort_filled_keys(nt, permT, ws + L.off_sort, L.sort_bytes, st);
       if (rc) return rc;
     }
     if (nq) {
       const svm::SortBuffers sb = svm::sort_buffers(ws + L.off_sort, nq);
       hipLaunchKernelGGL(k_query_keys, dim3((nq + 255) / 256), dim3(256), 0, st, (const Geom*)geom, nq, mode, p->epsilon,
-                         (const Frame*)frame, 1.0f / stripQ, sb.keys, sb.iota);
+                         (const Frame*)frame, 1.0f / stripQ, sb.keys);
       int rc = svm::sort_filled_keys(nq, permQ, ws + L.off_sort, L.sort_bytes, st);
       if (rc) return rc;
     }

@@ -7,12 +7,11 @@
 namespace svm {
 // bytes of scratch sort_filled_keys needs for n elements (pure host arithmetic)
 size_t sort_scratch_bytes(uint32_t n);
-// the two arrays inside `scratch` the caller fills (on `stream`) before sort_filled_keys: keys[n] and iota[n] = 0 .. n-1
+// the array inside `scratch` the caller fills (on `stream`) before sort_filled_keys: keys[n]
 struct SortBuffers {
   uint32_t* keys;
-  uint32_t* iota;
 };
 SortBuffers sort_buffers(void* scratch, uint32_t n);
-// perm[0..n) = iota reordered by ascending key (stable); asynchronous on `stream`
+// perm[0..n) = 0 .. n-1 ordered by ascending (key, index): unique, so reproducible; asynchronous on `stream`
 int sort_filled_keys(uint32_t n, uint32_t* perm, void* scratch, size_t scratchBytes, hipStream_t stream);
 }  // namespace svm

@@ -244,6 +244,34 @@ def test_band_frame_is_only_an_order(direction, strip):
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_key_sort_orders_by_key_then_index(capi):
+    """ssrlcv_hip_sort_keys_u32 (csrc/spatial_sort.hip: bucket by the key's high half, bitonic per bucket): the
+    permutation is numpy's order by (bucket, key, index), which is the stable argsort of the keys while the strips fit one
+    window of 4096 -- for frame-like keys (a few hundred strips), for arbitrary 32-bit words (every bucket used, strips
+    aliasing into buckets), for one bucket holding everything (the global-memory network, sizes that are and are not
+    powers of two), for duplicates and for tiny inputs."""
+    import torch
+    rng = np.random.default_rng(8)
+    cases = []
+    strips = rng.integers(32768 - 150, 32768 + 150, 300000).astype(np.uint32)
+    cases.append((strips << 16) | rng.integers(32768 - 3000, 32768 + 3000, 300000).astype(np.uint32))   # frame-like
+    cases.append(rng.integers(0, 2 ** 32, 200000, dtype=np.uint64).astype(np.uint32))                    # arbitrary words
+    cases.append((np.uint32(32768) << 16) | rng.integers(0, 65536, 20000).astype(np.uint32))            # one bucket, > LDS
+    cases.append((np.uint32(32768) << 16) | rng.integers(0, 65536, 16384).astype(np.uint32))            # ... a power of two
+    cases.append((np.uint32(40000) << 16) | rng.integers(0, 4, 5000).astype(np.uint32))                 # heavy duplicates
+    cases.append(np.full(777, 0xFFFFFFFF, np.uint32))
+    cases.append(np.array([5], np.uint32))
+    cases.append(np.array([9, 3, 3, 1 << 31, 0], np.uint32))
+    for keys in cases:
+        perm = capi.sort_keys(capi.to_dev(keys), len(keys)).cpu().numpy().view(np.uint32)
+        bucket = ((keys >> 16) + 2048) & 4095
+        ref = np.lexsort((np.arange(len(keys)), keys, bucket)).astype(np.uint32)
+        assert np.array_equal(perm, ref), len(keys)
+        if int(keys.max() >> 16) - int(keys.min() >> 16) < 2048 and 30720 <= int(keys.min() >> 16) and int(keys.max() >> 16) < 34816:
+            assert np.array_equal(perm, np.argsort(keys, kind="stable").astype(np.uint32))
+    assert capi.sort_keys(torch.empty(0, dtype=torch.uint8, device="cuda"), 0).numel() == 0
+
+
 def test_compact_matches_is_stable(capi):
     q, t = random_features(5000, 15, hi=64), random_features(800, 16, hi=64)
     probe = run_gpu(capi, 0, q, t, capi.OUT_DMATCH, absolute=3e7)
