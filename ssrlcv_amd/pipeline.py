@@ -17,6 +17,7 @@ torch.distributed); all compute is libssrlcv_hip.so.  A `Workspace` keeps the pe
 seed descriptors between calls: creating and freeing them per pair / per image was a third of a step.
 """
 import os
+import sys
 import time
 
 import numpy as np
@@ -186,13 +187,30 @@ def _pinned_copy(t_d, nbytes, slot):
     return stage.numpy()
 
 
+def _result_buffer(nbytes, slot):
+    """A host byte array for a result the caller will own.  Fresh arrays of this size (12 MB of key points per step of the
+    4 x 4096^2 flow) are mmap'ed and page-faulted by every call, and now and then that stalls for 25-30 ms (seen in bench.py's
+    N-view leg: one `merge` stage in five).  So the arrays are pooled per slot and handed out again once nobody outside the
+    pool refers to them any more (a result array is a view whose base is the pooled buffer: the reference count tells)."""
+    pool = build_match_set.__dict__.setdefault("_results", {}).setdefault(slot, [])
+    for buf in pool:
+        if buf.size >= nbytes and sys.getrefcount(buf) == 3:  # the pool's list, `buf`, getrefcount's argument
+            return buf
+    buf = np.empty(max(nbytes, 1 << 16), np.uint8)
+    if len(pool) >= 4:
+        pool.pop(0)
+    pool.append(buf)
+    return buf
+
+
 def _host_records(t_d, count, dtype, slot):
     """`count` records of a device byte tensor as a structured numpy array the caller owns.  The copy out of the staging
     buffer is a plain byte copy: `view(dtype).copy()` on a structured dtype went element by element and took 5 of the
     merge stage's 7 ms for 0.7 M key points."""
-    raw = np.empty(count * dtype.itemsize, np.uint8)
+    nbytes = count * dtype.itemsize
+    raw = _result_buffer(nbytes, slot)[:nbytes]
     if count:
-        np.copyto(raw, _pinned_copy(t_d, count * dtype.itemsize, slot))
+        np.copyto(raw, _pinned_copy(t_d, nbytes, slot))
     return raw.view(dtype)
 
 
