@@ -2079,7 +2079,7 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
   hipStream_t sd = as ? as->table : st;
   static const DogSchedule sched;
   static const bool overlapOctaves = svdev::env("SSRLCV_NO_OCTAVE_OVERLAP") == nullptr;
-  static const int overlapFrom = svdev::env("SSRLCV_OCTAVE_OVERLAP_FROM") ? atoi(svdev::env("SSRLCV_OCTAVE_OVERLAP_FROM")) : 2;
+  static const int overlapFrom = svdev::env("SSRLCV_OCTAVE_OVERLAP_FROM") ? atoi(svdev::env("SSRLCV_OCTAVE_OVERLAP_FROM")) : 1;
   hipLaunchKernelGGL(k_init_minmax, dim3(1), dim3(64), 0, st, mmAll, pairs);
   // S1+S2: u8 -> f32 + one 2x upsample (startingOctave = -1)
   float* in = (float*)(ws + plan->off_in0);
@@ -2109,9 +2109,11 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
     const svp::OctavePlan& oc = plan->oct[o];
     float* mm = mmAll + (size_t)o * 2 * (svp::kGauss + svp::kDog);
     const size_t* offGauss = plan->off_gauss[o];
-    // Octave 2 runs on a side stream: it only needs level 3 of octave 1 (its bin), so its latency-bound levels run beside
-    // levels 4-5 of octave 1; octave 3, back on the caller's stream behind octave 1, then runs beside levels 4-5 of
-    // octave 2.  (Octave 1 stays behind octave 0: levels 4-5 of octave 0 fill every CU's LDS.)
+    // An octave only needs level 3 of the one before (its bin), so octaves alternate between the caller's stream and a side
+    // stream from octave `overlapFrom` on: the next octave's first levels run beside levels 4-5 of the current one.
+    // Rounds 2-3 started at octave 2 (levels 4-5 of octave 0 were MFMA blocks that filled every CU's LDS: octave 1 beside
+    // them only waited); with level 4 on the register-marching kernel octave 1 finds room: end of round 4, the bench step
+    // 10.13 -> 10.09 ms, the stage 1.708 -> 1.683 ms per 4096^2 image (two runs each), so the default is 1.
     const hipStream_t so = (as && overlapOctaves && o >= overlapFrom && ((o - overlapFrom) & 1) == 0) ? as->chain : st;
     // DoG / extrema passes: octaves 0 and 1 on the side stream (beside the next octave's convolutions); with the overlap
     // the last two follow their own convolutions on those streams -- behind octave 1's in one in-order stream they were the tail
