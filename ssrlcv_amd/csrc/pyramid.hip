@@ -1268,19 +1268,18 @@ __global__ __launch_bounds__(256) void k_dogx(DogxArgs a) {
   for (int k = 0; k < 3; ++k)
 #pragma unroll
     for (int i = 0; i < NPX; ++i) { gmxA[k][i] = gmnA[k][i] = gmxB[k][i] = gmnB[k][i] = ctrB[k][i] = 0.0f; }
-  vec nxt[svp::kGauss];
+  // The next row is loaded into the registers of the current one as soon as its values have been normalised (they are
+  // dead then): the loads fly under the ~300 instructions of the rest of the row.  (A separate `next` set, copied at the
+  // top of the loop, was 24 of the row's 430 vector instructions.)
+  vec cur[svp::kGauss];
   auto fetch = [&](int y) {
     y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);  // rows -1 and H only neighbour border rows, which do not flag
     const size_t row = (size_t)y * W + xl;
 #pragma unroll
-    for (int b = first; b <= last; ++b) nxt[b] = __builtin_nontemporal_load(reinterpret_cast<const vec*>(a.lvl[b] + row));
+    for (int b = first; b <= last; ++b) cur[b] = __builtin_nontemporal_load(reinterpret_cast<const vec*>(a.lvl[b] + row));
   };
   fetch(r0 - 1);
   for (int y = r0 - 1; y <= r1; ++y) {
-    vec cur[svp::kGauss];
-#pragma unroll
-    for (int b = first; b <= last; ++b) cur[b] = nxt[b];
-    if (y < r1) fetch(y + 1);
     // normalised levels and DoG values of this row
     float d[svp::kDog][NPX];
     {
@@ -1298,6 +1297,14 @@ __global__ __launch_bounds__(256) void k_dogx(DogxArgs a) {
         for (int i = 0; i < NPX; ++i) prev[i] = n[i];
       }
     }
+    // (the compiler would issue these loads at the top of the row, into other registers, and copy: the DoG values are
+    // pinned in front of them)
+#pragma unroll
+    for (int b = first; b < last; ++b) {
+#pragma unroll
+      for (int i = 0; i < NPX; ++i) asm volatile("" : "+v"(d[b][i]) : : "memory");
+    }
+    if (y < r1) fetch(y + 1);
     // 3-wide max / min per level; the level's {min, max} ride on them (pixel i's triple covers i - 1 .. i + 1; the halo
     // rows and columns a wave sees beyond its own are pixels of the image too)
     float hmx[svp::kDog][NPX], hmn[svp::kDog][NPX];
