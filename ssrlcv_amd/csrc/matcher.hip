@@ -1018,6 +1018,15 @@ int ssrlcv_dbg_match_stats(unsigned long long* out12) {
            f[0] / f[4], f[1] / f[4], f[2] / f[4], f[3] / f[4], f[4], f[5]);
   float zf[8] = {0};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_match_fstats), zf, sizeof(zf));
+  unsigned long long cy[8];
+  (void)hipMemcpyFromSymbol(cy, HIP_SYMBOL(g_match_cycles), sizeof(cy));
+  if (cy[5])
+    printf("s_memtime of the band-culled waves: whole 100 %%; waiting for the tile in flight %.1f %%, slot -> registers %.1f %%, queueing the next "
+           "transfer %.1f %%, chains + epilogue %.1f %% (of which the slow path %.1f %%), walk between hits %.1f %%\n",
+           100.0 * cy[0] / cy[5], 100.0 * cy[1] / cy[5], 100.0 * cy[2] / cy[5], 100.0 * cy[3] / cy[5], 100.0 * cy[6] / cy[5],
+           100.0 * cy[4] / cy[5]);
+  unsigned long long zc[8] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_match_cycles), zc, sizeof(zc));
   return 0;
 }
 #endif
