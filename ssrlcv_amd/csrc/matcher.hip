@@ -868,10 +868,10 @@ int run_match(const ssrlcv_sift_feature* query, uint32_t nq, const ssrlcv_sift_f
   } else {
     hipLaunchKernelGGL(k_pack_i8, dim3((L.nq_pad * 16 + 255) / 256), dim3(256), 0, st, query, nq, L.nq_pad, 0, permQ,
                        (uint8_t*)pq, (int*)nqv, (ssrlcv_float2*)nullptr, 0);
-    // band-culled targets: tile records in the order of the matcher's LDS slot (the region is sized for the fp16 rows:
-    // 9216 bytes per tile, a record takes 5120)
+    // targets: tile records in the order of the matchers' LDS slots (the region is sized for the fp16 rows: 9216 bytes
+    // per tile, a record takes 5120)
     hipLaunchKernelGGL(k_pack_i8, dim3((L.nt_pad * 16 + 255) / 256), dim3(256), 0, st, target, nt, L.nt_pad, 1, permT,
-                       (uint8_t*)pt, (int*)(ws + L.off_nt), lt, band ? 1 : 0);
+                       (uint8_t*)pt, (int*)(ws + L.off_nt), lt, 1);
   }
   SSRLCV_HIP_TRY(hipMemsetAsync(keys, 0xff, (size_t)L.nq_pad * 8, st));
   const float eps = mode != 0 ? p->epsilon : 0.0f;
