@@ -118,20 +118,21 @@ __device__ __forceinline__ void bitonic_ascending(Ptr w, uint32_t cnt) {
   }
 }
 
-__global__ __launch_bounds__(256) void k_bin_sort(const uint32_t* __restrict__ binBase, unsigned long long* __restrict__ words,
+constexpr int kSortThreads = 1024;  // a bin's network is ~70 dependent stages of a few pairs per thread: latency, so many waves
+__global__ __launch_bounds__(kSortThreads) void k_bin_sort(const uint32_t* __restrict__ binBase, unsigned long long* __restrict__ words,
                                                   uint32_t* __restrict__ perm) {
   __shared__ unsigned long long s_w[kSortCap];
   const uint32_t b0 = binBase[blockIdx.x], cnt = binBase[blockIdx.x + 1] - b0;  // (block-uniform)
   if (cnt == 0) return;
   if (cnt <= (uint32_t)kSortCap) {
-    for (uint32_t i = threadIdx.x; i < cnt; i += 256) s_w[i] = words[b0 + i];
+    for (uint32_t i = threadIdx.x; i < cnt; i += kSortThreads) s_w[i] = words[b0 + i];
     __syncthreads();
     bitonic_ascending(s_w, cnt);
-    for (uint32_t i = threadIdx.x; i < cnt; i += 256) perm[b0 + i] = (uint32_t)s_w[i];
+    for (uint32_t i = threadIdx.x; i < cnt; i += kSortThreads) perm[b0 + i] = (uint32_t)s_w[i];
   } else {  // a bin beyond the LDS capacity (every feature in one strip ...): in place in global memory, rare and merely right
     unsigned long long* w = words + b0;
     bitonic_ascending(w, cnt);
-    for (uint32_t i = threadIdx.x; i < cnt; i += 256) perm[b0 + i] = (uint32_t)w[i];
+    for (uint32_t i = threadIdx.x; i < cnt; i += kSortThreads) perm[b0 + i] = (uint32_t)w[i];
   }
 }
 }  // namespace
@@ -166,7 +167,7 @@ int sort_filled_keys(uint32_t n, uint32_t* perm, void* scratch, size_t scratchBy
   hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, stream, (const uint32_t*)binCount, binBase, cursor);
   hipLaunchKernelGGL(k_bin_scatter, dim3(kChunkBlocks), dim3(256), 0, stream, keys, n, chunk, (const uint32_t*)binBase, cursor,
                      words);
-  hipLaunchKernelGGL(k_bin_sort, dim3(kBins), dim3(256), 0, stream, (const uint32_t*)binBase, words, perm);
+  hipLaunchKernelGGL(k_bin_sort, dim3(kBins), dim3(kSortThreads), 0, stream, (const uint32_t*)binBase, words, perm);
   e = hipGetLastError();
   return e == hipSuccess ? SSRLCV_OK : (int)e;
 }
