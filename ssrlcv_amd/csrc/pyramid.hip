@@ -1162,14 +1162,17 @@ __global__ __launch_bounds__(256) void k_dog(DogArgs a, int first, int last) {
   }
 }
 
-// PARTIAL mode, second step: block b reduces the per-wave partials of DoG level first + b and stores its {min, max}
-__global__ __launch_bounds__(256) void k_dog_finalize(const float* __restrict__ partial, unsigned waves, int first,
-                                                      float* __restrict__ dogMinMax) {
+// PARTIAL mode, second step: block b reduces the per-wave partials of DoG level first + b and stores its {min, max}.
+// 1024 threads: the kernel sits between the pass of octave o and that of octave o + 1 on the side stream, and five blocks
+// of 256 threads walking 14 336 partials each took 44 us of pure load latency there.
+constexpr int kFinalizeThreads = 1024;
+__global__ __launch_bounds__(kFinalizeThreads) void k_dog_finalize(const float* __restrict__ partial, unsigned waves, int first,
+                                                                   float* __restrict__ dogMinMax) {
   const int b = first + (int)blockIdx.x;
   const float* pmn = partial + (size_t)(2 * b) * svp::kDogMaxWaves;
   const float* pmx = partial + (size_t)(2 * b + 1) * svp::kDogMaxWaves;
   float mn = FLT_MAX, mx = -FLT_MAX;
-  for (unsigned i = threadIdx.x; i < waves; i += 256) {
+  for (unsigned i = threadIdx.x; i < waves; i += kFinalizeThreads) {
     mn = fminf(mn, pmn[i]);
     mx = fmaxf(mx, pmx[i]);
   }
@@ -1178,12 +1181,12 @@ __global__ __launch_bounds__(256) void k_dog_finalize(const float* __restrict__ 
     mn = fminf(mn, __shfl_xor(mn, o, 64));
     mx = fmaxf(mx, __shfl_xor(mx, o, 64));
   }
-  __shared__ float s_red[8];
+  __shared__ float s_red[2 * kFinalizeThreads / 64];
   const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) { s_red[2 * wave] = mn; s_red[2 * wave + 1] = mx; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; ++w) { mn = fminf(mn, s_red[2 * w]); mx = fmaxf(mx, s_red[2 * w + 1]); }
+    for (int w = 1; w < kFinalizeThreads / 64; ++w) { mn = fminf(mn, s_red[2 * w]); mx = fmaxf(mx, s_red[2 * w + 1]); }
     dogMinMax[2 * b] = mn;
     dogMinMax[2 * b + 1] = mx;
   }
@@ -1451,7 +1454,7 @@ int launch_dogx(const float* const levels[svp::kGauss], const float* levelMinMax
   else if (first == 1 && last == 5 && mmFirst == 3 && orFlags) SSRLCV_LAUNCH_DOGX(1, 5, 3, true);
   else return SSRLCV_ERR_INVALID_ARG;  // the three launches build_dog's schedule is made of
 #undef SSRLCV_LAUNCH_DOGX
-  hipLaunchKernelGGL(k_dog_finalize, dim3((unsigned)(last - mmFirst)), dim3(256), 0, st, partial, waves, mmFirst, dogMinMax);
+  hipLaunchKernelGGL(k_dog_finalize, dim3((unsigned)(last - mmFirst)), dim3(kFinalizeThreads), 0, st, partial, waves, mmFirst, dogMinMax);
   SSRLCV_LAUNCH_CHECK();
   return SSRLCV_OK;
 }
@@ -1863,7 +1866,7 @@ static int launch_dog(const float* const levels_host[6], const float* levelMinMa
     if (maxBlocks > svp::kDogMaxBlocks) maxBlocks = svp::kDogMaxBlocks;
     if (blocks > maxBlocks) blocks = maxBlocks;
     hipLaunchKernelGGL(k_dog<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, firstDog, lastDog);
-    hipLaunchKernelGGL(k_dog_finalize, dim3((unsigned)(lastDog - firstDog)), dim3(256), 0, (hipStream_t)stream, partial,
+    hipLaunchKernelGGL(k_dog_finalize, dim3((unsigned)(lastDog - firstDog)), dim3(kFinalizeThreads), 0, (hipStream_t)stream, partial,
                        (unsigned)blocks * 4, firstDog, dogMinMax);
   } else {
     if (blocks > 1024) blocks = 1024;  // 4 blocks per CU; each block ends with up to 10 same-address atomics
