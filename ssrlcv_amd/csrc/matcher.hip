@@ -839,8 +839,15 @@ int run_match(const ssrlcv_sift_feature* query, uint32_t nq, const ssrlcv_sift_f
     // the frame of the pair and the two orders (see "band culling"): bands of the queries in caller order -> u ->
     // targets by (strip across u, position along u) -> queries by where their band lies
     static const float forceDeg = svdev::env("SSRLCV_BAND_DIR") ? (float)atof(svdev::env("SSRLCV_BAND_DIR")) : 1e30f;
-    static const float stripT = svdev::env("SSRLCV_BAND_STRIP") ? (float)atof(svdev::env("SSRLCV_BAND_STRIP")) : SSRLCV_BAND_STRIP;
-    static const float stripQ = svdev::env("SSRLCV_BAND_STRIP_Q") ? (float)atof(svdev::env("SSRLCV_BAND_STRIP_Q")) : stripT;
+    // strip width: 0.4 epsilon within [4, 16] px (the bands are 2 epsilon thick; end of round 4, epsilon 25 on the 4-view
+    // 4096^2 flow: 6 px 6.48 ms, 8 6.57, 10 6.54, 12 6.58, 16 6.87, 20 7.43, 24 7.2; queries at half or twice the targets'
+    // width no better)
+    static const float stripEnvT = svdev::env("SSRLCV_BAND_STRIP") ? (float)atof(svdev::env("SSRLCV_BAND_STRIP")) : 0.0f;
+    static const float stripEnvQ = svdev::env("SSRLCV_BAND_STRIP_Q") ? (float)atof(svdev::env("SSRLCV_BAND_STRIP_Q")) : 0.0f;
+    const float epsAbs = fabsf(p->epsilon);
+    const float stripAuto = !(epsAbs == epsAbs) ? (float)SSRLCV_BAND_STRIP : fminf(16.0f, fmaxf(4.0f, 0.4f * epsAbs));
+    const float stripT = stripEnvT > 0.0f ? stripEnvT : stripAuto;
+    const float stripQ = stripEnvQ > 0.0f ? stripEnvQ : stripT;
     launch_geom(nullptr);
     hipLaunchKernelGGL(k_band_direction, dim3(1), dim3(1024), 0, st, (const Geom*)geom, nq, mode, forceDeg, frame);
     if (nt) {
