@@ -239,13 +239,14 @@ __device__ __forceinline__ bool passes_prefilter(const Geom& g, ssrlcv_float2 t,
 // per-pair test in the epilogue's slow path.  Now
 //   * u = the dominant direction of the queries' bands in the target image (axial mean, k_band_direction); the frame
 //     (w, v) = (u . p, u_perp . p) has w along the bands and v across them;
-//   * targets are ordered by (v strip of kStrip pixels, w): a tile is kStrip pixels across the bands and long along them;
+//   * targets are ordered by (v strip, w), strips 0.4 epsilon wide within [4, 16] px: a tile is one strip across the bands
+//     and long along them;
 //   * queries are ordered by WHERE THEIR BAND LIES in that frame (v strip of the band's centre, then its w), not by where
 //     they are in their own image: the 32 bands of a wave nearly coincide;
 //   * boxes and bands are compared in the frame: a band is the line v = vc + slope (w - wc), |w - wc| <= hw, thickened by
 //     `half` (BandR, formed in double precision from the Geom of the exact test), a box is centre + half extents, and the
 //     test is 8 vector instructions with no per-test margin arithmetic (the margins are folded into hw / half / the boxes).
-// With horizontal epipolar lines (the bench scenes) this equals 16-pixel row strips, which alone took the match stage of
+// With horizontal epipolar lines (the bench scenes) this equals image-row strips; at 16 pixels those alone took the match stage of
 // the 4 x 4096^2 flow from 22.4 to 14.6 ms; the frame makes that independent of the direction of the baseline.
 struct Frame {        // device-resident, written by k_band_direction / k_target_keys
   float ux, uy;       // unit vector along the bands (target image)
