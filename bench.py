@@ -102,7 +102,10 @@ def git_head():
         return None
 
 
-def bench_matcher(capi, torch, nq, nt, iters):
+def bench_matcher(capi, torch, nq, nt, iters, arithmetic="int8"):
+    """ssrlcv_hip_match_u8x128, brute force, Nq x Nt synthetic descriptors.  arithmetic = "int8" (the default formulation:
+    v_mfma_i32_32x32x32_i8, priced against the int8 dense peak) or "f16" (v_mfma_f32_32x32x16_f16, the formulation the
+    north star names, priced against the fp16 dense peak); both exact, selected by ssrlcv_hip_set_match_arithmetic."""
     q = synth_descriptors(nq, 1)
     t = synth_descriptors(nt, 2)
     rng = np.random.default_rng(3)
@@ -113,30 +116,44 @@ def bench_matcher(capi, torch, nq, nt, iters):
     ws = capi.match_workspace(nq, nt)
     out = capi.dev_bytes(nq * 48)
     params = capi.make_match_params(0, 0, 1, 0.0, 0.0, 0.6, 200.0 * 200.0)
-    capi.match(q_d, nq, t_d, nt, params, capi.OUT_DMATCH, workspace=ws, out=out)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
+    before = capi.get_match_arithmetic()
+    capi.set_match_arithmetic(capi.MATCH_ARITH_F16 if arithmetic == "f16" else capi.MATCH_ARITH_I8)
+    try:
         capi.match(q_d, nq, t_d, nt, params, capi.OUT_DMATCH, workspace=ws, out=out)
-    e1.record()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            capi.match(q_d, nq, t_d, nt, params, capi.OUT_DMATCH, workspace=ws, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+    finally:
+        capi.set_match_arithmetic(before)
     ms = e0.elapsed_time(e1) / iters
     pairs = float(nq) * float(nt)
     tops = 2.0 * 128.0 * pairs / (ms * 1e-3) / 1e12
-    return {"value": pairs / (ms * 1e-3) / 1e6, "unit": "Mmatches/s", "nq": nq, "nt": nt, "ms": ms,
-            "output_matches_per_s": nq / (ms * 1e-3), "dtype": "int8",
-            "roofline": {"bound": "mfma", "achieved": tops, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
-                         "frac": tops / MFMA_I8_PEAK_TOPS, "traffic": None,
-                         "frac_of_fp16_peak": tops / MFMA_F16_PEAK_TFLOPS,
-                         "sustained_peak_random_operands": MFMA_I8_SUSTAINED_TOPS,
-                         "frac_of_sustained_peak": tops / MFMA_I8_SUSTAINED_TOPS,
-                         "kernel": "k_match_i8 (v_mfma_i32_32x32x32_i8, exact), whole ssrlcv_hip_match_u8x128 call; "
-                                   "ops = 2*128*Nq*Nt, priced against the int8 dense peak (2x the fp16 peak the "
-                                   "north star names: frac_of_fp16_peak is the same rate against that); "
-                                   "sustained_peak_random_operands = the same instruction alone on random bytes "
-                                   "(tools/mfma_i8_peak.hip: the part is power-limited there, 4.96 POP/s on zeros); "
-                                   "matrix-pipe busy cycles and clock: profiles/r04_matcher_pmc.txt"}}
+    res = {"value": pairs / (ms * 1e-3) / 1e6, "unit": "Mmatches/s", "nq": nq, "nt": nt, "ms": ms,
+           "output_matches_per_s": nq / (ms * 1e-3), "dtype": arithmetic,
+           "checksum": int(torch.sum(out.view(torch.int32)[10::12].to(torch.int64)).item())}  # DMatch.distance bits: equal for both formulations
+    if arithmetic == "f16":
+        res["roofline"] = {"bound": "mfma", "achieved": tops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": tops / MFMA_F16_PEAK_TFLOPS, "traffic": None,
+                           "kernel": "k_match (v_mfma_f32_32x32x16_f16, exact: norms as base-1024 digits in a ninth K step), whole "
+                                     "ssrlcv_hip_match_u8x128 call; flops = 2*128*Nq*Nt (BASELINE.md section 4: the K = 144 the kernel "
+                                     "really issues is not credited), priced against the fp16 dense peak"}
+    else:
+        res["roofline"] = {"bound": "mfma", "achieved": tops, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
+                           "frac": tops / MFMA_I8_PEAK_TOPS, "traffic": None,
+                           "frac_of_fp16_peak": tops / MFMA_F16_PEAK_TFLOPS,
+                           "sustained_peak_random_operands": MFMA_I8_SUSTAINED_TOPS,
+                           "frac_of_sustained_peak": tops / MFMA_I8_SUSTAINED_TOPS,
+                           "kernel": "k_match_i8 (v_mfma_i32_32x32x32_i8, exact), whole ssrlcv_hip_match_u8x128 call; "
+                                     "ops = 2*128*Nq*Nt, priced against the int8 dense peak (2x the fp16 peak the "
+                                     "north star names: frac_of_fp16_peak is the same rate against that); "
+                                     "sustained_peak_random_operands = the same instruction alone on random bytes "
+                                     "(tools/mfma_i8_peak.hip: the part is power-limited there, 4.96 POP/s on zeros); "
+                                     "matrix-pipe busy cycles and clock: profiles/r04_matcher_pmc.txt"}
+    return res
 
 
 def bench_matcher_epipolar(capi, torch, n, size, iters):
@@ -359,6 +376,7 @@ def run_nview(args, torch, dist, capi, world, rank, dev, views, size, steps, war
     import helpers as H
     import scene
     from ssrlcv_amd import pipeline
+    from ssrlcv_amd import dist as sd
     imgs, cams, _, _ = scene.pinhole_views(views, size, device=dev)
     seed, _ = H.load_seed_features()
     ws = pipeline.Workspace()
@@ -384,16 +402,43 @@ def run_nview(args, torch, dist, capi, world, rank, dev, views, size, steps, war
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    mine = {k: v / steps * 1e3 for k, v in ws.times.items()}
+    per_rank = [mine]
+    if dist is not None:   # every rank's stage times: the spread is the load imbalance (pairs of different cost, images per rank)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+    stage_names = list(mine.keys())
+    spread = {k: {"min": min(r.get(k, 0.0) for r in per_rank), "max": max(r.get(k, 0.0) for r in per_rank)} for k in stage_names}
+    nf = [int(f.numel() // 152) for f in res["features"]]
+    owners = sd.assign_pairs(nf, world)
+    pairs = sd.pair_list(views)
+    cost = [float(nf[i]) * nf[j] for i, j in pairs]
+    load = [sum(c for c, o in zip(cost, owners) if o == r) for r in range(world)]
+    step_ms = dt / steps * 1e3
+    # stages every rank repeats on the whole problem (the rest shrinks with the rank count): the serial fraction of the flow
+    replicated = sum(mine.get(k, 0.0) for k in ("merge", "filter"))
+    wire = {"exchange_features_bytes": int(sum(f.numel() for f in res["features"])),
+            "exchange_pairs_bytes": int(sum(p.numel() for p in res["pairs"])),
+            "cloud_all_gather_bytes": int(res["points"].shape[0] * 12),
+            "ba_all_reduce_bytes": 612 * 4,
+            "note": "payload every rank ends up holding, per step; each rank sends its own share once at its exact size "
+                    "(one grouped broadcast per rank, dist._gather_segments); world 1 moves nothing"}
     return {"metric": "Mpix/s N-view reconstruction (SIFT + exhaustive orbit match + merge + N-view triangulate + BA sweep)",
             "value": views * size * size * steps / dt / 1e6, "unit": "Mpix/s", "n_gpus": world, "steps": steps,
-            "ms_per_step": dt / steps * 1e3, "scaling": "strong",
+            "ms_per_step": step_ms, "scaling": "strong", "views": views, "pairs": len(pairs),
             "workload": "%d-view %dx%d scene, image/pair shard over %d GPU(s): all-gather of features, pairs balanced by "
                         "nq*nt, all-gather of uint2_pair arrays, replicated merge on the device (ssrlcv_hip_merge_matches), bundle-range "
                         "triangulation + all-gather of the cloud, 612-point BA error sweep + all-reduce" % (views, size, size, world),
-            "stage_ms_per_step_rank0": {k: v / steps * 1e3 for k, v in ws.times.items()},
+            "stage_ms_per_step_rank0": mine,
+            "stage_ms_per_step_over_ranks": spread,
+            "replicated_stage_ms": replicated, "replicated_share_of_step": replicated / step_ms if step_ms else None,
+            "pair_cost_share_per_rank": [l / max(sum(cost), 1.0) for l in load],
+            "pair_balance_max_over_mean": max(load) / (sum(load) / world) if sum(load) else None,
+            "images_per_rank": [sum(1 for v in range(views) if sd.image_owner(v, world) == r) for r in range(world)],
+            "wire": wire,
             "multi_matches": int(len(res["matches"])), "points": int(res["points"].shape[0]),
             "ba_bundles": int(res.get("ba_bundles", 0)),
-            "features_per_image": [int(f.numel() // 152) for f in res["features"]]}
+            "features_per_image": nf}
 
 
 def main():
@@ -412,7 +457,9 @@ def main():
     ap.add_argument("--no-matcher", action="store_true")
     ap.add_argument("--no-nview", action="store_true")
     ap.add_argument("--no-class-api", action="store_true")
-    ap.add_argument("--nview-views", type=int, default=4)
+    ap.add_argument("--nview-views", type=int, default=0,
+                    help="views of the N-view leg; 0 = max(4, world): config[3]'s four views (6 pairs) up to four ranks, eight views "
+                         "(28 pairs, src/MatchFactory.cu:907-1028 order) on eight, so that no rank is left without an image or a pair")
     ap.add_argument("--nview-size", type=int, default=4096, help="edge of the N-view leg's images (config[3]: 4-view 4096x4096)")
     ap.add_argument("--nview-steps", type=int, default=2)
     ap.add_argument("--noise-input", action="store_true", help="round-1 input: multi-scale noise instead of the scene generator")
@@ -430,7 +477,7 @@ def main():
     else:
         dist = None
         torch.cuda.set_device(0)
-    from ssrlcv_amd import capi  # raises if the HIP library is missing: no CPU fallback
+    from ssrlcv_amd import capi, _lib  # raises if the HIP library is missing: no CPU fallback (default: the release build)
     import scene
 
     W = H_ = args.size
@@ -504,7 +551,8 @@ def main():
             "dtype": "f32", "data": "synthetic", "commit": git_head(),
             "config": {"workload": "2-view %dx%d pair per GPU (%s): SIFT_FeatureFactory::generateFeatures (sparse DoG "
                                    "path) on each image, pixels resident in HBM" % (W, H_, workload),
-                       "images_per_gpu": args.images, "features_per_image": nfeat, "parallelism": "image-pair shard"},
+                       "images_per_gpu": args.images, "features_per_image": nfeat, "parallelism": "image-pair shard",
+                       "library": "%s build (%s)" % (_lib.flavour(), os.path.basename(_lib.LIB_PATH))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "scale-space stage = ssrlcv_hip_sift_build_dog: S1-S8 (u8 upsample in the first level's loader, "
@@ -525,7 +573,8 @@ def main():
     if not args.no_nview:
         # every rank enters the N-view leg together (the barrier inside run_nview): the rank-0-only legs come after it,
         # so that its stage times are not polluted by rank skew
-        nv = run_nview(args, torch, dist, capi, world, rank, dev, args.nview_views, args.nview_size, args.nview_steps, 1)
+        nviews = args.nview_views if args.nview_views > 0 else max(4, world)
+        nv = run_nview(args, torch, dist, capi, world, rank, dev, nviews, args.nview_size, args.nview_steps, 1)
         if rank == 0:
             line["nview"] = nv
     if rank == 0:
@@ -533,6 +582,8 @@ def main():
             line["class_api"] = class_api_leg(img0, W, line["value"] / world)
         if not args.no_matcher:
             line["matcher"] = bench_matcher(capi, torch, args.match_n, args.match_n, args.match_iters)
+            line["matcher_f16"] = bench_matcher(capi, torch, args.match_n, args.match_n, args.match_iters, "f16")
+            line["matcher_f16"]["same_output_as_int8"] = line["matcher_f16"]["checksum"] == line["matcher"]["checksum"]
             line["matcher_epipolar"] = bench_matcher_epipolar(capi, torch, args.match_n, W, args.match_iters)
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a single-GPU-run figure
             line["cpu_baseline"] = cpu_baseline(args.cpu_size, args.cpu_big, args.cpu_reps)

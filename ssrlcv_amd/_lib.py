@@ -1,9 +1,27 @@
-"""ctypes loader for libssrlcv_hip.so.  Fails loudly when the HIP extension has not been built."""
+"""ctypes loader for the HIP C-ABI library.  Fails loudly when the extension has not been built.
+
+Two flavours are built from the same sources (csrc/Makefile): libssrlcv_hip_release.so -- what INTEGRATION.md tells a
+deployer to link: every SSRLCV_* developer switch compiled out (csrc/dev_switch.h) -- and libssrlcv_hip.so, the developer
+build whose code paths the environment can steer.  The RELEASE flavour is the default here, so bench.py, smoke() and the
+parity tests run the library that ships; SSRLCV_DEV_BUILD=1 selects the developer build (the formulation-by-formulation
+tests do, in child processes: tests/helpers.py dev_env), SSRLCV_HIP_LIB=<path> any other build (A/B experiments)."""
 import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("SSRLCV_HIP_LIB", os.path.join(_HERE, "libssrlcv_hip.so"))  # override: developer experiments
+RELEASE_LIB_PATH = os.path.join(_HERE, "libssrlcv_hip_release.so")
+DEV_LIB_PATH = os.path.join(_HERE, "libssrlcv_hip.so")
+LIB_PATH = os.environ.get("SSRLCV_HIP_LIB") or (DEV_LIB_PATH if os.environ.get("SSRLCV_DEV_BUILD") else RELEASE_LIB_PATH)
+
+
+def flavour():
+    """'release', 'developer' or the path of a custom build: which library this process loads."""
+    real = os.path.realpath(LIB_PATH)
+    if real == os.path.realpath(RELEASE_LIB_PATH):
+        return "release"
+    if real == os.path.realpath(DEV_LIB_PATH):
+        return "developer"
+    return LIB_PATH
 
 _lib = None
 
@@ -18,7 +36,7 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise HipExtensionMissing(
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
-                "`make -C ssrlcv_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+                "`make -C ssrlcv_amd/csrc all release` (there is no CPU fallback)" % LIB_PATH)
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.ssrlcv_hip_version.restype = ctypes.c_char_p
         _lib.ssrlcv_hip_status_string.restype = ctypes.c_char_p
@@ -37,7 +55,7 @@ EXPORTED = [
     "ssrlcv_hip_generate_bundles", "ssrlcv_hip_generate_pushbroom_bundles", "ssrlcv_hip_triangulate2",
     "ssrlcv_hip_triangulateN", "ssrlcv_hip_ba_sweep2_workspace_bytes", "ssrlcv_hip_ba_sweep2",
     "ssrlcv_hip_pose_lm_terms", "ssrlcv_hip_pose_cost",
-    "ssrlcv_projection_matrix_host", "ssrlcv_hip_match_workspace_bytes", "ssrlcv_hip_seed_distances_u8x128",
+    "ssrlcv_projection_matrix_host", "ssrlcv_hip_match_workspace_bytes", "ssrlcv_hip_set_match_arithmetic", "ssrlcv_hip_get_match_arithmetic", "ssrlcv_hip_seed_distances_u8x128",
     "ssrlcv_hip_match_u8x128", "ssrlcv_hip_compact_matches", "ssrlcv_hip_compact_matches_async", "ssrlcv_hip_keypoints_from_members",
     "ssrlcv_hip_matchset_from_matches", "ssrlcv_merge_matches_host", "ssrlcv_merge_matches_host_mode", "ssrlcv_host_free", "ssrlcv_assign_pairs_host",
     "ssrlcv_hip_merge_workspace_bytes", "ssrlcv_hip_merge_matches",

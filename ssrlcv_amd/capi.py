@@ -206,6 +206,18 @@ def make_match_params(mode, query_id, target_id, epsilon=0.0, delta=0.0, rel=0.0
     return p
 
 
+MATCH_ARITH_I8, MATCH_ARITH_F16 = 0, 1
+
+
+def set_match_arithmetic(arithmetic):
+    """int8 MFMA (default) or fp16 MFMA behind every matcher call of this process: both exact, same outputs."""
+    check(LIB.ssrlcv_hip_set_match_arithmetic(c_int(arithmetic)))
+
+
+def get_match_arithmetic():
+    return int(LIB.ssrlcv_hip_get_match_arithmetic())
+
+
 def match(query_d, nq, target_d, nt, params, out_kind=OUT_DMATCH, seed_d=None, workspace=None, out=None):
     ws = workspace if workspace is not None else match_workspace(nq, nt)
     if out is None:

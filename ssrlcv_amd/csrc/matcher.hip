@@ -30,6 +30,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <atomic>
 #include "compact.h"
 #include "dev_switch.h"
 #include "device_math.h"
@@ -774,6 +775,13 @@ __global__ __launch_bounds__(256) void k_seed_finalize(const unsigned long long*
   out[q] = (k == kNoKey) ? FLT_MAX : (float)(uint32_t)(k >> 32);
 }
 
+// Which formulation of the distance contraction the matcher calls use (process-wide; ssrlcv_hip_set_match_arithmetic):
+// both are exact, so the choice never changes a result.  The developer build starts from SSRLCV_MATCH_F16.
+std::atomic<int>& match_arithmetic() {
+  static std::atomic<int> a(svdev::env("SSRLCV_MATCH_F16") != nullptr ? SSRLCV_MATCH_ARITH_F16 : SSRLCV_MATCH_ARITH_I8);
+  return a;
+}
+
 struct Layout {
   uint32_t nq_pad, nt_pad;
   size_t off_pq, off_pt, off_nq, off_nt, off_lt, off_geom, off_key, off_scratch, off_permq, off_permt, off_tilebox, off_groupbox,
@@ -866,8 +874,9 @@ int run_match(const ssrlcv_sift_feature* query, uint32_t nq, const ssrlcv_sift_f
       if (rc) return rc;
     }
   }
-  // Integer formulation (matcher_i8.inc) by default; SSRLCV_MATCH_F16=1 selects the fp16 one (same results).
-  static const bool useF16 = svdev::env("SSRLCV_MATCH_F16") != nullptr;
+  // Integer formulation (matcher_i8.inc) by default; ssrlcv_hip_set_match_arithmetic(SSRLCV_MATCH_ARITH_F16) -- or, in the
+  // developer build, SSRLCV_MATCH_F16=1 -- selects the fp16 one (same results).
+  const bool useF16 = match_arithmetic().load(std::memory_order_relaxed) == SSRLCV_MATCH_ARITH_F16;
   if (useF16) {
     hipLaunchKernelGGL(k_pack, dim3((L.nq_pad * 16 + 255) / 256), dim3(256), 0, st, query, nq, L.nq_pad, 0, permQ, pq, nqv,
                        (ssrlcv_float2*)nullptr);
@@ -1009,6 +1018,13 @@ __global__ __launch_bounds__(256) void k_matchset(const ELEM* __restrict__ in, u
 }  // namespace
 
 extern "C" {
+
+int ssrlcv_hip_set_match_arithmetic(int arithmetic) {
+  if (arithmetic != SSRLCV_MATCH_ARITH_I8 && arithmetic != SSRLCV_MATCH_ARITH_F16) return SSRLCV_ERR_INVALID_ARG;
+  match_arithmetic().store(arithmetic, std::memory_order_relaxed);
+  return SSRLCV_OK;
+}
+int ssrlcv_hip_get_match_arithmetic(void) { return match_arithmetic().load(std::memory_order_relaxed); }
 
 size_t ssrlcv_hip_match_workspace_bytes(uint32_t numQuery, uint32_t numTarget) {
   return make_layout(numQuery, numTarget).total;

@@ -187,14 +187,39 @@ def _pinned_copy(t_d, nbytes, slot):
     return stage.numpy()
 
 
+def _pool_probe():
+    """How sys.getrefcount reads for a pooled array nobody else refers to, measured with the very loop _result_buffer runs
+    (the pool's list, the loop variable, getrefcount's argument: 3 on CPython 3.10; interpreters that borrow references
+    read lower), and checked: one outstanding view must read exactly one more.  None = the count cannot be trusted on this
+    interpreter, and the pool is not used (every result gets a fresh array)."""
+    pool = [np.empty(16, np.uint8)]
+    free = held = None
+    for buf in pool:
+        free = sys.getrefcount(buf)
+    view = pool[0][:8].view(np.uint16)   # what a caller holds: a view whose base is the pooled buffer
+    for buf in pool:
+        held = sys.getrefcount(buf)
+    del view
+    for buf in pool:
+        again = sys.getrefcount(buf)
+    return free if (held == free + 1 and again == free) else None
+
+
+_POOL_FREE_COUNT = _pool_probe()
+
+
 def _result_buffer(nbytes, slot):
     """A host byte array for a result the caller will own.  Fresh arrays of this size (12 MB of key points per step of the
     4 x 4096^2 flow) are mmap'ed and page-faulted by every call, and now and then that stalls for 25-30 ms (seen in bench.py's
     N-view leg: one `merge` stage in five).  So the arrays are pooled per slot and handed out again once nobody outside the
-    pool refers to them any more (a result array is a view whose base is the pooled buffer: the reference count tells)."""
+    pool refers to them any more: a result array, and every slice or view a caller takes of it, is a view whose base is the
+    pooled buffer, so the buffer's reference count tells -- against the free reading calibrated by _pool_probe() on this
+    interpreter, not a constant."""
+    if _POOL_FREE_COUNT is None:
+        return np.empty(max(nbytes, 1 << 16), np.uint8)
     pool = build_match_set.__dict__.setdefault("_results", {}).setdefault(slot, [])
     for buf in pool:
-        if buf.size >= nbytes and sys.getrefcount(buf) == 3:  # the pool's list, `buf`, getrefcount's argument
+        if buf.size >= nbytes and sys.getrefcount(buf) == _POOL_FREE_COUNT:
             return buf
     buf = np.empty(max(nbytes, 1 << 16), np.uint8)
     if len(pool) >= 4:

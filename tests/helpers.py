@@ -125,6 +125,15 @@ def limit_openmp():
     return n
 
 
+def dev_env(**switches):
+    """Environment of a child process that loads the DEVELOPER build of the HIP library (ssrlcv_amd/_lib.py: the default
+    is the release build, in which every SSRLCV_* switch is compiled out) with the given switches set."""
+    env = dict(os.environ, SSRLCV_DEV_BUILD="1")
+    env.pop("SSRLCV_HIP_LIB", None)
+    env.update(switches)
+    return env
+
+
 def oracle():
     """Build (if needed) and load oracle/_build/libssrlcv_oracle.so."""
     global _ORACLE

@@ -118,6 +118,25 @@ def test_release_build_has_no_developer_switches():
         assert not re.search(r'(?<![A-Za-z_:])getenv\(', src), f
 
 
+def test_the_default_library_is_the_release_build():
+    """ssrlcv_amd/_lib.py loads libssrlcv_hip_release.so unless told otherwise, so bench.py, smoke() and the parity tests run
+    the library INTEGRATION.md tells a deployer to link; tests/helpers.py dev_env() is how a child process gets the
+    developer build (the formulation-by-formulation tests), SSRLCV_HIP_LIB any other one."""
+    import subprocess
+    import sys
+    import helpers as H
+    probe = "import sys; sys.path.insert(0, %r); from ssrlcv_amd import _lib; print(_lib.flavour(), _lib.LIB_PATH)" % ROOT
+    env = dict(os.environ)
+    env.pop("SSRLCV_HIP_LIB", None)
+    env.pop("SSRLCV_DEV_BUILD", None)
+    out = subprocess.check_output([sys.executable, "-c", probe], env=env, text=True).split()
+    assert out[0] == "release" and out[1].endswith("libssrlcv_hip_release.so")
+    out = subprocess.check_output([sys.executable, "-c", probe], env=H.dev_env(SSRLCV_GAUSS_VALU="1"), text=True).split()
+    assert out[0] == "developer" and out[1].endswith("libssrlcv_hip.so")
+    out = subprocess.check_output([sys.executable, "-c", probe], env=dict(env, SSRLCV_HIP_LIB="/tmp/other.so"), text=True).split()
+    assert out == ["/tmp/other.so", "/tmp/other.so"]
+
+
 def test_matcher_kernels_register_budget():
     """The matcher kernels are built for fixed occupancies (__launch_bounds__): the compiler's resource report must stay
     what the timings were taken with -- no scratch in either.  Brute force: four query tiles, two waves per SIMD.

@@ -405,7 +405,7 @@ def test_band_culled_pairs_at_size_equal_the_fp16_kernels(tmp_path):
     assert sum(v.numel() // 16 for v in pairs.values()) > 50000
     npz, out = str(tmp_path / "feats.npz"), str(tmp_path / "pairs.npz")
     np.savez(npz, cams=cams.view(np.uint8), **{"f%d" % i: f.cpu().numpy() for i, f in enumerate(feats)})
-    env = dict(os.environ, SSRLCV_MATCH_F16="1")
+    env = H.dev_env(SSRLCV_MATCH_F16="1")
     r = subprocess.run([sys.executable, "-c", _F16_SCENE_SCRIPT % {"root": ROOT, "npz": npz, "out": out}], env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "F16 SCENE OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
@@ -418,9 +418,48 @@ def test_fp16_mfma_matcher_is_bit_exact_too():
     """The matcher's fp16-MFMA formulation (v_mfma_f32_32x32x16_f16 with the norms carried as base-1024 digits; what
     the north star names) is selected once per process by SSRLCV_MATCH_F16=1, so it is exercised in a child process:
     brute force with duplicates / extreme rows and the orbit mode, both equal to the oracle entry for entry."""
-    env = dict(os.environ, SSRLCV_MATCH_F16="1")
+    env = H.dev_env(SSRLCV_MATCH_F16="1")
     r = subprocess.run([sys.executable, "-c", _F16_SCRIPT % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "F16 OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_match_arithmetic_is_selectable_at_run_time_in_the_release_build(capi, oracle_lib):
+    """ssrlcv_hip_set_match_arithmetic (the product's own switch, present in the release library): the fp16-MFMA formulation
+    the north star names and the default int8 one, in ONE process, brute force with duplicates / extreme rows and the
+    orbit mode, each equal to the oracle entry for entry -- and therefore to each other."""
+    from ssrlcv_amd import _lib
+    assert _lib.flavour() == "release"
+
+    def feats(n, seed):
+        r = np.random.default_rng(seed)
+        f = np.zeros(n, H.FEATURE)
+        f["parent"] = -1
+        f["values"] = r.integers(0, 256, (n, 128), dtype=np.uint8)
+        f["loc"] = r.uniform(0, 1024, (n, 2)).astype(np.float32)
+        return f
+    q, t = feats(3000, 1), feats(5000, 2)
+    t["values"][:500] = q["values"][:500]
+    t["values"][600:700] = 255
+    q["values"][10:20] = 0
+    cams = H.load_view("Pipeline2View")["cameras"]
+    proj = H.oracle_projection(oracle_lib, cams[1:2])
+    ref0 = H.oracle_match_dmatch(oracle_lib, 0, 0, q, 1, t, None, None, 0, 0, None, 0.6, 3.0e7)
+    ref1 = H.oracle_match_pairs(oracle_lib, 1, 0, q, 1, t, cams[0:1], proj, 25.0, 5.0, None, 0.6, 200.0 * 200.0)
+    assert capi.get_match_arithmetic() == capi.MATCH_ARITH_I8
+    assert capi.LIB.ssrlcv_hip_set_match_arithmetic(ctypes.c_int(7)) != 0   # unknown values are refused, the setting stays
+    try:
+        for arith in (capi.MATCH_ARITH_F16, capi.MATCH_ARITH_I8):
+            capi.set_match_arithmetic(arith)
+            assert capi.get_match_arithmetic() == arith
+            p0 = capi.make_match_params(0, 0, 1, 0.0, 0.0, 0.6, 3.0e7)
+            out = capi.to_host(capi.match(capi.to_dev(q), len(q), capi.to_dev(t), len(t), p0, capi.OUT_DMATCH), H.DMATCH, len(q))
+            assert np.array_equal(out["invalid"], ref0["invalid"]) and np.array_equal(out["distance"], ref0["distance"])
+            assert np.array_equal(out["kp1_loc"], ref0["kp1_loc"])
+            p1 = capi.make_match_params(1, 0, 1, 25.0, 5.0, 0.6, 200.0 * 200.0, cams[0:1], capi.projection_matrix(cams[1:2]))
+            out = capi.to_host(capi.match(capi.to_dev(q), len(q), capi.to_dev(t), len(t), p1, capi.OUT_UINT2_PAIR), H.UINT2_PAIR, len(q))
+            assert np.array_equal(out["a"], ref1["a"]) and np.array_equal(out["b"], ref1["b"])
+    finally:
+        capi.set_match_arithmetic(capi.MATCH_ARITH_I8)
 
 
 @pytest.mark.parametrize("depth", [2, 3, 4])

@@ -188,7 +188,8 @@ def test_full_size_pyramid_is_the_same_on_every_kernel_path(size):
     sums = []
     for variant in ({}, {"SSRLCV_GAUSS_VALU": "1", "SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_NO_BIN_FUSION": "1", "SSRLCV_DOG_SPLIT": "0",
                          "SSRLCV_DOGX_NPX": "1", "SSRLCV_SIFT_SERIAL": "1", "SSRLCV_NO_UPSAMPLE_FUSION": "1"}):
-        r = subprocess.run([sys.executable, "-c", _CHECKSUM_SCRIPT % {"root": root}, str(size)], env=dict(os.environ, **variant),
+        r = subprocess.run([sys.executable, "-c", _CHECKSUM_SCRIPT % {"root": root}, str(size)],
+                           env=H.dev_env(**variant) if variant else dict(os.environ),  # default path: the release build
                            capture_output=True, text=True, timeout=900)
         line = [l for l in r.stdout.splitlines() if l.startswith("CHECKSUMS ")]
         assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-4000:]

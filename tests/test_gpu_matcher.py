@@ -237,7 +237,7 @@ def test_band_frame_is_only_an_order(direction, strip):
     what is culled, never what is found.  A developer build lets the environment force u and the strip width; the
     oracle-parity tests of the culled modes are repeated in a child process with the frame turned away from the bands
     (37, 90, -63.5 degrees: bands steep or across the frame) and with strips of 1 to 64 pixels."""
-    env = dict(os.environ, SSRLCV_BAND_DIR=direction, SSRLCV_BAND_STRIP=strip)
+    env = H.dev_env(SSRLCV_BAND_DIR=direction, SSRLCV_BAND_STRIP=strip)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
                         "double_constrained or fundamental_constrained or conservative_on_degenerate"],
                        env=env, capture_output=True, text=True, timeout=900)

@@ -295,7 +295,7 @@ def test_every_gaussian_formulation_is_bit_exact(variant):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, **variant)
+    env = H.dev_env(**variant)
     r = subprocess.run([sys.executable, "-c", _CONV_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "CONV OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
@@ -356,7 +356,7 @@ def test_every_pyramid_schedule_is_bit_exact(variant):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, **variant)
+    env = H.dev_env(**variant)
     r = subprocess.run([sys.executable, "-c", _PYRAMID_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "PYRAMID OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
