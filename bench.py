@@ -497,13 +497,14 @@ def main():
         torch.cuda.synchronize()
 
     def step(ev=None):
+        """One pass of the hot path over this rank's images: ssrlcv_hip_sift_extract (both stages in one call, as
+        SIFT_FeatureFactory::generateFeatures makes it).  ev[i] = (before, between the stages, after): the middle event is
+        recorded by the library itself on the launching stream (ssrlcv_sift_plan_set_stage_event)."""
         for i, (p, im) in enumerate(zip(plans, imgs)):
             if ev is not None:
+                p.set_stage_event(ev[i][1])
                 ev[i][0].record()
-            p.build_dog(im)
-            if ev is not None:
-                ev[i][1].record()
-            p.describe()
+            p.extract(im)
             if ev is not None:
                 ev[i][2].record()
 
@@ -520,6 +521,8 @@ def main():
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    for p in plans:
+        p.set_stage_event(None)
     nfeat = [p.count() for p in plans]  # raises if a key-point list overflowed its capacity (truncated result)
     pyr_ms = float(np.mean([e[0].elapsed_time(e[1]) for st in events for e in st]))
     desc_ms = float(np.mean([e[1].elapsed_time(e[2]) for st in events for e in st]))

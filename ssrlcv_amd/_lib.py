@@ -67,7 +67,7 @@ EXPORTED = [
     "ssrlcv_sift_plan_create", "ssrlcv_sift_plan_destroy", "ssrlcv_sift_plan_workspace_bytes",
     "ssrlcv_sift_plan_max_features", "ssrlcv_hip_sift_build_dog", "ssrlcv_hip_sift_describe",
     "ssrlcv_hip_sift_extract", "ssrlcv_hip_sift_stage", "ssrlcv_sift_plan_level", "ssrlcv_sift_plan_keypoints",
-    "ssrlcv_sift_plan_set_stop_stage", "ssrlcv_hip_math_eval", "ssrlcv_sift_plan_overflow",
+    "ssrlcv_sift_plan_set_stop_stage", "ssrlcv_sift_plan_set_stage_event", "ssrlcv_hip_math_eval", "ssrlcv_sift_plan_overflow",
     "ssrlcv_hip_find_extrema", "ssrlcv_hip_compact_workspace_bytes", "ssrlcv_hip_compact_addresses", "ssrlcv_hip_compact_thetas",
     "ssrlcv_hip_compact_keypoints", "ssrlcv_hip_fill_extrema", "ssrlcv_hip_flag_noise", "ssrlcv_hip_refine_location",
     "ssrlcv_hip_flag_edges", "ssrlcv_hip_check_keypoints", "ssrlcv_hip_pixel_gradients", "ssrlcv_hip_compute_thetas",

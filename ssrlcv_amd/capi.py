@@ -385,6 +385,16 @@ class SiftPlan:
     def set_stop_stage(self, stage):
         LIB.ssrlcv_sift_plan_set_stop_stage(self.handle, c_int(stage))
 
+    def set_stage_event(self, event):
+        """A torch.cuda.Event (or None) that extract() records on the launching stream between the scale-space stage and the
+        key-point stage (ssrlcv_sift_plan_set_stage_event): how a caller times the stages of the fused call."""
+        handle = None
+        if event is not None:
+            event.record()           # torch creates the underlying hipEvent_t lazily, on the first record
+            handle = event.cuda_event
+        self._stage_event = event    # (kept alive as long as the plan refers to it)
+        check(LIB.ssrlcv_sift_plan_set_stage_event(self.handle, c_vp(handle) if handle is not None else None))
+
     def build_dog(self, pixels_d):
         check(LIB.ssrlcv_hip_sift_build_dog(self.handle, ptr(pixels_d), ptr(self.workspace), stream_ptr()))
 

@@ -20,6 +20,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include "compact.h"
+#include "dev_switch.h"
 #include "scan_lookback.h"
 #include "device_math.h"
 #include "sift_plan.h"
@@ -495,18 +496,20 @@ constexpr int kThetaChunk = 8;
 struct RangeTable {
   uint32_t first[20], count[20], start[20];  // range r = order * 4 + octave: list index, length, first work unit
   uint32_t total;                            // work units in all ranges
+  uint32_t pad[3];
 };
-static_assert(sizeof(RangeTable) <= 256, "lives in an octave's 256-byte bookkeeping slot");
+static_assert(sizeof(RangeTable) == 256, "tables sit at 256-byte strides in the plan's group block");
 __device__ __constant__ const int kSegOrder[5] = {3, 2, 1, 4, 0};
 // unitShift: log2 of the key points per work unit (6: one 64-lane block of k_thetas; 0: one wave of k_descriptors)
-__global__ void k_build_ranges(const OctaveState* st, RangeTable* tab, int unitShift) {
+// sel: bit o * 5 + seg = the range of blur segment `seg` of octave o is wanted (the others stay empty)
+__device__ __forceinline__ void build_ranges(const OctaveState* st, RangeTable* tab, int unitShift, uint32_t sel) {
   uint32_t pos = 0;
   for (int k = 0; k < 5; ++k) {
     const int seg = kSegOrder[k];
     for (int o = 0; o < svp::kOctaves; ++o) {
       const int r = k * 4 + o;
       uint32_t first = 0, count = 0;
-      if (st[o].hasExtrema) {
+      if (st[o].hasExtrema && ((sel >> (o * 5 + seg)) & 1u)) {
         const int lo = st[o].idx[seg], hi = seg < svp::kDog - 1 ? st[o].idx[seg + 1] : st[o].n;
         if (hi > lo) { first = (uint32_t)lo; count = (uint32_t)(hi - lo); }
       }
@@ -514,6 +517,84 @@ __global__ void k_build_ranges(const OctaveState* st, RangeTable* tab, int unitS
       tab->count[r] = count;
       tab->start[r] = pos;
       pos += (count + (1u << unitShift) - 1) >> unitShift;
+    }
+  }
+  tab->total = pos;
+}
+__global__ void k_build_ranges(const OctaveState* st, RangeTable* tab, int unitShift, uint32_t sel) { build_ranges(st, tab, unitShift, sel); }
+
+// ---- the sampling kernels in groups (round 5) ---------------------------------------------------------------------------------
+// k_thetas is a latency chain per lane (VALU at a quarter of its issue rate), k_descriptors is bound by vector-instruction
+// issue, and the second needs the first's result only per key point: the key points are cut into kSampleGroups groups that
+// are CONTIGUOUS IN THE OUTPUT ORDER (octave-major, blur segment, raster) --
+//     0: octave 0, segments 0-1     1: octave 0, segment 2     2: octave 0, segments 3-4     3: octaves 1-3
+// -- so that a group's features can be written as soon as the groups in front of it are expanded (their counts are the
+// offsets), and the orientation launches of the later groups run beside the descriptor launches of the earlier ones.
+// Octave 0's three groups are pieces of ONE order-preserving expansion (k_expand_orient over an element range, each piece
+// starting at the running total the piece before it left).  The cut points are extremaBlurIndices; the reference's blur
+// re-scan can leave stale entries in them (book_rescan), so the device checks that they are an ordered partition of the
+// list (`regular`); if not, group 0 takes the whole octave's orientations and group 2 all its descriptors -- the single
+// launch order of rounds 2-4 -- and nothing depends on where the cuts fall.
+constexpr int kOct0Groups = svp::kSampleGroups - 1;
+struct GroupCtl {                       // one per octave, in the plan's group block (zeroed before the first expansion)
+  uint32_t segStart[svp::kDog];         // offset + 1 of the first kept element of every segment (0 = not met yet)
+  uint32_t totals[svp::kSampleGroups + 1];  // totals[g] = kept elements in front of piece g (totals[0] = 0)
+  uint32_t groupSum[svp::kSampleGroups];    // kept elements of piece g (written by the block of its last tile)
+  uint32_t done[svp::kSampleGroups];        // blocks of piece g's launch that have left
+  uint32_t regular;                     // the octave's blur indices are an ordered partition of its list
+  uint32_t cut[2];                      // list indices where pieces 1 and 2 start (n, n when not regular)
+  uint32_t pad[32 - svp::kDog - 3 * svp::kSampleGroups - 4];
+};
+static_assert(sizeof(GroupCtl) == 128, "four of them + eight range tables fit the plan's 4 KB group block");
+__device__ __forceinline__ bool blur_indices_regular(const OctaveState* st) {
+  if (!st->hasExtrema) return true;
+  bool ok = st->idx[0] == 0;
+  for (int k = 1; k < svp::kDog; ++k) ok = ok && st->idx[k - 1] <= st->idx[k];
+  return ok && st->idx[svp::kDog - 1] <= st->n;
+}
+// before the orientation launches: the four groups' orientation work lists and octave 0's cut points (one thread)
+__global__ void k_build_group_ranges(const OctaveState* st, RangeTable* tabs, GroupCtl* ctl, int unitShift, bool forceIrregular) {
+  const bool reg = blur_indices_regular(st) && !forceIrregular;
+  const uint32_t n0 = st[0].hasExtrema && st[0].n > 0 ? (uint32_t)st[0].n : 0u;
+  ctl[0].regular = reg ? 1u : 0u;
+  ctl[0].cut[0] = reg && n0 ? (uint32_t)st[0].idx[2] : n0;
+  ctl[0].cut[1] = reg && n0 ? (uint32_t)st[0].idx[3] : n0;
+  const uint32_t oct0 = 0x1Fu, rest = 0xFFFFFu & ~oct0;
+  build_ranges(st, tabs + 0, unitShift, reg ? 0x03u : oct0);
+  build_ranges(st, tabs + 1, unitShift, reg ? 0x04u : 0u);
+  build_ranges(st, tabs + 2, unitShift, reg ? 0x18u : 0u);
+  build_ranges(st, tabs + 3, unitShift, rest);
+}
+// after piece g of octave 0's expansion: the descriptor work list of group g over the EXPANDED list.  Regular: the
+// segments of the piece, from the running offsets the expansion recorded; not regular: nothing for groups 0 and 1, the
+// whole octave (its final state, piece 2 has written it) for group 2.
+__global__ void k_build_desc_ranges_oct0(const OctaveState* st, RangeTable* tab, const GroupCtl* ctl, int g, uint32_t cap) {
+  if (!ctl->regular) {
+    build_ranges(st, tab, 0, g == kOct0Groups - 1 ? 0x1Fu : 0u);
+    return;
+  }
+  const int segLo = g == 0 ? 0 : g + 1, segHi = g == 0 ? 2 : (g == 1 ? 3 : svp::kDog);
+  const uint32_t end = ctl->totals[g + 1] < cap ? ctl->totals[g + 1] : cap;
+  auto start_of = [&](int seg) {  // a segment nobody has met yet is empty and lies at the end of what is expanded so far
+    if (seg >= segHi) return end;
+    const uint32_t enc = ctl->segStart[seg];
+    const uint32_t v = enc ? enc - 1u : end;
+    return v < end ? v : end;
+  };
+  uint32_t pos = 0;
+  for (int k = 0; k < 5; ++k) {
+    const int seg = kSegOrder[k];
+    for (int o = 0; o < svp::kOctaves; ++o) {
+      const int r = k * 4 + o;
+      uint32_t first = 0, count = 0;
+      if (o == 0 && seg >= segLo && seg < segHi) {
+        const uint32_t lo = start_of(seg), hi = start_of(seg + 1);
+        if (hi > lo) { first = lo; count = hi - lo; }
+      }
+      tab->first[r] = first;
+      tab->count[r] = count;
+      tab->start[r] = pos;
+      pos += count;
     }
   }
   tab->total = pos;
@@ -758,14 +839,21 @@ struct DescConst {
   int32_t segment;      // blur segment of the key point = DoG level its window is sampled from
 };
 static_assert(sizeof(DescConst) == 32, "one s_load_dwordx8");
-// one launch for all octaves: blockIdx.y = octave
-__global__ __launch_bounds__(256) void k_desc_consts(const OctaveState* states, OctaveSet set, float lambda) {
-  const OctaveState* st = states + blockIdx.y;
-  const ssrlcv_sskeypoint* kps = set.kps[blockIdx.y];
-  const float pixelWidth = set.pixelWidth[blockIdx.y];
-  DescConst* __restrict__ out = (DescConst*)const_cast<void*>(set.consts[blockIdx.y]);
-  const int n = st->hasExtrema ? st->n : 0;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+// One launch over a descriptor work list (every octave, or one sampling group): unit u of the table = one key point.
+// segment: the blur segment the octave's state gives the key point (segment_of) -- or, for a group of octave 0 whose
+// expansion is still running in pieces (regularCtl set and ->regular: the state is rewritten by the last piece), the segment
+// of the unit's range, which is the same number there (the blur indices are an ordered partition, see GroupCtl).
+__global__ __launch_bounds__(256) void k_desc_consts(const RangeTable* tab, OctaveSet set, float lambda, const OctaveState* states,
+                                                     const GroupCtl* regularCtl) {
+  const uint32_t total = tab->total;
+  const bool fromTable = regularCtl != nullptr && regularCtl->regular != 0u;
+  for (uint32_t u = blockIdx.x * 256 + threadIdx.x; u < total; u += gridDim.x * 256) {
+    const int range = range_of(tab, u);
+    const int octave = range & 3;
+    const int i = (int)(tab->first[range] + (u - tab->start[range]));
+    const ssrlcv_sskeypoint* kps = set.kps[octave];
+    const float pixelWidth = set.pixelWidth[octave];
+    DescConst* __restrict__ out = (DescConst*)const_cast<void*>(set.consts[octave]);
     DescConst d;
     const float theta = kps[i].theta;
     d.c = sv_cosf(-theta);
@@ -779,7 +867,7 @@ __global__ __launch_bounds__(256) void k_desc_consts(const OctaveState* states, 
     d.invBin = 1.0f / (d.windowWidth / 2.0f);
     const unsigned wi = (unsigned)(int)d.windowWidth;
     d.magic = wi > 1u ? 0xFFFFFFFFu / wi + 1u : 0u;  // ceil(2^32 / w) (2^32 / w when w is a power of two); w = 1 is special-cased
-    d.segment = segment_of(st, i);
+    d.segment = fromTable ? kSegOrder[range >> 2] : segment_of(states + octave, i);
     out[i] = d;
   }
 }
@@ -1076,6 +1164,23 @@ void launch_polar(const ssrlcv_sift_plan* plan, char* ws, hipStream_t st) {
   hipLaunchKernelGGL(k_polar, dim3(pos), dim3(256), 0, st, jobs);
 }
 
+}  // namespace
+namespace svp {
+void launch_polar_octave(const ssrlcv_sift_plan* plan, char* ws, int octave, hipStream_t st) {
+  PolarJobs jobs;
+  const svp::OctavePlan& oc = plan->oct[octave];
+  const uint32_t tilesX = (oc.w + 255) / 256, tiles = tilesX * ((oc.h + kPolRows - 1) / kPolRows);
+  for (int o = 0; o < svp::kOctaves; ++o) {  // every block resolves to `octave`: start[k] = 0 up to it, past the grid behind it
+    jobs.L[o] = make_levels(plan, ws, octave);
+    jobs.out[o] = (float2*)(ws + oc.off_polar);
+    jobs.tilesX[o] = tilesX;
+    jobs.start[o] = o <= octave ? 0u : tiles;
+  }
+  jobs.start[svp::kOctaves] = tiles;
+  hipLaunchKernelGGL(k_polar, dim3(tiles), dim3(256), 0, st, jobs);
+}
+}  // namespace svp
+namespace {
 // discardExtrema: stable per-segment compaction from `src` into `dst`
 hipError_t run_discard(OctaveState* st, const ssrlcv_sskeypoint* src, ssrlcv_sskeypoint* dst, uint32_t cap,
                        uint32_t* words, hipStream_t stream) {
@@ -1274,45 +1379,52 @@ OctaveSet make_set(const ssrlcv_sift_plan* plan, char* ws, uint32_t* unitBlocks)
 // octave between k_thetas and k_descriptors); here a tile takes its prefix by decoupled look-back (scan_lookback.h).
 // The new extremaBlurIndices need no counting: idx'[s] = the number of kept elements in front of segment s = the running
 // offset of the thread that meets element idx[s] * maxO.  The bookkeeping runs in the last block to leave.
-struct ExpandCtl {
-  uint32_t* segStart;  // [kDog] offset + 1 of the first element of every segment (0 = not met: the segment starts at the end)
-  uint32_t* total;     // kept elements
-  uint32_t* done;      // blocks that have left
-};
+// Round 5: the launch covers PIECE g of the list -- the elements of the key points [lo, hi) with lo / hi = the octave's
+// cut points (GroupCtl::cut; piece 0 starts at 0, the last piece ends at n) -- and continues the running offset where
+// piece g - 1 stopped (ctl->totals[g], complete when this launch starts: the pieces are ordered by events).  One piece
+// covering everything (pieces = 1) is the whole-octave expansion of round 4.  Only the LAST piece rewrites the octave's
+// state, after every block of it has left, so every piece reads the same pre-expansion n and blur indices.
 __global__ __launch_bounds__(svs::kThreads) void k_expand_orient(OctaveState* st, const ssrlcv_sskeypoint* __restrict__ src,
                                                                  ssrlcv_sskeypoint* __restrict__ dst, const float* __restrict__ thetas,
                                                                  const uint32_t* __restrict__ thetaCnt, uint32_t maxO, uint32_t cap,
-                                                                 svs::TileScan<1> ts, ExpandCtl ctl) {
+                                                                 svs::TileScan<1> ts, GroupCtl* ctl, int g, int pieces) {
   constexpr int ITEMS = 4;
   constexpr uint32_t kTile = svs::kThreads * ITEMS;
   // read BEFORE anything of this launch can rewrite the state (the bookkeeping below waits for every block)
   const uint32_t n = st->hasExtrema && st->n > 0 ? (uint32_t)st->n : 0u;
-  const uint32_t elems = n * maxO;
-  const uint32_t tiles = (elems + kTile - 1) / kTile;  // <= ts.numTiles (sized for the capacity)
+  uint32_t lo = 0, hi = n;
+  if (pieces > 1) {
+    if (g > 0) lo = ctl->cut[g - 1] < n ? ctl->cut[g - 1] : n;
+    if (g + 1 < pieces) hi = ctl->cut[g] < n ? ctl->cut[g] : n;
+    if (hi < lo) hi = lo;
+  }
+  const uint32_t e0 = lo * maxO, e1 = hi * maxO;
+  const uint32_t tiles = (e1 - e0 + kTile - 1) / kTile;  // <= ts.numTiles (sized for the capacity)
+  const uint32_t before = ctl->totals[g];
   uint32_t segFirst[svp::kDog];
 #pragma unroll
   for (int k = 0; k < svp::kDog; ++k) segFirst[k] = (uint32_t)st->idx[k] * maxO;
   for (uint32_t tile = svs::next_tile(ts.counter); tile < tiles; tile = svs::next_tile(ts.counter)) {
-    const uint32_t base = tile * kTile + threadIdx.x * ITEMS;
+    const uint32_t base = e0 + tile * kTile + threadIdx.x * ITEMS;
     bool keep[ITEMS];
     uint32_t mine[1] = {0};
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
       const uint32_t e = base + j, i = e / maxO;
-      keep[j] = e < elems && (e - i * maxO) < thetaCnt[i];
+      keep[j] = e < e1 && (e - i * maxO) < thetaCnt[i];
       mine[0] += keep[j] ? 1u : 0u;
     }
     uint32_t excl[1], total[1], prefix[1];
     svs::block_exclusive<1>(mine, excl, total);
     svs::tile_prefix<1>(ts, tile, total, prefix);
-    uint32_t at = prefix[0] + excl[0];
+    uint32_t at = before + prefix[0] + excl[0];
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
       const uint32_t e = base + j;
-      if (e < elems) {
+      if (e < e1) {
 #pragma unroll
         for (int k = 0; k < svp::kDog; ++k)
-          if (segFirst[k] == e) ctl.segStart[k] = at + 1u;
+          if (segFirst[k] == e) ctl->segStart[k] = at + 1u;
       }
       if (keep[j]) {
         if (at < cap) {
@@ -1324,22 +1436,23 @@ __global__ __launch_bounds__(svs::kThreads) void k_expand_orient(OctaveState* st
         ++at;
       }
     }
-    if (tile == tiles - 1 && threadIdx.x == 0) *ctl.total = prefix[0] + total[0];
+    if (tile == tiles - 1 && threadIdx.x == 0) ctl->groupSum[g] = prefix[0] + total[0];
   }
-  // bookkeeping (book_orient's): after EVERY block has left its loop -- a block that starts late must still read the old n
+  // bookkeeping: after EVERY block has left its loop -- a block that starts late must still read the old n
   __shared__ bool s_last;
   __syncthreads();
   if (threadIdx.x == 0) {
     __threadfence();
-    s_last = atomicAdd(ctl.done, 1u) == gridDim.x - 1;
+    s_last = atomicAdd(&ctl->done[g], 1u) == gridDim.x - 1;
   }
   __syncthreads();
   if (s_last && threadIdx.x == 0) {
     __threadfence();
-    if (st->hasExtrema) {
-      const uint32_t total = __hip_atomic_load(ctl.total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t total = before + __hip_atomic_load(&ctl->groupSum[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ctl->totals[g + 1] = total;  // where the next piece continues (book_orient's running sum)
+    if (g + 1 == pieces && st->hasExtrema) {
       for (int b = 0; b < svp::kDog; ++b) {
-        const uint32_t enc = __hip_atomic_load(&ctl.segStart[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t enc = __hip_atomic_load(&ctl->segStart[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t start = enc ? enc - 1u : total;  // a segment nobody met lies behind the last element
         st->idx[b] = (int)(start < cap ? start : cap);
       }
@@ -1351,6 +1464,55 @@ __global__ __launch_bounds__(svs::kThreads) void k_expand_orient(OctaveState* st
   }
 }
 
+// the plan's 4 KB group block: four orientation work lists, four descriptor work lists, one GroupCtl per octave
+struct GroupBlock {
+  RangeTable thetaTab[svp::kSampleGroups];
+  RangeTable descTab[svp::kSampleGroups];
+  GroupCtl ctl[svp::kOctaves];
+};
+static_assert(sizeof(RangeTable) <= 256 && 8 * 256 + svp::kOctaves * sizeof(GroupCtl) <= 4096, "fits the plan's group block");
+inline RangeTable* theta_tab(const ssrlcv_sift_plan* plan, char* ws, int g) { return (RangeTable*)(ws + plan->off_groups + 256 * g); }
+inline RangeTable* desc_tab(const ssrlcv_sift_plan* plan, char* ws, int g) { return (RangeTable*)(ws + plan->off_groups + 256 * (svp::kSampleGroups + g)); }
+inline GroupCtl* group_ctl(const ssrlcv_sift_plan* plan, char* ws, int o) { return (GroupCtl*)(ws + plan->off_groups + 2048) + o; }
+
+template <typename... Args>
+void launch_thetas(uint32_t maxO, unsigned blocks, hipStream_t st, Args... args) {
+  switch (maxO) {
+    case 1: hipLaunchKernelGGL(k_thetas<1>, dim3(blocks), dim3(64), 0, st, args...); break;
+    case 2: hipLaunchKernelGGL(k_thetas<2>, dim3(blocks), dim3(64), 0, st, args...); break;
+    case 3: hipLaunchKernelGGL(k_thetas<3>, dim3(blocks), dim3(64), 0, st, args...); break;
+    default: hipLaunchKernelGGL(k_thetas<4>, dim3(blocks), dim3(64), 0, st, args...); break;
+  }
+}
+
+// piece g of `pieces` of octave o's expansion (thrust::remove of the -FLT_MAX / -1 slots + expandKeyPoints, :594-611) on
+// stream es; the tile descriptors of piece g live in its own slice of the octave's partition scratch
+int launch_expand(const ssrlcv_sift_plan* plan, char* ws, int o, int g, int pieces, hipStream_t es) {
+  const svp::OctavePlan& oc = plan->oct[o];
+  const uint32_t maxO = plan->params.maxOrientations, cap = oc.cap;
+  OctaveState* states = (OctaveState*)(ws + plan->off_state);
+  const ssrlcv_sskeypoint* src = (const ssrlcv_sskeypoint*)(ws + (plan->listInB[o] ? oc.off_kpB : oc.off_kpA));
+  ssrlcv_sskeypoint* dst = (ssrlcv_sskeypoint*)(ws + (plan->listInB[o] ? oc.off_kpA : oc.off_kpB));
+  const uint32_t capTiles = (cap * maxO + svs::kThreads * 4 - 1) / (svs::kThreads * 4);
+  const size_t scanBytes = svs::workspace_bytes<1>(capTiles);
+  char* part = ws + oc.off_part + (size_t)g * scanBytes;
+  SSRLCV_HIP_TRY(hipMemsetAsync(part, 0, scanBytes, es));
+  // a grid for the usual list lengths (a tenth of the capacity), persistent over the tiles
+  unsigned blocks = capTiles / 8 + 1;
+  blocks = blocks > 1024u ? 1024u : blocks;
+  hipLaunchKernelGGL(k_expand_orient, dim3(blocks), dim3(svs::kThreads), 0, es, states + o, src, dst, (const float*)(ws + oc.off_theta),
+                     (const uint32_t*)(ws + oc.off_thetaCnt), maxO, cap, svs::make_tile_scan<1>(part, capTiles), group_ctl(plan, ws, o), g, pieces);
+  return SSRLCV_OK;
+}
+// the partition scratch of an octave holds `pieces` tile-descriptor slices
+bool expand_scratch_fits(const ssrlcv_sift_plan* plan, int o, int pieces) {
+  const svp::OctavePlan& oc = plan->oct[o];
+  const uint32_t capTiles = (oc.cap * plan->params.maxOrientations + svs::kThreads * 4 - 1) / (svs::kThreads * 4);
+  const size_t P = (size_t)oc.w * oc.h;
+  const size_t words = (size_t)3 * 4 * ((P + 8191) / 8192) + 16 + (size_t)svp::kDog * 4 * (((size_t)oc.cap * svp::kMaxOrient + 2047) / 2048) + 16;
+  return (size_t)pieces * svs::workspace_bytes<1>(capTiles) <= words * 4;
+}
+
 // computeKeyPointOrientations (src/FeatureFactory.cu:540-632) for all octaves: gradient tables (unless the caller built
 // them on a side stream already), one orientation launch, the expansion of every key point into its orientations
 int stage_orientations(const ssrlcv_sift_plan* plan, char* ws, hipStream_t caller, svp::PlanAsync* as, bool polarDone) {
@@ -1358,22 +1520,17 @@ int stage_orientations(const ssrlcv_sift_plan* plan, char* ws, hipStream_t calle
   const uint32_t maxO = plan->params.maxOrientations;
   uint32_t unitBlocks = 0;
   OctaveSet set = make_set(plan, ws, &unitBlocks);
-  // the two range tables live in the bookkeeping slots of octaves 1 and 2 (octave 0's holds the feature offsets)
-  RangeTable* thetaRanges = (RangeTable*)(ws + plan->oct[1].off_featBase);
+  RangeTable* thetaRanges = theta_tab(plan, ws, 0);
   if (!polarDone) launch_polar(plan, ws, caller);
   // (Round 3 built this kernel with two and with four lanes per key point -- the 36 bins split between the lanes of a
   // group, each bin keeping its sequential chain, the samples' weights shared by DPP: bit-identical, and the same 0.58 ms
   // per 4096^2 image with 1, 2 or 4 lanes.  The kernel is bound by the gather of the polar tables: it reads all 2.2 GB of
   // them once, at the ~4 TB/s that 150-300-byte row segments reach.)
-  hipLaunchKernelGGL(k_build_ranges, dim3(1), dim3(1), 0, caller, states, thetaRanges, 6);
+  hipLaunchKernelGGL(k_build_ranges, dim3(1), dim3(1), 0, caller, states, thetaRanges, 6, 0xFFFFFu);
+  SSRLCV_HIP_TRY(hipMemsetAsync(group_ctl(plan, ws, 0), 0, sizeof(GroupCtl) * svp::kOctaves, caller));
   const float lambdaO = plan->params.orientationContribWidth, othr = plan->params.orientationThreshold;
-  switch (maxO) {
-    case 1: hipLaunchKernelGGL(k_thetas<1>, dim3(unitBlocks), dim3(64), 0, caller, states, thetaRanges, set, lambdaO, othr); break;
-    case 2: hipLaunchKernelGGL(k_thetas<2>, dim3(unitBlocks), dim3(64), 0, caller, states, thetaRanges, set, lambdaO, othr); break;
-    case 3: hipLaunchKernelGGL(k_thetas<3>, dim3(unitBlocks), dim3(64), 0, caller, states, thetaRanges, set, lambdaO, othr); break;
-    default: hipLaunchKernelGGL(k_thetas<4>, dim3(unitBlocks), dim3(64), 0, caller, states, thetaRanges, set, lambdaO, othr); break;
-  }
-  // The four expansions are independent three-kernel chains of ~30 us each (launch-bound on the short lists): octave 1's
+  launch_thetas(maxO, unitBlocks, caller, (const OctaveState*)states, (const RangeTable*)thetaRanges, set, lambdaO, othr);
+  // The four expansions are independent chains of ~30 us each (launch-bound on the short lists): octave 1's
   // runs on one side stream, those of octaves 2 and 3 on the other, beside octave 0's on the caller's stream.
   if (as) {
     SSRLCV_HIP_TRY(hipEventRecord(as->expandFork, caller));
@@ -1381,32 +1538,9 @@ int stage_orientations(const ssrlcv_sift_plan* plan, char* ws, hipStream_t calle
     SSRLCV_HIP_TRY(hipStreamWaitEvent(as->table, as->expandFork, 0));
   }
   for (int o = 0; o < svp::kOctaves; ++o) {
-    // thrust::remove of the -FLT_MAX / -1 slots + expandKeyPoints (:594-611): element space n x maxOrientations
     const hipStream_t es = !as || o == 0 ? caller : (o == 1 ? as->chain : as->table);
-    const svp::OctavePlan& oc = plan->oct[o];
-    const uint32_t cap = oc.cap;
-    const OctaveState* cst = states + o;
-    const ssrlcv_sskeypoint* src = (const ssrlcv_sskeypoint*)(ws + (plan->listInB[o] ? oc.off_kpB : oc.off_kpA));
-    ssrlcv_sskeypoint* dst = (ssrlcv_sskeypoint*)(ws + (plan->listInB[o] ? oc.off_kpA : oc.off_kpB));
-    const float* thetas = set.thetas[o];
-    const uint32_t* thetaCnt = set.thetaCnt[o];
-    (void)cst;
-    {
-      // scan descriptors + control words live in the octave's partition scratch
-      const uint32_t capTiles = (cap * maxO + svs::kThreads * 4 - 1) / (svs::kThreads * 4);
-      char* part = ws + oc.off_part;
-      const size_t scanBytes = svs::workspace_bytes<1>(capTiles);
-      SSRLCV_HIP_TRY(hipMemsetAsync(part, 0, scanBytes + 64, es));
-      ExpandCtl ctl;
-      ctl.segStart = (uint32_t*)(part + scanBytes);
-      ctl.total = ctl.segStart + svp::kDog;
-      ctl.done = ctl.total + 1;
-      // a grid for the usual list lengths (a tenth of the capacity), persistent over the tiles
-      unsigned blocks = capTiles / 8 + 1;
-      blocks = blocks > 1024u ? 1024u : blocks;
-      hipLaunchKernelGGL(k_expand_orient, dim3(blocks), dim3(svs::kThreads), 0, es, states + o, src, dst, thetas, thetaCnt, maxO, cap,
-                         svs::make_tile_scan<1>(part, capTiles), ctl);
-    }
+    int rc = launch_expand(plan, ws, o, 0, 1, es);
+    if (rc) return rc;
     plan->listInB[o] ^= 1;
   }
   if (as) {
@@ -1423,24 +1557,101 @@ void book_features(const ssrlcv_sift_plan* plan, char* ws, uint32_t* numFeatures
                      (uint32_t*)(ws + plan->oct[0].off_featBase), numFeatures, plan->maxFeatures);
 }
 
+unsigned desc_blocks(const ssrlcv_sift_plan* plan, int oFirst, int oLast, unsigned* maxBlocks) {
+  unsigned blocks = 0, mx = 1;
+  for (int o = oFirst; o <= oLast; ++o) {
+    blocks += list_blocks(plan->oct[o].cap);
+    mx = list_blocks(plan->oct[o].cap) > mx ? list_blocks(plan->oct[o].cap) : mx;
+  }
+  if (maxBlocks) *maxBlocks = mx;
+  return blocks;
+}
+
 // fillDescriptors (src/SIFT_FeatureFactory.cu:131-166,475-549), all octaves in one launch (book_features first)
 int stage_descriptors(const ssrlcv_sift_plan* plan, char* ws, ssrlcv_sift_feature* features, hipStream_t caller) {
   OctaveState* states = (OctaveState*)(ws + plan->off_state);
   OctaveSet set = make_set(plan, ws, nullptr);
-  RangeTable* descRanges = (RangeTable*)(ws + plan->oct[2].off_featBase);
+  RangeTable* descRanges = desc_tab(plan, ws, 0);
   uint32_t* featBase = (uint32_t*)(ws + plan->oct[0].off_featBase);
-  uint32_t descBlocks = 0, maxBlocks = 1;
-  for (int o = 0; o < svp::kOctaves; ++o) {
-    const svp::OctavePlan& oc = plan->oct[o];
-    descBlocks += list_blocks(oc.cap);
-    maxBlocks = list_blocks(oc.cap) > maxBlocks ? list_blocks(oc.cap) : maxBlocks;
-  }
-  hipLaunchKernelGGL(k_desc_consts, dim3(maxBlocks, svp::kOctaves), dim3(256), 0, caller, states, set,
-                     plan->params.descriptorContribWidth);
+  unsigned maxBlocks = 1;
+  const unsigned descBlocks = desc_blocks(plan, 0, svp::kOctaves - 1, &maxBlocks);
   // one launch over every octave's key points, largest windows first (see RangeTable)
-  hipLaunchKernelGGL(k_build_ranges, dim3(1), dim3(1), 0, caller, states, descRanges, 0);
-  hipLaunchKernelGGL(k_descriptors, dim3(descBlocks * kWaveKernelOversubscription), dim3(256), 0, caller, descRanges, set,
-                     featBase, features, plan->maxFeatures);
+  hipLaunchKernelGGL(k_build_ranges, dim3(1), dim3(1), 0, caller, states, descRanges, 0, 0xFFFFFu);
+  hipLaunchKernelGGL(k_desc_consts, dim3(maxBlocks * svp::kOctaves), dim3(256), 0, caller, (const RangeTable*)descRanges, set,
+                     plan->params.descriptorContribWidth, (const OctaveState*)states, (const GroupCtl*)nullptr);
+  hipLaunchKernelGGL(k_descriptors, dim3(descBlocks * kWaveKernelOversubscription), dim3(256), 0, caller, (const RangeTable*)descRanges, set,
+                     (const uint32_t*)featBase, features, plan->maxFeatures);
+  return SSRLCV_OK;
+}
+
+// computeKeyPointOrientations + fillDescriptors pipelined over the sampling groups (see k_build_group_ranges): the
+// orientation launches of all groups start together (group 0 on the caller's stream, the others on the side streams); a
+// group's expansion, constants and work list follow on its stream, and the caller's stream runs the four descriptor
+// launches in output order, each behind its group's `ready` event.  Results are those of stage_orientations +
+// stage_descriptors: the same kernels over the same key points, the expansion in pieces that continue each other.
+int stage_sampling_pipelined(const ssrlcv_sift_plan* plan, char* ws, ssrlcv_sift_feature* features, uint32_t* numFeatures,
+                             hipStream_t caller, svp::PlanAsync* as) {
+  OctaveState* states = (OctaveState*)(ws + plan->off_state);
+  const uint32_t maxO = plan->params.maxOrientations;
+  const float lambdaO = plan->params.orientationContribWidth, othr = plan->params.orientationThreshold;
+  const float lambdaD = plan->params.descriptorContribWidth;
+  uint32_t* featBase = (uint32_t*)(ws + plan->oct[0].off_featBase);
+  OctaveSet setT = make_set(plan, ws, nullptr);  // the lists as the chains left them: what k_thetas reads
+  for (int o = 0; o < svp::kOctaves; ++o) plan->listInB[o] ^= 1;
+  OctaveSet setD = make_set(plan, ws, nullptr);  // the expanded lists
+  for (int o = 0; o < svp::kOctaves; ++o) plan->listInB[o] ^= 1;  // (launch_expand reads the un-flipped state)
+  const hipStream_t gs[svp::kSampleGroups] = {caller, as->chain, as->chain2, as->table};
+  unsigned thetaBlocks[svp::kSampleGroups], descBlocks[svp::kSampleGroups], constBlocks[svp::kSampleGroups];
+  for (int g = 0; g < svp::kSampleGroups; ++g) {
+    const int oFirst = g < kOct0Groups ? 0 : 1, oLast = g < kOct0Groups ? 0 : svp::kOctaves - 1;
+    thetaBlocks[g] = 20;
+    for (int o = oFirst; o <= oLast; ++o) thetaBlocks[g] += (plan->oct[o].cap + 63) / 64;
+    unsigned mx = 1;
+    descBlocks[g] = desc_blocks(plan, oFirst, oLast, &mx) * kWaveKernelOversubscription;
+    constBlocks[g] = mx * (unsigned)(oLast - oFirst + 1);
+  }
+  SSRLCV_HIP_TRY(hipMemsetAsync(group_ctl(plan, ws, 0), 0, sizeof(GroupCtl) * svp::kOctaves, caller));
+  SSRLCV_HIP_TRY(hipMemsetAsync(featBase, 0, 4 * svp::kOctaves, caller));  // octave 0's features start at 0, known now
+  // (developer build: SSRLCV_SAMPLING_IRREGULAR=1 takes the fallback for blur indices that are not an ordered partition)
+  static const bool forceIrregular = svdev::env("SSRLCV_SAMPLING_IRREGULAR") != nullptr;
+  hipLaunchKernelGGL(k_build_group_ranges, dim3(1), dim3(1), 0, caller, (const OctaveState*)states, theta_tab(plan, ws, 0), group_ctl(plan, ws, 0), 6,
+                     forceIrregular);
+  SSRLCV_HIP_TRY(hipEventRecord(as->groupFork, caller));
+  for (int g = 1; g < svp::kSampleGroups; ++g) SSRLCV_HIP_TRY(hipStreamWaitEvent(gs[g], as->groupFork, 0));
+  for (int g = 0; g < svp::kSampleGroups; ++g)
+    launch_thetas(maxO, thetaBlocks[g], gs[g], (const OctaveState*)states, (const RangeTable*)theta_tab(plan, ws, g), setT, lambdaO, othr);
+  // octave 0: three pieces of one expansion, piece g behind piece g - 1
+  for (int g = 0; g < kOct0Groups; ++g) {
+    if (g > 0) SSRLCV_HIP_TRY(hipStreamWaitEvent(gs[g], as->groupExpanded[g - 1], 0));
+    int rc = launch_expand(plan, ws, 0, g, kOct0Groups, gs[g]);
+    if (rc) return rc;
+    SSRLCV_HIP_TRY(hipEventRecord(as->groupExpanded[g], gs[g]));
+    hipLaunchKernelGGL(k_build_desc_ranges_oct0, dim3(1), dim3(1), 0, gs[g], (const OctaveState*)states, desc_tab(plan, ws, g),
+                       (const GroupCtl*)group_ctl(plan, ws, 0), g, plan->oct[0].cap);
+    hipLaunchKernelGGL(k_desc_consts, dim3(constBlocks[g]), dim3(256), 0, gs[g], (const RangeTable*)desc_tab(plan, ws, g), setD, lambdaD,
+                       (const OctaveState*)states, (const GroupCtl*)group_ctl(plan, ws, 0));
+    if (g > 0) SSRLCV_HIP_TRY(hipEventRecord(as->groupReady[g], gs[g]));
+  }
+  // octaves 1-3: whole-octave expansions, then the feature offsets (octave 0's final count: piece 2), constants, work list
+  {
+    const int g = svp::kSampleGroups - 1;
+    for (int o = 1; o < svp::kOctaves; ++o) {
+      int rc = launch_expand(plan, ws, o, 0, 1, gs[g]);
+      if (rc) return rc;
+    }
+    SSRLCV_HIP_TRY(hipStreamWaitEvent(gs[g], as->groupExpanded[kOct0Groups - 1], 0));
+    book_features(plan, ws, numFeatures, gs[g]);
+    hipLaunchKernelGGL(k_build_ranges, dim3(1), dim3(1), 0, gs[g], (const OctaveState*)states, desc_tab(plan, ws, g), 0, 0xFFFFFu & ~0x1Fu);
+    hipLaunchKernelGGL(k_desc_consts, dim3(constBlocks[g]), dim3(256), 0, gs[g], (const RangeTable*)desc_tab(plan, ws, g), setD, lambdaD,
+                       (const OctaveState*)states, (const GroupCtl*)nullptr);
+    SSRLCV_HIP_TRY(hipEventRecord(as->groupReady[g], gs[g]));
+  }
+  for (int o = 0; o < svp::kOctaves; ++o) plan->listInB[o] ^= 1;
+  for (int g = 0; g < svp::kSampleGroups; ++g) {
+    if (g > 0) SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->groupReady[g], 0));
+    hipLaunchKernelGGL(k_descriptors, dim3(descBlocks[g]), dim3(256), 0, caller, (const RangeTable*)desc_tab(plan, ws, g), setD,
+                       (const uint32_t*)featBase, features, plan->maxFeatures);
+  }
   return SSRLCV_OK;
 }
 
@@ -1464,7 +1675,7 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
     SSRLCV_HIP_TRY(hipStreamWaitEvent(as->chain, as->fork, 0));
     SSRLCV_HIP_TRY(hipStreamWaitEvent(as->chain2, as->fork, 0));
     SSRLCV_HIP_TRY(hipStreamWaitEvent(as->table, as->fork, 0));
-    if (stop >= 6) launch_polar(plan, ws, as->table);
+    if (stop >= 6 && !plan->polarInFlight) launch_polar(plan, ws, as->table);
   }
   for (int o = 0; o < svp::kOctaves; ++o) {
     // octave 1's chain on one side stream, those of octaves 2 and 3 one after the other on a second (round 3: the three
@@ -1488,6 +1699,22 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
   if (as) {  // the polar stream joins too (its tables are read by the sampling kernels below)
     SSRLCV_HIP_TRY(hipEventRecord(as->join[svp::kOctaves], as->table));
     SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->join[svp::kOctaves], 0));
+    if (plan->polarInFlight) {  // queued by build_dog of the same fused extract (one launch per octave on `polar`)
+      for (int o = 0; o < svp::kOctaves; ++o) SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->polarDone[o], 0));
+      plan->polarInFlight = 0;
+    }
+  }
+  // Developer build, SSRLCV_SAMPLING_PIPELINED=1: the pipelined form (orientation launches of the later sampling groups
+  // beside the descriptor launches of the earlier ones).  Exact (tests/test_gpu_sift.py), measured in round 5 and NOT the
+  // default: the step took 10.29 ms with it against 10.19 without (profiles/r05_schedule_ab.txt) -- the resident one-wave
+  // orientation blocks hold 9 KB of LDS each, 13 per CU, and the descriptor blocks beside them run at a quarter of their
+  // occupancy; both kernels also draw on the same gather bandwidth of the polar tables.
+  static const bool pipelinedSampling = svdev::env("SSRLCV_SAMPLING_PIPELINED") != nullptr;
+  if (stop >= 7 && as && pipelinedSampling && expand_scratch_fits(plan, 0, kOct0Groups)) {
+    int rc = stage_sampling_pipelined(plan, ws, features, numFeatures, caller, as);
+    if (rc) return rc;
+    SSRLCV_LAUNCH_CHECK();
+    return SSRLCV_OK;
   }
   if (stop >= 6) {
     int rc = stage_orientations(plan, ws, caller, as, as != nullptr);
@@ -1929,8 +2156,12 @@ int ssrlcv_hip_fill_descriptors(uint32_t numFeatures, uint32_t keyPointIndex, ui
 
 int ssrlcv_hip_sift_extract(const ssrlcv_sift_plan* plan, const uint8_t* pixels, void* workspace,
                             ssrlcv_sift_feature* features, uint32_t* numFeatures, ssrlcv_stream_t stream) {
+  if (!plan) return SSRLCV_ERR_INVALID_ARG;
+  plan->fusedCall = 1;  // build_dog may leave the polar tables in flight: describe joins them below
   int rc = ssrlcv_hip_sift_build_dog(plan, pixels, workspace, stream);
+  plan->fusedCall = 0;
   if (rc) return rc;
+  if (plan->stageEvent && hipEventRecord(plan->stageEvent, (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
   return ssrlcv_hip_sift_describe(plan, workspace, features, numFeatures, stream);
 }
 

@@ -1719,25 +1719,27 @@ PlanAsync* plan_async(const ssrlcv_sift_plan* plan) {
       auto mk = [&](hipEvent_t& e) { ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
       if (ok) {
         // per-device side streams, created once and kept for the life of the process
-        struct Side { hipStream_t chain, table, chain2; };
+        struct Side { hipStream_t chain, table, chain2, polar; };
         static std::map<int, Side> pool;
         int dev = 0;
         ok = hipGetDevice(&dev) == hipSuccess;
         auto it = pool.find(dev);
         if (ok && it == pool.end()) {
-          Side pr{nullptr, nullptr, nullptr};
+          Side pr{nullptr, nullptr, nullptr, nullptr};
           int least = 0, greatest = 0;
           (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
           const int tablePrio = svdev::env("SSRLCV_SIDE_LOW_PRIORITY") ? least : 0;
           ok = hipStreamCreateWithFlags(&pr.chain, hipStreamNonBlocking) == hipSuccess &&
                hipStreamCreateWithPriority(&pr.table, hipStreamNonBlocking, tablePrio) == hipSuccess &&
-               hipStreamCreateWithFlags(&pr.chain2, hipStreamNonBlocking) == hipSuccess;
+               hipStreamCreateWithFlags(&pr.chain2, hipStreamNonBlocking) == hipSuccess &&
+               hipStreamCreateWithFlags(&pr.polar, hipStreamNonBlocking) == hipSuccess;
           if (ok) it = pool.emplace(dev, pr).first;
         }
         if (ok) {
           a->chain = it->second.chain;
           a->table = it->second.table;
           a->chain2 = it->second.chain2;
+          a->polar = it->second.polar;
         }
         mk(a->fork);
         for (hipEvent_t& e : a->join) mk(e);
@@ -1745,6 +1747,9 @@ PlanAsync* plan_async(const ssrlcv_sift_plan* plan) {
         for (hipEvent_t& e : a->dogDone) mk(e);
         for (hipEvent_t& e : a->polarDone) mk(e);
         for (hipEvent_t& e : a->binDone) mk(e);
+        mk(a->groupFork);
+        for (hipEvent_t& e : a->groupExpanded) mk(e);
+        for (hipEvent_t& e : a->groupReady) mk(e);
         mk(a->expandFork);
         for (hipEvent_t& e : a->expandJoin) mk(e);
         for (auto& lv : a->levelDone)
@@ -1929,6 +1934,9 @@ int ssrlcv_sift_plan_create(uint32_t w, uint32_t h, const ssrlcv_sift_params* pa
   p->padY = padY;
   p->params = *params;
   p->stopStage = 7;
+  p->fusedCall = 0;
+  p->polarInFlight = 0;
+  p->stageEvent = nullptr;
   p->async = nullptr;
   p->asyncState = 0;
   // sigma ladder: SIFT_FeatureFactory.cu:63-64 + FeatureFactory.cu:383-399
@@ -1987,6 +1995,7 @@ int ssrlcv_sift_plan_create(uint32_t w, uint32_t h, const ssrlcv_sift_params* pa
   }
   p->off_extremaCounts = take(256);
   p->off_dogPartial = take(sizeof(float) * 2 * svp::kDog * svp::kDogMaxWaves * svp::kOctaves);  // one region per octave: their DoG kernels may run side by side
+  p->off_groups = take(4096);
   p->total = off;
   p->maxFeatures = maxFeat;
   *out = p;
@@ -2004,6 +2013,9 @@ void ssrlcv_sift_plan_destroy(ssrlcv_sift_plan* plan) {
     for (hipEvent_t e : a->polarDone) (void)hipEventDestroy(e);
     for (hipEvent_t e : a->binDone) (void)hipEventDestroy(e);
     (void)hipEventDestroy(a->expandFork);
+    (void)hipEventDestroy(a->groupFork);
+    for (hipEvent_t e : a->groupExpanded) (void)hipEventDestroy(e);
+    for (hipEvent_t e : a->groupReady) (void)hipEventDestroy(e);
     for (hipEvent_t e : a->expandJoin) (void)hipEventDestroy(e);
     for (auto& lv : a->levelDone)
       for (hipEvent_t e : lv) (void)hipEventDestroy(e);
@@ -2014,6 +2026,11 @@ void ssrlcv_sift_plan_destroy(ssrlcv_sift_plan* plan) {
 size_t ssrlcv_sift_plan_workspace_bytes(const ssrlcv_sift_plan* plan) { return plan ? plan->total : 0; }
 uint32_t ssrlcv_sift_plan_max_features(const ssrlcv_sift_plan* plan) { return plan ? plan->maxFeatures : 0; }
 void ssrlcv_sift_plan_set_stop_stage(ssrlcv_sift_plan* plan, int stage) { if (plan) plan->stopStage = stage; }
+int ssrlcv_sift_plan_set_stage_event(ssrlcv_sift_plan* plan, void* event) {
+  if (!plan) return SSRLCV_ERR_INVALID_ARG;
+  plan->stageEvent = (hipEvent_t)event;
+  return SSRLCV_OK;
+}
 
 int ssrlcv_sift_plan_level(const ssrlcv_sift_plan* plan, void* workspace, int kind, int octave, int blur, float** data,
                            uint32_t* w, uint32_t* h, float** minmax_dev) {
@@ -2090,6 +2107,18 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
   static const DogSchedule sched;
   static const bool overlapOctaves = svdev::env("SSRLCV_NO_OCTAVE_OVERLAP") == nullptr;
   static const int overlapFrom = svdev::env("SSRLCV_OCTAVE_OVERLAP_FROM") ? atoi(svdev::env("SSRLCV_OCTAVE_OVERLAP_FROM")) : 1;
+  // Developer build, SSRLCV_EARLY_POLAR=1: a fused extract starts an octave's gradient tables (k_polar, the first thing the
+  // key-point stage needs) on a side stream as soon as that octave's DoG pass is through, beside the small octaves' launches.
+  // Exact, measured in round 5 and NOT the default: the scale-space stage grows by 0.36 ms per 4096^2 image (the tables'
+  // 16 384 short blocks crowd the small octaves' latency-bound launches) and the key-point stage shrinks by 0.10
+  // (profiles/r05_schedule_ab.txt: step 10.19 -> 10.67 ms).
+  static const bool wantEarlyPolar = svdev::env("SSRLCV_EARLY_POLAR") != nullptr;
+  const bool earlyPolar = as && plan->fusedCall && plan->stopStage >= 6 && wantEarlyPolar;
+  plan->polarInFlight = 0;
+  if (earlyPolar) {  // the tables may still be read by the sampling kernels of the previous extract on this plan: behind the caller's stream
+    SSRLCV_HIP_TRY(hipEventRecord(as->fork, st));
+    SSRLCV_HIP_TRY(hipStreamWaitEvent(as->polar, as->fork, 0));
+  }
   hipLaunchKernelGGL(k_init_minmax, dim3(1), dim3(64), 0, st, mmAll, pairs);
   // S1+S2: u8 -> f32 + one 2x upsample (startingOctave = -1)
   float* in = (float*)(ws + plan->off_in0);
@@ -2115,6 +2144,64 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
   if (rc) return rc;
   float* nextIn[3] = {(float*)(ws + plan->off_in1), (float*)(ws + plan->off_in2), (float*)(ws + plan->off_in1)};
   const float firstNoise = (float)(svp::kNoiseThreshold * 0.8);  // removeNoise(noiseThreshold * 0.8), src/FeatureFactory.cu:484
+  // Experimental schedule (developer build, SSRLCV_PHASED=<n + 1>): the dependency chain of the stage -- levels 0-3 of every
+  // octave, each octave's input being the bin of the previous one's level 3 -- runs in order on the caller's stream (phases
+  // A_0 .. A_3); what hangs off it (levels 4-5 and the DoG / extrema pass of octave o: phase B_o) goes to side streams and
+  // may be held back until the chain is n octaves ahead (B_o waits for the bin of octave o + n), so that the long-lived
+  // blocks of the big levels do not sit on the CUs while the chain's short launches look for room.
+  static const int phased = svdev::env("SSRLCV_PHASED") ? atoi(svdev::env("SSRLCV_PHASED")) : 0;
+  if (as && phased > 0) {
+    const int ahead = phased - 1;
+    const float* octIn = in;
+    for (int o = 0; o < svp::kOctaves; ++o) {  // the chain
+      const svp::OctavePlan& oc = plan->oct[o];
+      float* mm = mmAll + (size_t)o * 2 * (svp::kGauss + svp::kDog);
+      const float* src = octIn;
+      for (int b = 0; b < 4; ++b) {
+        float* dst = (float*)(ws + plan->off_gauss[o][b]);
+        bool binned = false;
+        rc = launch_conv(src, dst, nullptr, oc.w, oc.h, oc.taps[b], oc.weights[b], mm + 2 * b, st,
+                         (fuseUpsample && o == 0 && b == 0) ? pixels : nullptr, (b == 3 && o + 1 < svp::kOctaves) ? nextIn[o] : nullptr, &binned);
+        if (rc) return rc;
+        src = dst;
+        if (b == 3 && o + 1 < svp::kOctaves) {
+          if (!binned) {
+            rc = ssrlcv_hip_bin2x(dst, oc.w, oc.h, nextIn[o], (ssrlcv_stream_t)st);
+            if (rc) return rc;
+          }
+          octIn = nextIn[o];
+        }
+      }
+      SSRLCV_HIP_TRY(hipEventRecord(as->binDone[o], st));
+    }
+    for (int o = 0; o < svp::kOctaves; ++o) {  // what hangs off it
+      const svp::OctavePlan& oc = plan->oct[o];
+      float* mm = mmAll + (size_t)o * 2 * (svp::kGauss + svp::kDog);
+      const hipStream_t sb = o == 0 ? as->table : (o == 1 ? as->chain : st);
+      const int gate = o + ahead < svp::kOctaves ? o + ahead : svp::kOctaves - 1;
+      if (sb != st) SSRLCV_HIP_TRY(hipStreamWaitEvent(sb, as->binDone[gate], 0));
+      const float* lv[svp::kGauss];
+      for (int b = 0; b < svp::kGauss; ++b) lv[b] = (const float*)(ws + plan->off_gauss[o][b]);
+      for (int b = 4; b < svp::kGauss; ++b) {
+        rc = launch_conv(lv[b - 1], (float*)(ws + plan->off_gauss[o][b]), nullptr, oc.w, oc.h, oc.taps[b], oc.weights[b], mm + 2 * b, sb);
+        if (rc) return rc;
+      }
+      float* dogPartial = (float*)(ws + plan->off_dogPartial) + (size_t)o * 2 * svp::kDog * svp::kDogMaxWaves;
+      rc = launch_dogx(lv, mm, oc.w, oc.h, (uint8_t*)(ws + oc.off_flags), mm + 2 * svp::kGauss, dogPartial, 0, svp::kDog, 0, false, firstNoise,
+                       sched.waves, sb);
+      if (rc) return rc;
+      SSRLCV_HIP_TRY(hipEventRecord(as->dogDone[o], sb));
+      if (earlyPolar) {
+        SSRLCV_HIP_TRY(hipStreamWaitEvent(as->polar, as->dogDone[o], 0));
+        svp::launch_polar_octave(plan, ws, o, as->polar);
+        SSRLCV_HIP_TRY(hipEventRecord(as->polarDone[o], as->polar));
+      }
+    }
+    if (earlyPolar) plan->polarInFlight = 1;
+    SSRLCV_HIP_TRY(hipStreamWaitEvent(st, as->dogDone[0], 0));
+    SSRLCV_HIP_TRY(hipStreamWaitEvent(st, as->dogDone[1], 0));
+    return SSRLCV_OK;
+  }
   for (int o = 0; o < svp::kOctaves; ++o) {
     const svp::OctavePlan& oc = plan->oct[o];
     float* mm = mmAll + (size_t)o * 2 * (svp::kGauss + svp::kDog);
@@ -2170,7 +2257,13 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
     else rc = launch_dogx(lv, mm, oc.w, oc.h, flags, mm + 2 * svp::kGauss, dogPartial, 0, svp::kDog, 0, false, firstNoise, sched.waves, sdo);
     if (rc) return rc;
     if (as) SSRLCV_HIP_TRY(hipEventRecord(as->dogDone[o], sdo));
+    if (earlyPolar) {  // fused extract: this octave's gradient tables start now, on their own stream
+      SSRLCV_HIP_TRY(hipStreamWaitEvent(as->polar, as->dogDone[o], 0));
+      svp::launch_polar_octave(plan, ws, o, as->polar);
+      SSRLCV_HIP_TRY(hipEventRecord(as->polarDone[o], as->polar));
+    }
   }
+  if (earlyPolar) plan->polarInFlight = 1;
   if (as) {  // join: every stream a DoG pass ran on (in-order streams: the last pass of each covers the earlier ones)
     for (int o = 0; o < svp::kOctaves; ++o) SSRLCV_HIP_TRY(hipStreamWaitEvent(st, as->dogDone[o], 0));
   }

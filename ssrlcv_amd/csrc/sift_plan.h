@@ -82,9 +82,13 @@ struct OctavePlan {
 constexpr unsigned kDogMaxBlocks = 16384;               // grid bound of the streaming DoG kernel (256-thread blocks)
 constexpr unsigned kDogMaxWaves = kDogMaxBlocks * 4;
 
+constexpr int kSampleGroups = 4;  // describe: the (octave, blur segment) groups the orientation / descriptor kernels are pipelined over
+
 struct PlanAsync {
   hipStream_t chain, table, chain2;  // chain2: the list chains of octaves 2-3 in describe (octave 1's runs on `chain`)
+  hipStream_t polar;                 // round 5: the polar tables of a fused extract, started from inside build_dog
   hipEvent_t fork;
+  hipEvent_t groupFork, groupExpanded[kSampleGroups], groupReady[kSampleGroups];  // describe: pipelined sampling groups
   hipEvent_t join[kOctaves + 1], convDone[kOctaves], dogDone[kOctaves], polarDone[kOctaves];
   hipEvent_t binDone[kOctaves];              // build_dog: level 3 of octave o and its 2x2 bin are complete
   hipEvent_t expandFork, expandJoin[2];      // describe: the orientation-expansion partitions of octaves 1..3 on the side streams
@@ -110,6 +114,7 @@ struct ssrlcv_sift_plan {
   size_t off_state;    // OctaveState[kOctaves]
   size_t off_extremaCounts;  // scratch for the pixel-domain partition
   size_t off_dogPartial;     // per-wave {min, max} partials of the streaming DoG kernel: float[2 * kDog][kDogMaxWaves]
+  size_t off_groups;         // 4 KB: range tables and control words of the pipelined sampling groups (keypoints.hip)
   size_t total;
   uint32_t maxFeatures;
   int stopStage;
@@ -117,6 +122,13 @@ struct ssrlcv_sift_plan {
   // by every key-point stage, read by the next one and by ssrlcv_sift_plan_keypoints.  Host-side state of the (plan,
   // workspace) pair the stages run on: one extraction at a time per plan.
   mutable uint8_t listInB[svp::kOctaves];
+  // ssrlcv_hip_sift_extract (both stages in one call): build_dog queues the polar tables of octave o on the `polar` side
+  // stream as soon as that octave's DoG min / max exist (they are the first thing the key-point stage needs and the small
+  // octaves' launches leave the chip half idle at the end of the scale-space stage); describe then joins them instead of
+  // launching them.  The stand-alone stage calls keep their stream-ordered contract: nothing of theirs is left in flight.
+  mutable int fusedCall;          // set by extract around its two stage calls
+  mutable int polarInFlight;      // build_dog has queued the polar tables (events polarDone[])
+  mutable hipEvent_t stageEvent;  // nullable: recorded by extract on the caller's stream between the two stages
   mutable svp::PlanAsync* async;  // created on first use (needs a device); see svp::plan_async
   mutable int asyncState;         // 0 not tried, 1 ready, -1 serial (SSRLCV_SIFT_SERIAL set or creation failed)
 };
@@ -124,4 +136,6 @@ struct ssrlcv_sift_plan {
 namespace svp {
 // -> the plan's side streams, or nullptr when the calls must run serially on the caller's stream
 PlanAsync* plan_async(const ssrlcv_sift_plan* plan);
+// k_polar (keypoints.hip) for ONE octave on `st`: the gradient tables of its DoG levels 1..3
+void launch_polar_octave(const ssrlcv_sift_plan* plan, char* ws, int octave, hipStream_t st);
 }  // namespace svp

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <map>
 #include <memory>
+#include <new>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -36,17 +37,29 @@ inline void __hipSafeCall(int status, const char* file, const int line) {
 namespace detail {
 class BlockCache {
   std::mutex mtx;
-  std::map<size_t, std::vector<void*>> freeList[2];  // [0] device, [1] pinned host
-  size_t cached[2] = {0, 0};
-  const size_t budget[2] = {(size_t)24 << 30, (size_t)2 << 30};
+  std::map<size_t, std::vector<void*>> freeList[3];  // [0] device, [1] pinned host, [2] pageable host (round 5)
+  size_t cached[3] = {0, 0, 0};
+  const size_t budget[3] = {(size_t)24 << 30, (size_t)2 << 30, (size_t)2 << 30};
   bool enabled;
 
  public:
   BlockCache() : enabled(std::getenv("SSRLCV_NO_BLOCK_CACHE") == nullptr) {}
   ~BlockCache() {  // process exit: the runtime may already be gone, so return codes are not checked
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < 3; ++k)
       for (auto& e : freeList[k])
-        for (void* p : e.second) (void)(k == 0 ? ssrlcv_hip_free(p) : ssrlcv_hip_host_free(p));
+        for (void* p : e.second) (void)release(k, p);
+  }
+  static int acquire(int kind, void** p, size_t bytes) {
+    if (kind == 0) return ssrlcv_hip_malloc(p, bytes);
+    if (kind == 1) return ssrlcv_hip_host_malloc(p, bytes);
+    *p = std::malloc(bytes);  // pageable: what `new T[n]` rests on (16-byte aligned, like operator new[])
+    return *p ? 0 : 2;        // 2 = hipErrorOutOfMemory
+  }
+  static int release(int kind, void* p) {
+    if (kind == 0) return ssrlcv_hip_free(p);
+    if (kind == 1) return ssrlcv_hip_host_free(p);
+    std::free(p);
+    return 0;
   }
   static size_t classOf(size_t bytes) {
     const size_t g = bytes <= ((size_t)1 << 20) ? 256 : ((size_t)1 << 20);
@@ -65,10 +78,10 @@ class BlockCache {
       }
     }
     void* p = nullptr;
-    int rc = kind == 0 ? ssrlcv_hip_malloc(&p, cls) : ssrlcv_hip_host_malloc(&p, cls);
+    int rc = acquire(kind, &p, cls);
     if (rc != 0 && enabled) {  // out of memory with blocks parked in the cache: release them and try once more
       trim(kind);
-      rc = kind == 0 ? ssrlcv_hip_malloc(&p, cls) : ssrlcv_hip_host_malloc(&p, cls);
+      rc = acquire(kind, &p, cls);
     }
     __hipSafeCall(rc, __FILE__, __LINE__);
     return p;
@@ -83,12 +96,12 @@ class BlockCache {
         return;
       }
     }
-    __hipSafeCall(kind == 0 ? ssrlcv_hip_free(p) : ssrlcv_hip_host_free(p), __FILE__, __LINE__);
+    __hipSafeCall(release(kind, p), __FILE__, __LINE__);
   }
   void trim(int kind) {
     std::lock_guard<std::mutex> lock(mtx);
     for (auto& e : freeList[kind])
-      for (void* p : e.second) (void)(kind == 0 ? ssrlcv_hip_free(p) : ssrlcv_hip_host_free(p));
+      for (void* p : e.second) (void)release(kind, p);
     freeList[kind].clear();
     cached[kind] = 0;
   }
@@ -107,7 +120,19 @@ template <typename T> struct host_pinned_delete {
   size_t cls;
   void operator()(T* p) const { detail::blockCache().give(1, p, cls); }
 };
-template <typename T> struct host_unpinned_delete { void operator()(T* p) const { delete[] p; } };
+// Pageable host arrays: `new T[n]` upstream.  Blocks of 1 MiB and more come from the cache too (a fresh 45 MB array is
+// mmap'ed, page-faulted by its first writer and unmapped again on every generateFeatures + transferMemoryTo(cpu): 5 of the
+// 7.3 ms that leg took in round 4); the elements are default-constructed in place unless the caller is about to overwrite
+// all of them (construct = false: transferMemoryTo's device-to-host copy), and destroyed when T needs it.
+template <typename T> struct host_unpinned_delete {
+  size_t n, cls;  // cls == 0: a plain new[] array
+  void operator()(T* p) const {
+    if (cls == 0) { delete[] p; return; }
+    if (!std::is_trivially_destructible<T>::value)
+      for (size_t i = n; i-- > 0;) p[i].~T();
+    detail::blockCache().give(2, p, cls);
+  }
+};
 
 namespace ptr {
 
@@ -154,15 +179,28 @@ class host : public base<T> {
  public:
   using base<T>::ptr;
   using base<T>::set;
-  void set(long n, bool pinned = false) {
+  void set(long n, bool pinned = false) { alloc(n, pinned, true); }
+  // the same allocation for a caller that overwrites every element next (Unity<T>::transferMemoryTo's device-to-host copy)
+  void setForOverwrite(long n, bool pinned = false) { alloc(n, pinned, false); }
+
+ private:
+  void alloc(long n, bool pinned, bool construct) {
     if (pinned) {
       size_t cls = 0;
       void* tmp = detail::blockCache().take(1, (size_t)n * sizeof(T), cls);
       ptr.reset((T*)tmp, host_pinned_delete<T>{cls});
+    } else if ((size_t)n * sizeof(T) >= ((size_t)1 << 20) && alignof(T) <= 16) {
+      size_t cls = 0;
+      T* tmp = (T*)detail::blockCache().take(2, (size_t)n * sizeof(T), cls);
+      if (construct && !std::is_trivially_default_constructible<T>::value)
+        for (long i = 0; i < n; ++i) ::new ((void*)(tmp + i)) T;
+      ptr.reset(tmp, host_unpinned_delete<T>{(size_t)n, cls});
     } else {
-      ptr.reset(new T[n], host_unpinned_delete<T>());
+      ptr.reset(new T[n], host_unpinned_delete<T>{(size_t)n, 0});
     }
   }
+
+ public:
   host() {}
   host(std::nullptr_t) noexcept {}
   host(const host& r) : base<T>() { this->ptr = r.ptr; }

@@ -332,7 +332,7 @@ class Unity {
     }
     if (state != both) {
       if (state == cpu && device == nullptr) device.set(numElements);
-      else if (state == gpu && host == nullptr) host.set(numElements, pinned);
+      else if (state == gpu && host == nullptr) host.setForOverwrite(numElements, pinned);  // every element is overwritten by d2h() below
       state = both;
     }
     if (fore == cpu) h2d();

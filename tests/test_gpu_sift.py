@@ -361,6 +361,48 @@ def test_every_pyramid_schedule_is_bit_exact(variant):
     assert r.returncode == 0 and "PYRAMID OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+_FEATURES_SCRIPT = r"""
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import numpy as np
+import helpers as H
+from ssrlcv_amd import capi
+lib = H.oracle()
+for (w, h, seed) in [(512, 384, 5), (262, 260, 6), (640, 128, 7)]:
+    img = H.synthetic_image(w, h, seed=seed)
+    plan = capi.SiftPlan(w, h)
+    for rep in range(2):                       # twice on one plan: the group control words are re-armed per call
+        plan.extract(capi.to_dev(img))
+        g = plan.features_host(H.FEATURE)
+    o = H.oracle_sift(lib, img)
+    assert len(g) == len(o) and len(g) > 100, (w, h, len(g), len(o))
+    H.assert_features_equal(g, o)
+print("FEATURES OK")
+"""
+
+
+@pytest.mark.parametrize("variant", [
+    {"SSRLCV_SAMPLING_PIPELINED": "1"},                                    # orientation / descriptor launches pipelined over four sampling groups
+    {"SSRLCV_SAMPLING_PIPELINED": "1", "SSRLCV_SAMPLING_IRREGULAR": "1"},  # ... its fallback for blur indices that are not an ordered partition
+    {"SSRLCV_EARLY_POLAR": "1"},                                           # gradient tables started from inside build_dog (fused extract)
+    {"SSRLCV_EARLY_POLAR": "1", "SSRLCV_SAMPLING_PIPELINED": "1"},
+    {"SSRLCV_PHASED": "1"}, {"SSRLCV_PHASED": "2"},                        # build_dog: the octave chain on one stream, levels 4-5 + DoG passes beside it
+], ids=lambda v: "+".join(k.replace("SSRLCV_", "") + "=" + x for k, x in v.items()))
+def test_every_sampling_schedule_is_bit_exact(variant):
+    """Round 5's schedule experiments (developer build; exact, measured, not the defaults: profiles/r05_schedule_ab.txt): the
+    orientation / descriptor kernels pipelined over four sampling groups (keypoints.hip: octave 0's expansion in three
+    pieces that continue each other) with the fallback the device takes when an octave's blur indices are irregular, the
+    gradient tables started from inside build_dog, and the phased order of build_dog's launches give the default schedule's
+    features -- every field equal to the oracle's -- in child processes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _FEATURES_SCRIPT % {"root": root}], env=H.dev_env(**variant), capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and "FEATURES OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 @pytest.mark.parametrize("size", [(64, 64), (72, 200), (136, 64), (200, 4096)])
 def test_small_and_thin_images_match_oracle(capi, oracle_lib, size):
     """The reference takes any image of at least 8 x 8 pixels (src/FeatureFactory.cu:341-345,364-376); below 64 pixels its
