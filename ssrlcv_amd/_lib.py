@@ -41,7 +41,8 @@ def load():
         _lib.ssrlcv_hip_version.restype = ctypes.c_char_p
         _lib.ssrlcv_hip_status_string.restype = ctypes.c_char_p
         for name in ("ssrlcv_hip_match_workspace_bytes", "ssrlcv_sift_plan_workspace_bytes",
-                     "ssrlcv_hip_ba_sweep2_workspace_bytes", "ssrlcv_hip_sort_workspace_bytes"):
+                     "ssrlcv_hip_ba_sweep2_workspace_bytes", "ssrlcv_hip_sort_workspace_bytes",
+                     "ssrlcv_hip_select_pair_workspace_bytes", "ssrlcv_hip_filter_workspace_bytes", "ssrlcv_hip_merge_workspace_bytes"):
             getattr(_lib, name).restype = ctypes.c_size_t
         _lib.ssrlcv_sift_plan_max_features.restype = ctypes.c_uint32
     return _lib
@@ -61,6 +62,7 @@ EXPORTED = [
     "ssrlcv_hip_merge_workspace_bytes", "ssrlcv_hip_merge_matches",
     "ssrlcv_hip_sort_workspace_bytes", "ssrlcv_hip_sort_keys_u32",
     "ssrlcv_hip_error_sample_cutoff", "ssrlcv_hip_filter_workspace_bytes", "ssrlcv_hip_filter_matchset",
+    "ssrlcv_hip_select_pair_workspace_bytes", "ssrlcv_hip_select_pair_bundles",
     "ssrlcv_hip_convert_to_bw", "ssrlcv_hip_u8_to_f32", "ssrlcv_hip_upsample2x", "ssrlcv_hip_upsample2x_u8", "ssrlcv_hip_bin2x",
     "ssrlcv_gauss_kernel_host", "ssrlcv_hip_gauss_sep_conv", "ssrlcv_hip_minmax", "ssrlcv_hip_normalize",
     "ssrlcv_hip_dog_normalised_sub",

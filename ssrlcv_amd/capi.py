@@ -135,6 +135,19 @@ def filter_matchset(bundles_d, keypoints_d, num_bundles, num_keypoints):
     return mm, kp, counts
 
 
+def select_pair_bundles(matches_d, keypoints_d, num_matches, num_keypoints, image_a, image_b):
+    """The two-view bundles of image pair (a, b) of a MatchSet on the device as a two-camera MatchSet
+    (ssrlcv_hip_select_pair_bundles) -> (MultiMatch bytes, KeyPoint bytes, count tensor); asynchronous."""
+    ws = dev_bytes(int(LIB.ssrlcv_hip_select_pair_workspace_bytes(c_u32(num_matches))))
+    mm = dev_bytes(8 * max(num_matches, 1))
+    kp = dev_bytes(32 * max(num_matches, 1))
+    count = torch.zeros(1, dtype=torch.int32, device="cuda")
+    check(LIB.ssrlcv_hip_select_pair_bundles(ptr(matches_d), ptr(keypoints_d), c_u32(num_matches), c_u32(num_keypoints),
+                                             c_int(image_a), c_int(image_b), ptr(mm), ptr(kp), ptr(count), ptr(ws), c_sz(ws.numel()),
+                                             stream_ptr()))
+    return mm, kp, count
+
+
 def ba_sweep2(matches_d, keypoints_d, num_bundles, cameras_d, num_cameras, params_d, K):
     sums = torch.zeros(K, dtype=torch.float32, device="cuda")
     check(LIB.ssrlcv_hip_ba_sweep2(ptr(matches_d), ptr(keypoints_d), c_u32(num_bundles), ptr(cameras_d),

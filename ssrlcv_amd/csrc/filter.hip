@@ -132,6 +132,55 @@ __global__ __launch_bounds__(svs::kThreads) void k_filter_matchset(const ssrlcv_
 
 inline uint32_t filter_tiles(uint32_t n) { return (n + svs::kThreads * kItems - 1) / (svs::kThreads * kItems); }
 
+// ---- the two-view bundles of one image pair out of an N-view MatchSet, as a two-camera MatchSet (round 5) -----------------------
+// BundleAdjustTwoView works on a 2-view MatchSet; in the N-view flows (config[3]) the sweep is run on the bundles of the
+// first image pair.  One look-back pass: a multi-match is taken when it has exactly two key points and they belong to
+// images a and b (in that order, which is the order generateMatchesExhaustive writes them); output j = {2, 2 j} with the
+// two key points re-labelled 0 / 1, order kept.
+__global__ __launch_bounds__(svs::kThreads) void k_select_pair(const ssrlcv_multimatch* __restrict__ mm, const ssrlcv_keypoint* __restrict__ kp,
+                                                               uint32_t n, uint32_t numKeyPoints, int imageA, int imageB,
+                                                               ssrlcv_multimatch* __restrict__ mmOut, ssrlcv_keypoint* __restrict__ kpOut,
+                                                               uint32_t* __restrict__ count, svs::TileScan<1> ts) {
+  constexpr uint32_t kTile = svs::kThreads * kItems;
+  for (uint32_t tile = svs::next_tile(ts.counter); tile < ts.numTiles; tile = svs::next_tile(ts.counter)) {
+    const uint32_t base = tile * kTile + threadIdx.x * kItems;
+    bool keep[kItems];
+    uint32_t first[kItems];
+    uint32_t mine[1] = {0};
+#pragma unroll
+    for (int j = 0; j < kItems; ++j) {
+      keep[j] = false;
+      first[j] = 0;
+      if (base + j < n) {
+        const ssrlcv_multimatch m = mm[base + j];
+        first[j] = (uint32_t)m.index;
+        keep[j] = m.numKeyPoints == 2u && m.index >= 0 && first[j] + 1u < numKeyPoints && kp[first[j]].parentId == imageA &&
+                  kp[first[j] + 1u].parentId == imageB;
+      }
+      mine[0] += keep[j] ? 1u : 0u;
+    }
+    uint32_t excl[1], total[1], prefix[1];
+    svs::block_exclusive<1>(mine, excl, total);
+    svs::tile_prefix<1>(ts, tile, total, prefix);
+    uint32_t at = prefix[0] + excl[0];
+#pragma unroll
+    for (int j = 0; j < kItems; ++j) {
+      if (!keep[j]) continue;
+      ssrlcv_keypoint k0 = kp[first[j]], k1 = kp[first[j] + 1u];
+      k0.parentId = 0;
+      k1.parentId = 1;
+      kpOut[2u * at] = k0;
+      kpOut[2u * at + 1u] = k1;
+      ssrlcv_multimatch m;
+      m.numKeyPoints = 2u;
+      m.index = (int)(2u * at);
+      mmOut[at] = m;
+      ++at;
+    }
+    if (tile == ts.numTiles - 1 && threadIdx.x == 0) *count = prefix[0] + total[0];
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -145,6 +194,27 @@ int ssrlcv_hip_error_sample_cutoff(const float* errors, uint32_t numErrors, uint
 }
 
 size_t ssrlcv_hip_filter_workspace_bytes(uint32_t numBundles) { return svs::workspace_bytes<3>(filter_tiles(numBundles ? numBundles : 1)); }
+
+size_t ssrlcv_hip_select_pair_workspace_bytes(uint32_t numMatches) { return svs::workspace_bytes<1>(filter_tiles(numMatches ? numMatches : 1)); }
+
+int ssrlcv_hip_select_pair_bundles(const ssrlcv_multimatch* matches, const ssrlcv_keypoint* keyPoints, uint32_t numMatches,
+                                   uint32_t numKeyPoints, int imageA, int imageB, ssrlcv_multimatch* matchesOut,
+                                   ssrlcv_keypoint* keyPointsOut, uint32_t* count, void* workspace, size_t workspaceBytes,
+                                   ssrlcv_stream_t stream) {
+  if (!count) return SSRLCV_ERR_INVALID_ARG;
+  const hipStream_t st = (hipStream_t)stream;
+  if (numMatches == 0) return (int)hipMemsetAsync(count, 0, 4, st);
+  if (!matches || !keyPoints || !matchesOut || !keyPointsOut || !workspace) return SSRLCV_ERR_INVALID_ARG;
+  const uint32_t tiles = filter_tiles(numMatches);
+  if (workspaceBytes < svs::workspace_bytes<1>(tiles)) return SSRLCV_ERR_WORKSPACE;
+  SSRLCV_HIP_TRY(hipMemsetAsync(workspace, 0, svs::workspace_bytes<1>(tiles), st));
+  const svs::TileScan<1> ts = svs::make_tile_scan<1>(workspace, tiles);
+  const unsigned blocks = tiles < 2048u ? tiles : 2048u;
+  hipLaunchKernelGGL(k_select_pair, dim3(blocks), dim3(svs::kThreads), 0, st, matches, keyPoints, numMatches, numKeyPoints, imageA, imageB,
+                     matchesOut, keyPointsOut, count, ts);
+  SSRLCV_LAUNCH_CHECK();
+  return SSRLCV_OK;
+}
 
 int ssrlcv_hip_filter_matchset(const ssrlcv_bundle* bundles, const ssrlcv_keypoint* keyPoints, uint32_t numBundles,
                                ssrlcv_multimatch* matchesOut, ssrlcv_keypoint* keyPointsOut, uint32_t* counts, void* workspace,

@@ -366,31 +366,15 @@ def ba_parameter_sets(cameras2, h_lin=1e-5, h_step=(1e-4, 1e-4, 1e-4, 1e-5, 1e-5
 
 
 def _ba_subset_device(dev, n_mm, pair, world, rank):
-    """The 2-view bundles of `pair` out of the device copy of the MatchSet, this rank's share of them, as a 2-camera
-    MatchSet on the device (torch index arithmetic: plumbing, no host round trip of the arrays).
-    -> (MultiMatch bytes, KeyPoint bytes, bundles of this rank, bundles of the pair)"""
-    mm_i = dev["matches"][: 8 * n_mm].view(torch.int32).view(-1, 2)          # {numKeyPoints, index}
-    kp_i = dev["keypoints"].view(torch.int32).view(-1, 4)                     # {parentId, pad, loc.x, loc.y}
-    idx = mm_i[:, 1].long()
-    two = (mm_i[:, 0] == 2)
-    idx2 = torch.where(two, idx, torch.zeros_like(idx))
-    sel = two & (kp_i[idx2, 0] == pair[0]) & (kp_i[torch.clamp(idx2 + 1, max=kp_i.shape[0] - 1), 0] == pair[1])
-    rows = torch.nonzero(sel).view(-1)
-    total = int(rows.numel())
+    """The 2-view bundles of `pair` out of the device copy of the MatchSet as a 2-camera MatchSet on the device
+    (ssrlcv_hip_select_pair_bundles: one library pass, the count is the only thing that comes back), and this rank's share
+    of them: the MultiMatch entries index the shared KeyPoint array, so a share is a slice of the MultiMatch array.
+    -> (MultiMatch bytes of the share, KeyPoint bytes, bundles of this rank, bundles of the pair)"""
+    n_kp = dev["keypoints"].numel() // 16
+    sub_mm, sub_kp, count = capi.select_pair_bundles(dev["matches"], dev["keypoints"], n_mm, n_kp, pair[0], pair[1])
+    total = int(count.item())
     lo, hi = sd.bundle_range(total, world, rank)
-    rows = rows[lo:hi]
-    n = hi - lo
-    sub_kp = torch.zeros((2 * n, 4), dtype=torch.int32, device=kp_i.device)
-    if n:
-        first = idx[rows]
-        sub_kp[0::2] = kp_i[first]
-        sub_kp[1::2] = kp_i[first + 1]
-        sub_kp[0::2, 0] = 0
-        sub_kp[1::2, 0] = 1
-    sub_mm = torch.empty((n, 2), dtype=torch.int32, device=kp_i.device)
-    sub_mm[:, 0] = 2
-    sub_mm[:, 1] = 2 * torch.arange(n, dtype=torch.int32, device=kp_i.device)
-    return sub_mm.view(torch.uint8).view(-1), sub_kp.view(torch.uint8).view(-1), n, total
+    return sub_mm[8 * lo: 8 * hi], sub_kp, hi - lo, total
 
 
 def ba_error_sweep(mm, kp, cameras, pair=(0, 1), params=None, dev=None):
