@@ -338,6 +338,42 @@ def class_api_leg(img_u8, size, value_c_abi, iters=5):
                     "(a D2H copy, as upstream) and the exact-size feature copy"}
 
 
+def class_api_flow_leg(imgs, cams, size, nview_ms, cloud_py, iters=3):
+    """BASELINE config[3]'s flow through the class-level calls of the C++ mirror (host/Distributed.hpp at world 1:
+    SIFT_FeatureFactory::generateFeatures per image from host pixels -> generateMatchesExhaustiveSharded -> nViewTriangulateSharded
+    -> selectPairBundles + the 612-point sweep), timed by tests/cpp/sharded_match_test.cpp `bench-flow`, beside the Python C-ABI
+    flow's step (`nview`); the C++ cloud is compared with the Python flow's bit for bit."""
+    import shutil
+    import tempfile
+    import helpers as H
+    exe = H.SHARDED_BIN
+    if not os.path.exists(exe):
+        return {"error": "sharded_match_test not built"}
+    info = H.host_typeinfo()
+    d = tempfile.mkdtemp(prefix="ssrlcv_flow_", dir="/tmp")
+    try:
+        for i, im in enumerate(imgs):
+            H.write_uty(os.path.join(d, "pixels_%d.uty" % i), *info["uchar"], 1, im.cpu().numpy().reshape(-1))
+            H.write_cpimg(os.path.join(d, "%d_%s.cpimg" % (i, info["Image"][0])), i, (size, size), cams[i:i + 1])
+        seed, _ = H.load_seed_features()
+        H.write_uty(os.path.join(d, "-1_%s.uty" % info["Feature"][0]), *info["Feature"], 2, seed)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([exe, "bench-flow", d, str(len(imgs)), str(iters)], capture_output=True, text=True, timeout=900, env=env)
+        if r.returncode != 0:
+            return {"error": (r.stdout + r.stderr)[-400:]}
+        j = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+        raw = open(os.path.join(d, "300_6float3.uty"), "rb").read()
+        pts = np.frombuffer(raw[len(raw) - 12 * j["points"]:], np.float32).reshape(-1, 3)
+        same = cloud_py is not None and pts.shape == tuple(cloud_py.shape) and bool(np.array_equal(pts.view(np.uint32), cloud_py.view(np.uint32)))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    j.update({"nview_ms_per_step": nview_ms, "flow_over_nview": j["flow_ms"] / nview_ms if nview_ms else None,
+              "cloud_equals_python_flow": same,
+              "note": "synchronous class-level calls, one image at a time, pixels in host memory (each generateFeatures uploads its image "
+                      "and restores the origin state); features stay on the device between the stages; RCCL communicator of one rank"})
+    return j
+
+
 def describe_roofline(ms_per_image, features, size):
     """Roofline of the key-point stage.  Its kernels are bound by vector-instruction issue (the sampling kernels) or move
     little data, so the stage is priced against the VALU issue peak with the wave-instruction count of the committed PMC
@@ -438,7 +474,8 @@ def run_nview(args, torch, dist, capi, world, rank, dev, views, size, steps, war
             "wire": wire,
             "multi_matches": int(len(res["matches"])), "points": int(res["points"].shape[0]),
             "ba_bundles": int(res.get("ba_bundles", 0)),
-            "features_per_image": nf}
+            "features_per_image": nf,
+            "_inputs": (imgs, cams, res["points"].cpu().numpy())}   # for the class-API flow leg (popped before printing)
 
 
 def main():
@@ -578,11 +615,14 @@ def main():
         # so that its stage times are not polluted by rank skew
         nviews = args.nview_views if args.nview_views > 0 else max(4, world)
         nv = run_nview(args, torch, dist, capi, world, rank, dev, nviews, args.nview_size, args.nview_steps, 1)
+        nv_inputs = nv.pop("_inputs")
         if rank == 0:
             line["nview"] = nv
     if rank == 0:
         if not args.no_class_api:
             line["class_api"] = class_api_leg(img0, W, line["value"] / world)
+            if not args.no_nview and world == 1:
+                line["class_api"]["flow"] = class_api_flow_leg(nv_inputs[0], nv_inputs[1], args.nview_size, nv["ms_per_step"], nv_inputs[2])
         if not args.no_matcher:
             line["matcher"] = bench_matcher(capi, torch, args.match_n, args.match_n, args.match_iters)
             line["matcher_f16"] = bench_matcher(capi, torch, args.match_n, args.match_n, args.match_iters, "f16")

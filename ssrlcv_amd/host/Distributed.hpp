@@ -13,16 +13,28 @@
 // (ssrlcv_assign_pairs_host: cost nq x nt, the same definition the Python driver ssrlcv_amd/dist.py uses).
 // Exact sizes travel: no padding to the largest rank.
 //
+// Round 5: the rest of the flow is sharded here too -- nViewTriangulateSharded (bundle ranges + a grouped broadcast of the
+// cloud), selectPairBundles (ssrlcv_hip_select_pair_bundles) and evaluateCameraSetsSharded (the 612-point BA error sweep
+// over a bundle range + ncclAllReduce of the sums): the C++ counterpart of ssrlcv_amd/pipeline.py's stages C and BA.
+//
+// Ordering: every exchange runs on Comm::stream.  The mirror's own calls (SIFT, matcher, ssrlcv_hip_memcpy) are synchronous
+// on the null stream and have returned before an exchange is queued, so Comm::stream may be the null stream or any other
+// stream: nothing asynchronous is pending when ncclGroupStart is reached.  Within a group RCCL serialises the broadcasts
+// on the communicator's stream; "grouped" here means one launch, not concurrency.
+//
 // Not part of the umbrella header ssrlcv.hpp: a program that includes it links librccl and libamdhip64 (still plain g++:
 // rccl_abi.hpp declares the few entry points used); everything else of the mirror needs only the C ABI library.
 #pragma once
 #include "rccl_abi.hpp"
 
+#include <algorithm>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
 #include "MatchFactory.hpp"
+#include "PointCloudFactory.hpp"
 
 namespace ssrlcv {
 namespace dist {
@@ -128,6 +140,130 @@ MatchSet generateMatchesExhaustiveSharded(Comm& c, MatchFactory<T>& matchFactory
   hipCheck(hipStreamSynchronize(c.stream), "pair exchange");
   // ---- replicated merge + KeyPoint table
   return matchFactory.assembleMatchSet(images, features, matchIndices, totalMatches);
+}
+
+// Stage C of the flow: PointCloudFactory::generateBundles + nViewTriangulate (src/PointCloudFactory.cu:832-925,568-818)
+// with the bundles range-partitioned over the ranks -- rank r takes bundles [r * per, (r + 1) * per), per = ceil(M / world),
+// the split ssrlcv_amd/dist.py bundle_range makes -- and the cloud completed by one grouped broadcast per rank (exact
+// sizes).  matchSet is replicated (every rank holds the same one after generateMatchesExhaustiveSharded); on return every
+// rank holds the whole cloud, on the cpu like upstream's triangulators return it, and the MatchSet is back on the cpu
+// (generateBundles leaves it there, :909-914).  Bundles are independent, so the cloud is the single-GPU cloud bit for bit.
+inline void bundleRange(unsigned long numBundles, int world, int rank, unsigned long& lo, unsigned long& hi) {
+  const unsigned long per = (numBundles + (unsigned long)world - 1) / (unsigned long)world;
+  lo = std::min((unsigned long)rank * per, numBundles);
+  hi = std::min(lo + per, numBundles);
+}
+inline ptr::value<Unity<float3>> nViewTriangulateSharded(Comm& c, MatchSet* matchSet, std::vector<ptr::value<Image>> images) {
+  const unsigned long M = matchSet->matches->size(), K = matchSet->keyPoints->size();
+  if (images.empty() || images.at(0)->isPushbroom) throw std::invalid_argument("nViewTriangulateSharded: projective cameras only");
+  matchSet->matches->transferMemoryTo(gpu);
+  matchSet->keyPoints->transferMemoryTo(gpu);
+  unsigned long lo = 0, hi = 0;
+  bundleRange(M, c.world, c.rank, lo, hi);
+  ptr::value<Unity<float3>> cloud(nullptr, M, gpu);
+  if (hi > lo) {
+    std::vector<ssrlcv_camera> cams(images.size());
+    for (size_t i = 0; i < images.size(); ++i) std::memcpy(&cams[i], &images[i]->camera, sizeof(ssrlcv_camera));
+    ptr::device<ssrlcv_camera> cams_d((long)cams.size());
+    HipSafeCall(ssrlcv_hip_memcpy(cams_d.get(), cams.data(), cams.size() * sizeof(ssrlcv_camera), 0));
+    // MultiMatch::index addresses the shared KeyPoint / line arrays: the range's bundles are a slice of the MultiMatch array
+    ptr::device<ssrlcv_bundle> bundles_d((long)(hi - lo));
+    ptr::device<ssrlcv_line> lines_d((long)K);
+    auto* mm = reinterpret_cast<const ssrlcv_multimatch*>(matchSet->matches->device.get()) + lo;
+    auto* kp = reinterpret_cast<const ssrlcv_keypoint*>(matchSet->keyPoints->device.get());
+    HipSafeCall(ssrlcv_hip_generate_bundles(mm, kp, (uint32_t)(hi - lo), cams_d.get(), (uint32_t)cams.size(), bundles_d.get(), lines_d.get(),
+                                            c.stream));
+    const int nview = images.size() > 2 ? 1 : 0;
+    auto* pts = reinterpret_cast<ssrlcv_float3*>(cloud->device.get()) + lo;
+    if (nview) HipSafeCall(ssrlcv_hip_triangulateN(lines_d.get(), bundles_d.get(), (uint32_t)(hi - lo), pts, nullptr, nullptr, nullptr, 1, c.stream));
+    else HipSafeCall(ssrlcv_hip_triangulate2(lines_d.get(), bundles_d.get(), (uint32_t)(hi - lo), pts, nullptr, nullptr, nullptr, c.stream));
+    hipCheck(hipStreamSynchronize(c.stream), "triangulation");  // (the device blocks above are released at scope exit)
+  }
+  if (c.world > 1) {
+    ncclCheck(ncclGroupStart(), "group");
+    for (int r = 0; r < c.world; ++r) {
+      unsigned long rlo = 0, rhi = 0;
+      bundleRange(M, c.world, r, rlo, rhi);
+      if (rhi > rlo)
+        ncclCheck(ncclBroadcast(cloud->device.get() + rlo, cloud->device.get() + rlo, (size_t)(rhi - rlo) * sizeof(float3), ncclChar, r, c.comm,
+                                c.stream), "broadcast of a cloud range");
+    }
+    ncclCheck(ncclGroupEnd(), "group");
+    hipCheck(hipStreamSynchronize(c.stream), "cloud exchange");
+  }
+  matchSet->matches->setFore(gpu);
+  matchSet->keyPoints->setFore(gpu);
+  matchSet->matches->transferMemoryTo(cpu);
+  matchSet->keyPoints->transferMemoryTo(cpu);
+  matchSet->matches->clear(gpu);
+  matchSet->keyPoints->clear(gpu);
+  cloud->transferMemoryTo(cpu);
+  cloud->clear(gpu);
+  return cloud;
+}
+
+// The two-view bundles of image pair (a, b) of an N-view MatchSet as a two-camera MatchSet on the DEVICE
+// (ssrlcv_hip_select_pair_bundles): what BundleAdjustTwoView, a two-view method, is given in the N-view flows.
+inline MatchSet selectPairBundles(MatchSet* matchSet, int imageA, int imageB) {
+  const unsigned long M = matchSet->matches->size(), K = matchSet->keyPoints->size();
+  const MemoryState mmOrigin = matchSet->matches->getMemoryState(), kpOrigin = matchSet->keyPoints->getMemoryState();
+  if (matchSet->matches->getFore() == cpu) matchSet->matches->transferMemoryTo(gpu);
+  if (matchSet->keyPoints->getFore() == cpu) matchSet->keyPoints->transferMemoryTo(gpu);
+  ptr::device<ssrlcv_multimatch> mm_d((long)M);
+  ptr::device<ssrlcv_keypoint> kp_d((long)(2 * M));
+  ptr::device<uint32_t> count_d(1);
+  const size_t wsBytes = ssrlcv_hip_select_pair_workspace_bytes((uint32_t)M);
+  ptr::device<unsigned char> ws_d((long)wsBytes);
+  HipSafeCall(ssrlcv_hip_select_pair_bundles(reinterpret_cast<const ssrlcv_multimatch*>(matchSet->matches->device.get()),
+                                             reinterpret_cast<const ssrlcv_keypoint*>(matchSet->keyPoints->device.get()), (uint32_t)M, (uint32_t)K,
+                                             imageA, imageB, mm_d.get(), kp_d.get(), count_d.get(), ws_d.get(), wsBytes, nullptr));
+  uint32_t n = 0;
+  HipSafeCall(ssrlcv_hip_memcpy(&n, count_d.get(), sizeof n, 1));
+  if (mmOrigin == cpu) matchSet->matches->clear(gpu);
+  if (kpOrigin == cpu) matchSet->keyPoints->clear(gpu);
+  MatchSet pair;
+  if (n == 0) return pair;  // (a Unity<T> cannot be empty: null members = no bundle of that pair)
+  pair.matches = ptr::value<Unity<MultiMatch>>(nullptr, (unsigned long)n, gpu);
+  pair.keyPoints = ptr::value<Unity<KeyPoint>>(nullptr, (unsigned long)(2 * n), gpu);
+  HipSafeCall(ssrlcv_hip_memcpy(pair.matches->device.get(), mm_d.get(), (size_t)n * sizeof(MultiMatch), 2));
+  HipSafeCall(ssrlcv_hip_memcpy(pair.keyPoints->device.get(), kp_d.get(), (size_t)(2 * n) * sizeof(KeyPoint), 2));
+  return pair;
+}
+
+// The K finite-difference evaluations of one BundleAdjustTwoView iteration (calculateImageGradient + calculateImageHessian,
+// src/PointCloudFactory.cu:1059-1504; PointCloudFactory::evaluateCameraSets on one GPU) over this rank's range of the
+// pair's bundles, then ncclAllReduce(sum) of the K partial sums.  pairSet: a two-camera MatchSet (selectPairBundles), on
+// the device or the host; params_host: K x 12 floats.  The float sum over ranks is not the single-GPU sum to the last bit
+// (upstream's own atomicAdd order is not defined either).
+inline std::vector<float> evaluateCameraSetsSharded(Comm& c, MatchSet* pairSet, std::vector<ptr::value<Image>> twoImages,
+                                                    const std::vector<float>& params_host, uint32_t K) {
+  std::vector<float> sums((size_t)K, 0.0f);
+  ptr::device<float> sums_d((long)K);
+  HipSafeCall(ssrlcv_hip_memset(sums_d.get(), 0, (size_t)K * sizeof(float)));
+  if (pairSet->matches != nullptr && pairSet->matches->size()) {
+    if (pairSet->matches->getFore() == cpu) pairSet->matches->transferMemoryTo(gpu);
+    if (pairSet->keyPoints->getFore() == cpu) pairSet->keyPoints->transferMemoryTo(gpu);
+    unsigned long lo = 0, hi = 0;
+    bundleRange(pairSet->matches->size(), c.world, c.rank, lo, hi);
+    if (hi > lo) {
+      std::vector<ssrlcv_camera> cams(twoImages.size());
+      for (size_t i = 0; i < twoImages.size(); ++i) std::memcpy(&cams[i], &twoImages[i]->camera, sizeof(ssrlcv_camera));
+      ptr::device<ssrlcv_camera> cams_d((long)cams.size());
+      HipSafeCall(ssrlcv_hip_memcpy(cams_d.get(), cams.data(), cams.size() * sizeof(ssrlcv_camera), 0));
+      ptr::device<float> params_d((long)params_host.size());
+      HipSafeCall(ssrlcv_hip_memcpy(params_d.get(), params_host.data(), params_host.size() * sizeof(float), 0));
+      HipSafeCall(ssrlcv_hip_ba_sweep2(reinterpret_cast<const ssrlcv_multimatch*>(pairSet->matches->device.get()) + lo,
+                                       reinterpret_cast<const ssrlcv_keypoint*>(pairSet->keyPoints->device.get()), (uint32_t)(hi - lo), cams_d.get(),
+                                       (uint32_t)cams.size(), params_d.get(), K, sums_d.get(), nullptr, 0, c.stream));
+      hipCheck(hipStreamSynchronize(c.stream), "BA sweep");
+    }
+  }
+  if (c.world > 1) {
+    ncclCheck(ncclAllReduce(sums_d.get(), sums_d.get(), (size_t)K, ncclFloat32, ncclSum, c.comm, c.stream), "all-reduce of the BA sums");
+    hipCheck(hipStreamSynchronize(c.stream), "BA all-reduce");
+  }
+  HipSafeCall(ssrlcv_hip_memcpy(sums.data(), sums_d.get(), (size_t)K * sizeof(float), 1));
+  return sums;
 }
 
 }  // namespace dist

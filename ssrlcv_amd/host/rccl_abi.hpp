@@ -16,7 +16,7 @@ typedef struct ncclComm* ncclComm_t;
 typedef struct { char internal[128]; } ncclUniqueId;  // NCCL_UNIQUE_ID_BYTES
 typedef enum { ncclSuccess = 0 } ncclResult_t;        // every other value is a failure; ncclGetErrorString names it
 typedef enum { ncclSum = 0 } ncclRedOp_t;
-typedef enum { ncclChar = 0, ncclUint32 = 3 } ncclDataType_t;
+typedef enum { ncclChar = 0, ncclUint32 = 3, ncclFloat32 = 7 } ncclDataType_t;
 ncclResult_t ncclGetUniqueId(ncclUniqueId* uniqueId);
 ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId commId, int rank);
 ncclResult_t ncclCommDestroy(ncclComm_t comm);

@@ -134,6 +134,53 @@ def dev_env(**switches):
     return env
 
 
+# ---- the C++ host mirror's test drivers (ssrlcv_amd/host/_build) and the reference's on-disk formats -------------------------
+HOST_MIRROR_BIN = os.path.join(ROOT, "ssrlcv_amd", "host", "_build", "host_mirror_test")
+SHARDED_BIN = os.path.join(ROOT, "ssrlcv_amd", "host", "_build", "sharded_match_test")
+
+
+def build_host_mirror():
+    """-> path of host_mirror_test (built against the RELEASE flavour of the library, like a deployer's program)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "ssrlcv_amd", "csrc"), "release"])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "ssrlcv_amd", "host")])
+    return HOST_MIRROR_BIN
+
+
+def host_typeinfo():
+    """typeid names / hash codes of the checkpointable types as the mirror's compiler gives them (= the reference's .uty headers)."""
+    out = subprocess.check_output([build_host_mirror(), "typeinfo"]).decode().split("\n")
+    info = {}
+    for line in out:
+        if line.strip():
+            label, name, h = line.split()
+            info[label] = (name, int(h))
+    return info
+
+
+def write_uty(path, name, hash_code, state, data):
+    """The reference's on-disk format (include/Unity.cuh:924-971)."""
+    import struct
+    raw = np.ascontiguousarray(data)
+    with open(path, "wb") as f:
+        f.write(name.encode() + b"\n")
+        f.write(struct.pack("<Q", hash_code) + b"\n")
+        f.write(struct.pack("<iQ", state, len(raw)) + b"\n")
+        f.write(raw.tobytes())
+
+
+def write_cpimg(path, image_id, size, camera):
+    """An Image checkpoint as Image::checkpoint dumps it (src/Image.cu:274-303: the 240-byte object; the mirror reads its POD
+    members at their offsets, host/Image.hpp): id @32, size @40, colorDepth @48, Camera (80 B) @56, isPushbroom @208."""
+    import struct
+    raw = bytearray(240)
+    struct.pack_into("<i", raw, 32, int(image_id))
+    struct.pack_into("<II", raw, 40, int(size[0]), int(size[1]))
+    struct.pack_into("<I", raw, 48, 1)
+    cam = np.ascontiguousarray(camera).view(np.uint8).reshape(-1)[:80]
+    raw[56:136] = cam.tobytes()
+    open(path, "wb").write(bytes(raw))
+
+
 def oracle():
     """Build (if needed) and load oracle/_build/libssrlcv_oracle.so."""
     global _ORACLE

@@ -19,29 +19,11 @@ BIN = os.path.join(H.ROOT, "ssrlcv_amd", "host", "_build", "host_mirror_test")
 
 
 def build_binary():
-    subprocess.check_call(["make", "-s", "-C", os.path.join(H.ROOT, "ssrlcv_amd", "csrc")])
-    subprocess.check_call(["make", "-s", "-C", os.path.join(H.ROOT, "ssrlcv_amd", "host")])
-    return BIN
+    return H.build_host_mirror()
 
 
-def typeinfo():
-    out = subprocess.check_output([build_binary(), "typeinfo"]).decode().split("\n")
-    info = {}
-    for line in out:
-        if line.strip():
-            label, name, h = line.split()
-            info[label] = (name, int(h))
-    return info
-
-
-def write_uty(path, name, hash_code, state, data):
-    """The reference's on-disk format (include/Unity.cuh:924-971)."""
-    raw = np.ascontiguousarray(data)
-    with open(path, "wb") as f:
-        f.write(name.encode() + b"\n")
-        f.write(struct.pack("<Q", hash_code) + b"\n")
-        f.write(struct.pack("<iQ", state, len(raw)) + b"\n")
-        f.write(raw.tobytes())
+typeinfo = H.host_typeinfo
+write_uty = H.write_uty
 
 
 def read_uty(path, dtype):
@@ -133,6 +115,11 @@ def test_sharded_generate_matches_exhaustive_in_cpp(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([exe, d, "3"], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0 and "sharded ok" in out.stdout and "sharded == single: 21177" in out.stdout, out.stdout + out.stderr
+    # round 5: stage C and the BA sweep through Distributed.hpp too -- the sharded cloud is PointCloudFactory's, which is the
+    # reference's golden 3-view cloud bit for bit; the pair's bundles come from the library pass (checked entry by entry in C++)
+    assert "sharded cloud == single: 21177 points" in out.stdout, out.stdout
+    pts, state, _ = read_uty(os.path.join(d, "200_6float3.uty"), np.dtype(("<f4", (3,))))
+    assert state == 1 and np.array_equal(pts.view(np.uint32), H.load_view("Pipeline3View")["points0"].view(np.uint32))
     gv = H.load_view("Pipeline3View")
     kp, _, _ = read_uty(os.path.join(d, "200_N6ssrlcv8KeyPointE.uty"), H.KEYPOINT)
     mm, _, _ = read_uty(os.path.join(d, "200_N6ssrlcv10MultiMatchE.uty"), H.MULTIMATCH)
