@@ -358,10 +358,14 @@ def class_api_flow_leg(imgs, cams, size, nview_ms, cloud_py, iters=3):
         seed, _ = H.load_seed_features()
         H.write_uty(os.path.join(d, "-1_%s.uty" % info["Feature"][0]), *info["Feature"], 2, seed)
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if os.environ.get("SSRLCV_BENCH_FLOW_DIAG"):
+            env["SSRLCV_FLOW_DIAG"] = "1"
         r = subprocess.run([exe, "bench-flow", d, str(len(imgs)), str(iters)], capture_output=True, text=True, timeout=900, env=env)
         if r.returncode != 0:
             return {"error": (r.stdout + r.stderr)[-400:]}
         j = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+        if os.environ.get("SSRLCV_BENCH_FLOW_DIAG"):
+            j["diag"] = [l for l in r.stderr.splitlines() if l.startswith("diag:")]
         raw = open(os.path.join(d, "300_6float3.uty"), "rb").read()
         pts = np.frombuffer(raw[len(raw) - 12 * j["points"]:], np.float32).reshape(-1, 3)
         same = cloud_py is not None and pts.shape == tuple(cloud_py.shape) and bool(np.array_equal(pts.view(np.uint32), cloud_py.view(np.uint32)))

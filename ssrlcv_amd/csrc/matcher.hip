@@ -1189,6 +1189,7 @@ int ssrlcv_hip_keypoints_from_members(const ssrlcv_uint2* members, uint32_t numM
   if (!features_host || !numFeatures_host || numImages == 0) return SSRLCV_ERR_INVALID_ARG;
   if (numMembers && (!members || !keyPoints)) return SSRLCV_ERR_INVALID_ARG;
   if (numMembers == 0) return SSRLCV_OK;
+  if (reinterpret_cast<size_t>(keyPoints) & 15) return SSRLCV_ERR_INVALID_ARG;  // elements are written with one 16-byte store
   for (uint32_t base = 0; base < numImages; base += (uint32_t)kMaxGatherImages) {
     GatherArgs a;
     for (uint32_t v = 0; v < (uint32_t)kMaxGatherImages; ++v) {

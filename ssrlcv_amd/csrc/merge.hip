@@ -136,8 +136,14 @@ __global__ __launch_bounds__(256) void k_merge_fill(Lists L, const ssrlcv_uint2_
 // read the number of unresolved seeds back to the host after every mark (13-16 stream synchronisations per call); now
 // the rounds are phases of one kernel separated by a grid-wide barrier, and the call is asynchronous.
 //
-// The grid is sized to be co-resident (launched cooperatively: the runtime refuses a grid that is not), every block
-// passes every barrier -- the loop bounds and the `left` test are grid-uniform -- so the grid always drains.
+// The grid is at most ONE block per CU (256 threads, no LDS to speak of: far inside what a CU admits), so every block
+// becomes resident -- at once on an idle chip, as soon as other kernels' blocks retire otherwise (a waiting block sleeps,
+// it holds nothing another kernel needs) -- and every block passes every barrier: the loop bounds and the `left` test are
+// grid-uniform, so the grid always drains.  A PLAIN launch since round 5: hipLaunchCooperativeKernel buys only the
+// launch-time check of the grid against the occupancy query (MI355X_MICROARCH.md, coop-launch), and on this driver stack
+// a process that has made one cooperative launch slows every OTHER process on the same GPU that has made one too -- two
+// such processes are time-sliced against each other: the C++ flow ran 45 ms alone and 98 ms as a child of a Python process
+// that had merged once (tools/flow_diag.py, profiles/r05_coop_launch.txt).
 // Barrier = __threadfence (release: this thread's stores and atomics are visible device-wide, across the XCDs' L2s),
 // one atomicAdd per block on a monotone counter, spin until it reaches (barriers so far) x gridDim.x, __threadfence
 // (acquire: drop what this CU cached before the barrier).
@@ -423,7 +429,7 @@ int ssrlcv_hip_merge_matches(uint32_t numImages, const uint32_t* numFeatures_hos
   SSRLCV_HIP_TRY(svs::exclusive_scan<8>((const uint32_t*)L.len, start, numLists + 1, ws + y.scanTmp, st));
   if (total) hipLaunchKernelGGL(k_merge_fill, dim3(eb), dim3(256), 0, st, L, pairs, total, (const uint32_t*)mask, (U2*)(ws + y.entries));
 
-  // ---- the walk, image by image (only images 0..V-3 seed multi-matches, :969), in one persistent cooperative launch
+  // ---- the walk, image by image (only images 0..V-3 seed multi-matches, :969), in one persistent launch (at most one block per CU)
   if (numSeeds) {
     static int s_blocks = 0;  // co-resident blocks of k_merge_walk on this device (all devices of a node are alike)
     if (s_blocks == 0) {
@@ -442,8 +448,7 @@ int ssrlcv_hip_merge_matches(uint32_t numImages, const uint32_t* numFeatures_hos
     ctl.unresolved = (uint32_t*)(ws + y.ctl + kBarrierBytes);
     ctl.counts = counts;
     ctl.bad = bad;
-    void* args[] = {&L, &numLists, &state, &outcome, &minReader, &minWriter, &good, &memberCnt, &ctl};
-    SSRLCV_HIP_TRY(hipLaunchCooperativeKernel((const void*)k_merge_walk, dim3(blocks), dim3(256), args, 0, st));
+    hipLaunchKernelGGL(k_merge_walk, dim3(blocks), dim3(256), 0, st, L, numLists, state, outcome, minReader, minWriter, good, memberCnt, ctl);
   }
   // ---- output in (image, feature) order
   if (numSeeds) {

@@ -85,6 +85,33 @@ static int bench_flow(dist::Comm& comm, const std::string& dir, int views, int i
   auto seed = ptr::value<Unity<Feature<SIFT_Descriptor>>>(cp_path<Feature<SIFT_Descriptor>>(dir, -1));
   MatchFactory<SIFT_Descriptor> matchFactory(0.6f, 200.0f * 200.0f);
   matchFactory.setSeedFeatures(seed);
+  if (std::getenv("SSRLCV_FLOW_DIAG")) {  // where a synchronous per-image call spends its time on this box
+    auto tick = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
+    const size_t n = images[0]->pixels->size();
+    ptr::device<unsigned char> d((long)n);
+    for (int rep = 0; rep < 3; ++rep) {
+      auto a = clk::now();
+      HipSafeCall(ssrlcv_hip_memcpy(d.get(), images[0]->pixels->host.get(), n, 0));
+      const double h2d = tick(a);
+      a = clk::now();
+      HipSafeCall(ssrlcv_hip_memcpy(images[0]->pixels->host.get(), d.get(), n, 1));
+      const double d2h = tick(a);
+      a = clk::now();
+      auto f = featureFactory.generateFeatures(images[0], false, 2, 0.8);
+      const double gen = tick(a);
+      a = clk::now();
+      images[0]->pixels->setMemoryState(gpu);
+      const double up = tick(a);
+      a = clk::now();
+      auto g = featureFactory.generateFeatures(images[0], false, 2, 0.8);
+      const double genDev = tick(a);
+      a = clk::now();
+      images[0]->pixels->setMemoryState(cpu);
+      const double down = tick(a);
+      std::fprintf(stderr, "diag: memcpy %zu B pageable H2D %.3f ms, D2H %.3f ms; generateFeatures from cpu-state pixels %.3f ms, from gpu-state %.3f ms; "
+                   "setMemoryState(gpu) %.3f ms, (cpu) %.3f ms; %lu features\n", n, h2d, d2h, gen, genDev, up, down, f->size());
+    }
+  }
   double ms[5] = {0, 0, 0, 0, 0};
   unsigned long nMatches = 0, nPair = 0;
   ptr::value<Unity<float3>> cloud;
@@ -240,7 +267,8 @@ int main(int argc, char** argv) {
         }
         if (world == 1) {  // one rank: the sweep's sums are the single-GPU sums bit for bit (the same launch over the same bundles)
           std::vector<float> want = pcf.evaluateCameraSets(&hostSet, two, params, 612);
-          for (int k = 0; k < 612; ++k) CHECK(want[(size_t)k] == sums[(size_t)k]);
+          // (the launch adds its blocks' partial sums with float atomics: the order, hence the last bits, vary from run to run)
+          for (int k = 0; k < 612; ++k) CHECK(std::fabs(want[(size_t)k] - sums[(size_t)k]) <= 1e-4f * std::fabs(want[(size_t)k]));
         }
         cloud->checkpoint(200, dir + "/");
         std::printf("sharded cloud == single: %lu points; pair (0,1): %lu bundles, f(base) = %g\n", cloud->size(), pairSet.matches->size(), sums[24 + 2]);
