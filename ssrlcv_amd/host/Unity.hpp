@@ -10,6 +10,7 @@
 // hands device function pointers to thrust); unified/pinned states beyond `pinned` host allocation are not supported
 // (upstream: "only types null,cpu,gpu,both are supported right now", :39).
 #pragma once
+#include <type_traits>
 #include <algorithm>
 #include <cstring>
 #include <fstream>
@@ -210,6 +211,10 @@ class Unity {
     if (s == gpu || (s == both && device != nullptr)) {
       if (s == both && host != nullptr) {
         h2d();
+      } else if (std::is_trivially_default_constructible<T>::value) {
+        // value-initialised PODs are zero bytes: the same device content without building the array on the host and
+        // copying it over (6 MB per image pair for a uint2_pair list of 4 x 10^5 queries, every matcher call)
+        HipSafeCall(ssrlcv_hip_memset(device.get(), 0, bytes()));
       } else {
         T* z = new T[numElements]();
         HipSafeCall(ssrlcv_hip_memcpy(device.get(), z, bytes(), 0));
