@@ -1708,6 +1708,10 @@ inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 }  // namespace
 
 namespace svp {
+int stream_priority_mode() {
+  static const int m = svdev::env("SSRLCV_PRIO") ? atoi(svdev::env("SSRLCV_PRIO")) : 0;
+  return m;
+}
 PlanAsync* plan_async(const ssrlcv_sift_plan* plan) {
   static std::mutex mu;
   std::lock_guard<std::mutex> lock(mu);
@@ -1729,10 +1733,14 @@ PlanAsync* plan_async(const ssrlcv_sift_plan* plan) {
           int least = 0, greatest = 0;
           (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
           const int tablePrio = svdev::env("SSRLCV_SIDE_LOW_PRIORITY") ? least : 0;
-          ok = hipStreamCreateWithFlags(&pr.chain, hipStreamNonBlocking) == hipSuccess &&
+          // SSRLCV_PRIO (developer build): 1 = the gradient tables of describe on their own LOW-priority stream, so that the list
+          // chains' short launches get the CU slots the tables' thousands of short-lived blocks keep freeing; 2 = and the
+          // chains' side streams at HIGH priority (see svp::stream_priority_mode)
+          const int prioMode = svp::stream_priority_mode();
+          ok = hipStreamCreateWithPriority(&pr.chain, hipStreamNonBlocking, (prioMode & 2) ? greatest : 0) == hipSuccess &&
                hipStreamCreateWithPriority(&pr.table, hipStreamNonBlocking, tablePrio) == hipSuccess &&
-               hipStreamCreateWithFlags(&pr.chain2, hipStreamNonBlocking) == hipSuccess &&
-               hipStreamCreateWithFlags(&pr.polar, hipStreamNonBlocking) == hipSuccess;
+               hipStreamCreateWithPriority(&pr.chain2, hipStreamNonBlocking, (prioMode & 2) ? greatest : 0) == hipSuccess &&
+               hipStreamCreateWithPriority(&pr.polar, hipStreamNonBlocking, (prioMode & 1) ? least : 0) == hipSuccess;
           if (ok) it = pool.emplace(dev, pr).first;
         }
         if (ok) {

@@ -136,6 +136,7 @@ struct ssrlcv_sift_plan {
 namespace svp {
 // -> the plan's side streams, or nullptr when the calls must run serially on the caller's stream
 PlanAsync* plan_async(const ssrlcv_sift_plan* plan);
+int stream_priority_mode();  // developer build: SSRLCV_PRIO (0 in the release build)
 // k_polar (keypoints.hip) for ONE octave on `st`: the gradient tables of its DoG levels 1..3
 void launch_polar_octave(const ssrlcv_sift_plan* plan, char* ws, int octave, hipStream_t st);
 }  // namespace svp
