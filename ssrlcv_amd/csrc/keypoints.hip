@@ -1363,396 +1363,6 @@ int stage_noise_edges_window(const ListCtx& c) {  // the three of them with one 
   return discard_flagged(c);
 }
 
-// ---- the list chains of ALL octaves in five launches (round 5) -------------------------------------------------------------
-// Stages 0-5 of a full run -- searchForExtrema's compaction with the first removeNoise folded in, refineExtremaLocation with
-// its discard, stable sort and blur re-scan, then removeNoise + removeEdges + checkKeyPoints with their discard -- were ~16
-// launches per octave (count -> scan -> scatter partitions, bookkeeping kernels) on three streams beside the gradient tables.
-// Every one of those launches waits for CU slots behind the tables' blocks, so the chains took ~1.0 ms of a 4096^2 image where
-// their kernels add up to 0.2 (profiles/r05_timeline_*.txt).  Here the four octaves share each launch, a partition is ONE pass
-// (decoupled look-back, scan_lookback.h) because the class totals it needs are counted by the launch before it, and the
-// bookkeeping runs in a thread of the launch that produced its inputs:
-//   k_chain_count   per (octave, DoG level) extrema counts of the flag bytes (+ zeroes the look-back descriptors)
-//   k_chain_emit    fillExtrema into list A at [level base + rank]; thread 0 of an octave: state reset + book_extrema
-//   k_chain_refine  refineLocation in place; kept key points counted per old segment and per new blur
-//   k_chain_sort    kept key points to list B at [blur base + rank] (= discardExtrema + stable_sort by blur, order kept);
-//                   the octave's last block: book_discard + book_rescan
-//   k_chain_final   the three tests on the segment's DoG level, survivors compacted into list A; last block: book_discard
-// The lists, blur indices and every key point are those of the staged path (which stays: stop stages below 5, the
-// stage-at-a-time entry point); `segment_of`, `refine_one`, `edge_response_above` and the book_* functions are shared.
-constexpr int kChainSortItems = 8;
-struct ChainCtl {               // per octave, zeroed before k_chain_count (128 bytes)
-  uint32_t ext[4];              // extrema per DoG level 1..3 (flag bit set); [3] unused
-  uint32_t oldKept[svp::kDog];  // after refinement: kept key points per OLD segment (book_discard's totals)
-  uint32_t blurKept[svp::kDog]; // ... per NEW blur value (book_rescan's totals, and the sort's class bases)
-  uint32_t finKept[svp::kDog];  // after the three tests: kept per segment
-  uint32_t sortDone, finDone;   // blocks of the octave that have left k_chain_sort / k_chain_final
-  uint32_t pad[32 - 4 - 3 * svp::kDog - 2];
-};
-static_assert(sizeof(ChainCtl) == 128, "four of them behind the sampling groups' control words");
-struct ChainOct {
-  LevelSet L;
-  OctaveState* st;
-  const uint8_t* flags;
-  ssrlcv_sskeypoint *A, *B;
-  ChainCtl* ctl;
-  svs::TileScan<3> tsExt;
-  svs::TileScan<svp::kDog> tsSort;
-  svs::TileScan<1> tsFin;
-  uint32_t P, cap, scanWords;   // scanWords: 32-bit words of the three descriptor areas (contiguous from tsExt.desc)
-  int octaveId;
-  float sigma[4];               // sigma of blur 0..3 (fillExtrema stores that of its level; refinement starts from sigma[0])
-  float mult, pixelWidth;
-};
-struct ChainArgs {
-  ChainOct o[svp::kOctaves];
-  uint32_t start[svp::kOctaves + 1];  // this launch's block ranges: octave k owns the blocks start[k] .. start[k + 1] - 1
-  int flagShift;
-  float noiseThr, edgeThr, lambdaD;
-};
-__device__ __forceinline__ int chain_octave(const ChainArgs& a) {
-  int o = 0;
-#pragma unroll
-  for (int k = 1; k < svp::kOctaves; ++k)
-    if (blockIdx.x >= a.start[k]) o = k;  // block-uniform
-  return o;
-}
-constexpr uint32_t kChainFlagTile = svc::kFlagRun * svc::kWavesPerBlock;  // flag bytes per block: 16 384
-
-__global__ __launch_bounds__(256) void k_chain_count(ChainArgs a) {
-  const int o = chain_octave(a);
-  const ChainOct& c = a.o[o];
-  const uint32_t blk = blockIdx.x - a.start[o], nblk = a.start[o + 1] - a.start[o];
-  // the look-back descriptors and tile counters of this image's three passes over the octave
-  uint32_t* scan = reinterpret_cast<uint32_t*>(c.tsExt.desc);
-  for (uint32_t i = blk * 256 + threadIdx.x; i < c.scanWords; i += nblk * 256) scan[i] = 0u;
-  const unsigned lane = threadIdx.x & 63;
-  __shared__ uint32_t s_cnt[3];
-  if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
-  __syncthreads();
-  // a few hundred blocks per octave walk its tiles: the three totals are same-address atomics (~50 ns each, serialised)
-  uint32_t cnt[3] = {0, 0, 0};
-  for (uint32_t tile = blk; tile < c.tsExt.numTiles; tile += nblk) {
-    const uint32_t base = tile * kChainFlagTile + (threadIdx.x >> 6) * (uint32_t)svc::kFlagRun;
-    unsigned long long m[3];
-    svc::flag_masks<3>(c.flags, base, c.P, lane, a.flagShift, m);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) cnt[k] += (uint32_t)__popcll(m[k]);
-  }
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const uint32_t n = svs::wave_total(cnt[k]);
-    if (lane == 0 && n) atomicAdd(&s_cnt[k], n);
-  }
-  __syncthreads();
-  if (threadIdx.x < 3 && s_cnt[threadIdx.x]) atomicAdd(&c.ctl->ext[threadIdx.x], s_cnt[threadIdx.x]);
-}
-
-__global__ __launch_bounds__(256) void k_chain_emit(ChainArgs a) {
-  const int o = chain_octave(a);
-  const ChainOct& c = a.o[o];
-  const uint32_t c1 = c.ctl->ext[0], c2 = c.ctl->ext[1], c3 = c.ctl->ext[2];
-  if (blockIdx.x == a.start[o] && threadIdx.x == 0) {  // k_state_reset + book_extrema (nothing of this launch reads the state)
-    OctaveState* st = c.st;
-    for (int i = 0; i < svp::kDog; ++i) { st->idx[i] = 0; st->stale[i] = 0; }
-    st->n = 0;
-    st->hasExtrema = 0;
-    st->overflow = 0;
-    const uint32_t totals[4] = {c1, c2, c3, c1 + c2 + c3};
-    book_extrema(st, totals, c.cap);
-  }
-  const uint32_t levelBase[3] = {0u, c1, c1 + c2};
-  const unsigned lane = threadIdx.x & 63;
-  const int W = c.L.w;
-  for (uint32_t tile = svs::next_tile(c.tsExt.counter); tile < c.tsExt.numTiles; tile = svs::next_tile(c.tsExt.counter)) {
-    const uint32_t base = tile * kChainFlagTile + (threadIdx.x >> 6) * (uint32_t)svc::kFlagRun;
-    unsigned long long m[3];
-    svc::flag_masks<3>(c.flags, base, c.P, lane, a.flagShift, m);
-    uint32_t mine[3], excl[3], total[3], prefix[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) mine[k] = (uint32_t)__popcll(m[k]);
-    svs::block_exclusive<3>(mine, excl, total);
-    svs::tile_prefix<3>(c.tsExt, tile, total, prefix);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      uint32_t d = levelBase[k] + prefix[k] + excl[k];
-      unsigned long long bits = m[k];
-      if (bits == 0ull) continue;
-      const DogView D = dog_view(c.L, k + 1);
-      while (bits != 0ull) {
-        const int j = __ffsll((long long)bits) - 1;
-        bits &= bits - 1ull;
-        const uint32_t p = base + 64u * lane + (uint32_t)j;
-        if (d < c.cap) {
-          ssrlcv_sskeypoint kp;  // fillExtrema (src/FeatureFactory.cu:883-890)
-          kp.octave = c.octaveId;
-          kp.blur = k + 1;
-          kp.loc.x = (float)(p % (uint32_t)W);
-          kp.loc.y = (float)(p / (uint32_t)W);
-          kp.intensity = D.raw(p);
-          kp.sigma = c.sigma[k + 1];
-          kp.theta = -1.0f;
-          kp.discard = 0;
-          c.A[d] = kp;
-        }
-        ++d;
-      }
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void k_chain_refine(ChainArgs a) {
-  const int o = chain_octave(a);
-  const ChainOct& c = a.o[o];
-  const OctaveState* st = c.st;
-  const int n = st->hasExtrema ? st->n : 0;
-  const uint32_t blk = blockIdx.x - a.start[o], nblk = a.start[o + 1] - a.start[o];
-  __shared__ uint32_t s_cnt[2 * svp::kDog];
-  if (threadIdx.x < 2 * svp::kDog) s_cnt[threadIdx.x] = 0;
-  __syncthreads();
-  const PlanSource src{c.L};
-  uint32_t old[svp::kDog], blr[svp::kDog];
-#pragma unroll
-  for (int k = 0; k < svp::kDog; ++k) old[k] = blr[k] = 0;
-  for (int gi = (int)(blk * 256 + threadIdx.x); gi < n; gi += (int)(nblk * 256)) {
-    ssrlcv_sskeypoint kp = c.A[gi];
-    refine_one(kp, c.L.w, c.L.h, svp::kDog, c.sigma[0], c.mult, src);
-    c.A[gi] = kp;
-    if (!kp.discard) {
-      const int seg = segment_of(st, gi);
-#pragma unroll
-      for (int k = 0; k < svp::kDog; ++k) {
-        old[k] += seg == k ? 1u : 0u;
-        blr[k] += kp.blur == k ? 1u : 0u;
-      }
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < svp::kDog; ++k) {
-    const uint32_t so = svs::wave_total(old[k]), sb = svs::wave_total(blr[k]);
-    if ((threadIdx.x & 63) == 0) {
-      if (so) atomicAdd(&s_cnt[k], so);
-      if (sb) atomicAdd(&s_cnt[svp::kDog + k], sb);
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < svp::kDog && s_cnt[threadIdx.x]) atomicAdd(&c.ctl->oldKept[threadIdx.x], s_cnt[threadIdx.x]);
-  else if (threadIdx.x >= svp::kDog && threadIdx.x < 2 * svp::kDog && s_cnt[threadIdx.x]) atomicAdd(&c.ctl->blurKept[threadIdx.x - svp::kDog], s_cnt[threadIdx.x]);
-}
-
-// the octave's block that leaves last runs `fn` in one thread (every other block has then finished reading the state)
-template <typename Fn>
-__device__ __forceinline__ void chain_last_block(uint32_t* done, uint32_t blocks, Fn fn) {
-  __shared__ bool s_last;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    s_last = atomicAdd(done, 1u) == blocks - 1;
-  }
-  __syncthreads();
-  if (s_last && threadIdx.x == 0) {
-    __threadfence();
-    fn();
-  }
-}
-
-__global__ __launch_bounds__(svs::kThreads) void k_chain_sort(ChainArgs a) {
-  constexpr uint32_t kTile = svs::kThreads * kChainSortItems;
-  const int o = chain_octave(a);
-  const ChainOct& c = a.o[o];
-  OctaveState* st = c.st;
-  const uint32_t n = st->hasExtrema && st->n > 0 ? (uint32_t)st->n : 0u;  // read before the last block rewrites it
-  const uint32_t tiles = (n + kTile - 1) / kTile;
-  uint32_t classBase[svp::kDog];
-  {
-    uint32_t run = 0;
-#pragma unroll
-    for (int k = 0; k < svp::kDog; ++k) { classBase[k] = run; run += c.ctl->blurKept[k]; }
-  }
-  for (uint32_t tile = svs::next_tile(c.tsSort.counter); tile < tiles; tile = svs::next_tile(c.tsSort.counter)) {
-    const uint32_t base = tile * kTile + threadIdx.x * kChainSortItems;
-    int cls[kChainSortItems];
-    uint32_t mine[svp::kDog];
-#pragma unroll
-    for (int k = 0; k < svp::kDog; ++k) mine[k] = 0;
-#pragma unroll
-    for (int j = 0; j < kChainSortItems; ++j) {
-      cls[j] = -1;
-      if (base + j < n) {
-        const ssrlcv_sskeypoint& kp = c.A[base + j];
-        const int b = kp.blur;
-        if (!kp.discard && b >= 0 && b < svp::kDog) cls[j] = b;
-      }
-#pragma unroll
-      for (int k = 0; k < svp::kDog; ++k) mine[k] += cls[j] == k ? 1u : 0u;
-    }
-    uint32_t excl[svp::kDog], total[svp::kDog], prefix[svp::kDog];
-    svs::block_exclusive<svp::kDog>(mine, excl, total);
-    svs::tile_prefix<svp::kDog>(c.tsSort, tile, total, prefix);
-    uint32_t at[svp::kDog];
-#pragma unroll
-    for (int k = 0; k < svp::kDog; ++k) at[k] = classBase[k] + prefix[k] + excl[k];
-#pragma unroll
-    for (int j = 0; j < kChainSortItems; ++j) {
-      if (cls[j] < 0) continue;
-      uint32_t d = 0;
-#pragma unroll
-      for (int k = 0; k < svp::kDog; ++k)
-        if (cls[j] == k) d = at[k]++;
-      c.B[d] = c.A[base + j];
-    }
-  }
-  const ChainCtl* ctl = c.ctl;
-  chain_last_block(&c.ctl->sortDone, a.start[o + 1] - a.start[o], [&]() {
-    uint32_t oldKept[svp::kDog], blurKept[svp::kDog];
-    for (int k = 0; k < svp::kDog; ++k) {
-      oldKept[k] = __hip_atomic_load(&ctl->oldKept[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      blurKept[k] = __hip_atomic_load(&ctl->blurKept[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    book_discard(st, oldKept);   // discardExtrema's bookkeeping (:161-215) ...
-    book_rescan(st, blurKept);   // ... then the stable_sort's re-scan of the blur boundaries (:249-259)
-  });
-}
-
-__global__ __launch_bounds__(svs::kThreads) void k_chain_final(ChainArgs a) {
-  constexpr uint32_t kTile = svs::kThreads * kChainSortItems;
-  const int o = chain_octave(a);
-  const ChainOct& c = a.o[o];
-  OctaveState* st = c.st;
-  const uint32_t n = st->hasExtrema && st->n > 0 ? (uint32_t)st->n : 0u;
-  const uint32_t tiles = (n + kTile - 1) / kTile;
-  __shared__ uint32_t s_seg[svp::kDog];
-  if (threadIdx.x < svp::kDog) s_seg[threadIdx.x] = 0;
-  uint32_t segKept[svp::kDog];
-#pragma unroll
-  for (int k = 0; k < svp::kDog; ++k) segKept[k] = 0;
-  for (uint32_t tile = svs::next_tile(c.tsFin.counter); tile < tiles; tile = svs::next_tile(c.tsFin.counter)) {
-    const uint32_t base = tile * kTile + threadIdx.x * kChainSortItems;
-    bool keep[kChainSortItems];
-    uint32_t mine[1] = {0};
-#pragma unroll
-    for (int j = 0; j < kChainSortItems; ++j) {
-      keep[j] = false;
-      if (base + j < n) {
-        // removeNoise + removeEdges (on the level of the key point's SEGMENT) + checkKeyPoints: k_flag_noise_edges_window's tests
-        const ssrlcv_sskeypoint kp = c.B[base + j];
-        const int seg = segment_of(st, (int)(base + j));
-        bool drop = fabsf(kp.intensity) < a.noiseThr;
-        drop = drop || edge_response_above(dog_view(c.L, seg), kp, c.L.w, a.edgeThr);
-        const float ww = kp.sigma * a.lambdaD / c.pixelWidth;
-        drop = drop || (kp.loc.x - ww) < 0.0f || (kp.loc.y - ww) < 0.0f || (kp.loc.x + ww) >= (unsigned)(c.L.w - 1) ||
-               (kp.loc.y + ww) >= (unsigned)(c.L.h - 1);
-        keep[j] = !drop;
-        if (keep[j]) {
-#pragma unroll
-          for (int k = 0; k < svp::kDog; ++k) segKept[k] += seg == k ? 1u : 0u;
-        }
-      }
-      mine[0] += keep[j] ? 1u : 0u;
-    }
-    uint32_t excl[1], total[1], prefix[1];
-    svs::block_exclusive<1>(mine, excl, total);
-    svs::tile_prefix<1>(c.tsFin, tile, total, prefix);
-    uint32_t at = prefix[0] + excl[0];
-#pragma unroll
-    for (int j = 0; j < kChainSortItems; ++j) {
-      if (!keep[j]) continue;
-      ssrlcv_sskeypoint kp = c.B[base + j];
-      kp.discard = 0;
-      c.A[at++] = kp;
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < svp::kDog; ++k) {
-    const uint32_t sk = svs::wave_total(segKept[k]);
-    if ((threadIdx.x & 63) == 0 && sk) atomicAdd(&s_seg[k], sk);
-  }
-  __syncthreads();
-  if (threadIdx.x < svp::kDog && s_seg[threadIdx.x]) atomicAdd(&c.ctl->finKept[threadIdx.x], s_seg[threadIdx.x]);
-  const ChainCtl* ctl = c.ctl;
-  chain_last_block(&c.ctl->finDone, a.start[o + 1] - a.start[o], [&]() {
-    uint32_t kept[svp::kDog];
-    for (int k = 0; k < svp::kDog; ++k) kept[k] = __hip_atomic_load(&ctl->finKept[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    book_discard(st, kept);
-  });
-}
-
-inline ChainCtl* chain_ctl(const ssrlcv_sift_plan* plan, char* ws, int o) { return (ChainCtl*)(ws + plan->off_groups + 2048 + 512) + o; }
-
-// the fused chain needs 64-byte flag runs (flag_masks) and room for its descriptors in every octave's partition scratch
-bool chain_fused_ok(const ssrlcv_sift_plan* plan, char* ws) {
-  for (int o = 0; o < svp::kOctaves; ++o) {
-    const svp::OctavePlan& oc = plan->oct[o];
-    const size_t P = (size_t)oc.w * oc.h;
-    if (P % 64u != 0u || (reinterpret_cast<size_t>(ws + oc.off_flags) & 15u) != 0u || P >= ((size_t)1 << 32)) return false;
-    const uint32_t tE = (uint32_t)((P + kChainFlagTile - 1) / kChainFlagTile), tL = (oc.cap + svs::kThreads * kChainSortItems - 1) / (svs::kThreads * kChainSortItems);
-    const size_t need = svs::workspace_bytes<3>(tE) + svs::workspace_bytes<svp::kDog>(tL) + svs::workspace_bytes<1>(tL);
-    const size_t words = (size_t)3 * 4 * ((P + 8191) / 8192) + 16 + (size_t)svp::kDog * 4 * (((size_t)oc.cap * svp::kMaxOrient + 2047) / 2048) + 16;
-    if (need > words * 4) return false;
-  }
-  return true;
-}
-
-int stage_chain_fused(const ssrlcv_sift_plan* plan, char* ws, hipStream_t st) {
-  ChainArgs a;
-  a.flagShift = svp::kNoiseFlagShift;  // the first removeNoise rides in the flag bits (see stage_extrema)
-  a.noiseThr = svp::kNoiseThreshold;
-  a.edgeThr = svp::kEdgeThreshold;
-  a.lambdaD = plan->params.descriptorContribWidth;
-  uint32_t flagBlocks[svp::kOctaves], listBlocks[svp::kOctaves], tileBlocks[svp::kOctaves];
-  static const uint32_t chainBlocks = svdev::env("SSRLCV_CHAIN_BLOCKS") ? (uint32_t)atoi(svdev::env("SSRLCV_CHAIN_BLOCKS")) : 768u;
-  for (int o = 0; o < svp::kOctaves; ++o) {
-    const svp::OctavePlan& oc = plan->oct[o];
-    ChainOct& c = a.o[o];
-    c.L = make_levels(plan, ws, o);
-    c.st = (OctaveState*)(ws + plan->off_state) + o;
-    c.flags = (const uint8_t*)(ws + oc.off_flags);
-    c.A = (ssrlcv_sskeypoint*)(ws + oc.off_kpA);
-    c.B = (ssrlcv_sskeypoint*)(ws + oc.off_kpB);
-    c.ctl = chain_ctl(plan, ws, o);
-    c.P = oc.w * oc.h;
-    c.cap = oc.cap;
-    c.octaveId = o;
-    for (int b = 0; b < 4; ++b) c.sigma[b] = oc.sigma[b];
-    c.mult = oc.sigma[1] / oc.sigma[0];
-    c.pixelWidth = oc.pixelWidth;
-    const uint32_t tE = (c.P + kChainFlagTile - 1) / kChainFlagTile;
-    const uint32_t tL = (oc.cap + svs::kThreads * kChainSortItems - 1) / (svs::kThreads * kChainSortItems);
-    char* part = ws + oc.off_part;
-    c.tsExt = svs::make_tile_scan<3>(part, tE);
-    c.tsSort = svs::make_tile_scan<svp::kDog>(part + svs::workspace_bytes<3>(tE), tL);
-    c.tsFin = svs::make_tile_scan<1>(part + svs::workspace_bytes<3>(tE) + svs::workspace_bytes<svp::kDog>(tL), tL);
-    c.scanWords = (uint32_t)((svs::workspace_bytes<3>(tE) + svs::workspace_bytes<svp::kDog>(tL) + svs::workspace_bytes<1>(tL)) / 4);
-    flagBlocks[o] = tE;
-    // enough blocks to keep the gathers of refinement and of the edge test in flight (with 128-256 blocks per octave these two
-    // kernels took 275 / 397 us in the flow); a block's counters are one same-address atomic each at its end
-    listBlocks[o] = list_blocks(oc.cap) < chainBlocks ? list_blocks(oc.cap) : chainBlocks;
-    tileBlocks[o] = tL < chainBlocks ? tL : chainBlocks;  // persistent over the tiles of the live list
-    plan->listInB[o] = 0;  // extrema into A, refined in place, sorted into B, the survivors back into A
-  }
-  auto ranges = [&](const uint32_t* blocks) {
-    uint32_t pos = 0;
-    for (int o = 0; o < svp::kOctaves; ++o) { a.start[o] = pos; pos += blocks[o]; }
-    a.start[svp::kOctaves] = pos;
-    return pos;
-  };
-  SSRLCV_HIP_TRY(hipMemsetAsync(chain_ctl(plan, ws, 0), 0, sizeof(ChainCtl) * svp::kOctaves, st));
-  uint32_t countBlocks[svp::kOctaves];
-  for (int o = 0; o < svp::kOctaves; ++o) countBlocks[o] = flagBlocks[o] < 512u ? flagBlocks[o] : 512u;
-  uint32_t grid = ranges(countBlocks);
-  hipLaunchKernelGGL(k_chain_count, dim3(grid), dim3(256), 0, st, a);
-  uint32_t emitBlocks[svp::kOctaves];
-  for (int o = 0; o < svp::kOctaves; ++o) emitBlocks[o] = flagBlocks[o] < 2048u ? flagBlocks[o] : 2048u;
-  grid = ranges(emitBlocks);
-  hipLaunchKernelGGL(k_chain_emit, dim3(grid), dim3(256), 0, st, a);
-  grid = ranges(listBlocks);
-  hipLaunchKernelGGL(k_chain_refine, dim3(grid), dim3(256), 0, st, a);
-  grid = ranges(tileBlocks);
-  hipLaunchKernelGGL(k_chain_sort, dim3(grid), dim3(svs::kThreads), 0, st, a);
-  hipLaunchKernelGGL(k_chain_final, dim3(grid), dim3(svs::kThreads), 0, st, a);
-  return SSRLCV_OK;
-}
-
 OctaveSet make_set(const ssrlcv_sift_plan* plan, char* ws, uint32_t* unitBlocks) {
   OctaveSet set;
   uint32_t blocks = 20;  // upper bound of the orientation kernel's grid: one block per 64 key points of a range
@@ -2080,15 +1690,13 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
     if ((svp::stream_priority_mode() & 1)) SSRLCV_HIP_TRY(hipStreamWaitEvent(as->polar, as->fork, 0));
     if (stop >= 6 && !plan->polarInFlight) launch_polar(plan, ws, (svp::stream_priority_mode() & 1) ? as->polar : as->table);
   }
-  // a full run takes the fused chain (all octaves in five launches on the caller's stream); runs that stop inside the chain, and
-  // sizes its byte-flag pass does not take, the staged one
-  static const bool stagedChain = svdev::env("SSRLCV_CHAIN_STAGED") != nullptr;
-  const bool fusedChain = stop >= 5 && !stagedChain && chain_fused_ok(plan, ws);
-  if (fusedChain) {
-    int rc = stage_chain_fused(plan, ws, caller);
-    if (rc) return rc;
-  }
-  for (int o = 0; o < svp::kOctaves && !fusedChain; ++o) {
+  // (Round 5 built the chains of all four octaves as five launches on one stream -- every partition one decoupled look-back
+  // pass, its class totals counted by the launch before it, the bookkeeping in a thread of the launch that produced its inputs;
+  // exact, and slower: 0.58-0.73 ms alone on a 4096^2 image against 0.43 for the staged chains below, whose wave-granular
+  // count -> scan -> scatter kernels keep a key point per thread in flight where a look-back tile serialises several per
+  // thread behind block-wide scans.  Removed; it is commit "Experiment: the list chains of all octaves ..." in the history,
+  // numbers in profiles/r05_schedule_ab.txt.)
+  for (int o = 0; o < svp::kOctaves; ++o) {
     // octave 1's chain on one side stream, those of octaves 2 and 3 one after the other on a second (round 3: the three
     // short chains in a row on one stream, ~25 launch-bound kernels each, ended after the polar tables)
     const ListCtx c = make_ctx(plan, ws, o, !as || o == 0 ? caller : (o == 1 ? as->chain : as->chain2));

@@ -387,7 +387,6 @@ print("FEATURES OK")
     {"SSRLCV_EARLY_POLAR": "1"},                                           # gradient tables started from inside build_dog (fused extract)
     {"SSRLCV_EARLY_POLAR": "1", "SSRLCV_SAMPLING_PIPELINED": "1"},
     {"SSRLCV_PHASED": "1"}, {"SSRLCV_PHASED": "2"},                        # build_dog: the octave chain on one stream, levels 4-5 + DoG passes beside it
-    {"SSRLCV_CHAIN_STAGED": "1"},                                          # the list chains as ~16 launches per octave on three streams (rounds 1-4) instead of the fused five
 ], ids=lambda v: "+".join(k.replace("SSRLCV_", "") + "=" + x for k, x in v.items()))
 def test_every_sampling_schedule_is_bit_exact(variant):
     """Round 5's schedule experiments (developer build; exact, measured, not the defaults: profiles/r05_schedule_ab.txt): the
