@@ -1237,7 +1237,10 @@ __device__ __forceinline__ float dmax3(float a, float b, float c) { return __bui
 __device__ __forceinline__ float dmin3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
 
 template <int NPX, int first, int last, int mmFirst, bool orFlags>
-__global__ __launch_bounds__(256) void k_dogx(DogxArgs a) {
+#ifndef SSRLCV_DOGX_MINWAVES
+#define SSRLCV_DOGX_MINWAVES 1
+#endif
+__global__ __launch_bounds__(256, SSRLCV_DOGX_MINWAVES) void k_dogx(DogxArgs a) {
   typedef float vec __attribute__((ext_vector_type(NPX)));
   const int lane = threadIdx.x & 63;
   const int gwave = blockIdx.x * 4 + (threadIdx.x >> 6);  // adjacent waves = adjacent strips of the same rows
