@@ -152,7 +152,7 @@ def bench_matcher(capi, torch, nq, nt, iters, arithmetic="int8"):
                                      "north star names: frac_of_fp16_peak is the same rate against that); "
                                      "sustained_peak_random_operands = the same instruction alone on random bytes "
                                      "(tools/mfma_i8_peak.hip: the part is power-limited there, 4.96 POP/s on zeros); "
-                                     "matrix-pipe busy cycles and clock: profiles/r04_matcher_pmc.txt"}
+                                     "matrix-pipe busy cycles and clock: profiles/r05_matcher_lab_pmc.txt"}
     return res
 
 
@@ -382,13 +382,13 @@ def describe_roofline(ms_per_image, features, size):
     """Roofline of the key-point stage.  Its kernels are bound by vector-instruction issue (the sampling kernels) or move
     little data, so the stage is priced against the VALU issue peak with the wave-instruction count of the committed PMC
     reduction (instructions per feature do not depend on the run; the time does), and its algorithmic bytes against HBM
-    beside it.  Per-kernel fractions come from the PMC run's own image and time (profiles/r04_describe_pmc.json)."""
-    path = os.path.join(ROOT, "profiles", "r04_describe_pmc.json")
+    beside it.  Per-kernel fractions come from the PMC run's own image and time (profiles/r05_describe_pmc.json)."""
+    path = os.path.join(ROOT, "profiles", "r05_describe_pmc.json")
     out = {"ms_per_image": ms_per_image, "features_per_image": features,
            "ns_per_feature": ms_per_image * 1e6 / max(features, 1),
            "kernels": "flag-byte compaction, k_refine, k_flag_*, list partitions, k_polar, k_thetas, k_desc_consts, k_descriptors "
                       "(ssrlcv_hip_sift_describe; the extrema search itself runs in the pyramid stage's fused DoG pass); "
-                      "events bracket the call on the launching stream"}
+                      "from the library's stage-boundary event to the end of the fused extract, on the launching stream"}
     if os.path.exists(path):
         pmc = json.load(open(path))
         per_feature = pmc.get("valu_wave_instructions_per_feature")
@@ -407,7 +407,7 @@ def describe_roofline(ms_per_image, features, size):
                                                         "valu_frac": None if v.get("valu_frac") is None else round(v["valu_frac"], 3),
                                                         "hbm_frac": None if v.get("hbm_frac") is None else round(v["hbm_frac"], 3)}
                                                     for k, v in pmc.get("per_kernel", {}).items()},
-                        "pmc_source": "profiles/r04_describe_pmc.json @ %s (its own image: %d features)" % (pmc.get("commit"), pmc.get("features_per_image", 0))})
+                        "pmc_source": "profiles/r05_describe_pmc.json @ %s (its own image: %d features)" % (pmc.get("commit"), pmc.get("features_per_image", 0))})
     return out
 
 
@@ -572,12 +572,12 @@ def main():
     line = None
     if rank == 0:
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r04_pyramid_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r05_pyramid_traffic.json")
         if W == 4096 and H_ == 4096 and os.path.exists(tpath):
             # HBM bytes of the pyramid stage per image from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the stage
             # benchmark (collected off-line: counters cannot be read from inside the timed run)
             tj = json.load(open(tpath))
-            traffic, traffic_src = tj["pyramid_stage_bytes_per_image"], "profiles/r04_pyramid_traffic.json @ %s" % tj.get("commit")
+            traffic, traffic_src = tj["pyramid_stage_bytes_per_image"], "profiles/r05_pyramid_traffic.json @ %s" % tj.get("commit")
         pixels_per_step = world * args.images * W * H_
         value = pixels_per_step * args.steps / dt / 1e6
         # Algorithmic bytes of the stage.  `frac` is priced on SURVEY.md 8(d)'s / BASELINE.md section 4's own figure,
@@ -603,7 +603,8 @@ def main():
                                    "24 gaussian levels -- the level-3 launches also write the 2x2 bin --, then per octave ONE pass "
                                    "that forms the 5 DoG levels in registers, reduces their min / max and finds the extrema: the "
                                    "DoG levels are never written); algorithmic bytes = B_pyr = 362.25*W*H per image (SURVEY 8d, S1-S7); "
-                                   "events bracket the stage on the launching stream",
+                                   "the stage is timed inside the fused ssrlcv_hip_sift_extract: HIP events on the launching stream, the one between "
+                                   "the two stages recorded by the library itself (ssrlcv_sift_plan_set_stage_event)",
                          "algorithmic_bytes": b_pyr,
                          "frac_s1_s8": (b_pyr + b_ext) / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes_s1_s8": b_pyr + b_ext,

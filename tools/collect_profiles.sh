@@ -13,6 +13,8 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-class-api --no-nview > $OUT/bench_line.json 2> $OUT/bench.err
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+# (the serial per-kernel passes need the developer build: the release library has no switches)
+export SSRLCV_DEV_BUILD=1
 export SSRLCV_SIFT_SERIAL=1
 rocprofv3 --kernel-trace --stats -d $OUT/serial -o s --output-format csv -- python3 tools/bench_sift_stages.py --size 4096 --scene --stages 7 > $OUT/serial.log 2>&1
 cp $(find $OUT/serial -name "*kernel_stats.csv" | head -1) $OUT/serial_kernel_stats.csv
@@ -21,6 +23,7 @@ rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_WRITE_SIZE --output-format csv -- python3
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d $OUT/pmc_SQ --output-format csv -- python3 tools/bench_sift_stages.py --size 4096 --scene --stages 7 > $OUT/pmc_sq.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE -d $OUT/pmc_MFMA --output-format csv -- python3 tools/bench_sift_stages.py --size 4096 --scene --stages 7 > $OUT/pmc_mfma.log 2>&1
 unset SSRLCV_SIFT_SERIAL
+unset SSRLCV_DEV_BUILD
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU -d $OUT/pmc_MATCH --output-format csv -- python3 tools/bench_matcher.py 262144 2 > $OUT/pmc_match.log 2>&1
 FEATURES=$(grep "stop=7" $OUT/pmc_sq.log | sed 's/.*n=//')
 python3 tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE 4 $COMMIT > $OUT/pyramid_traffic.json
