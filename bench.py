@@ -335,7 +335,8 @@ def class_api_leg(img_u8, size, value_c_abi, iters=5):
             "c_abi_resident_value": value_c_abi,
             "note": "one image at a time, synchronous like the reference's methods; plan, workspace and staging buffer "
                     "are pooled inside the factory; includes the image H2D, the restore of the pixels' origin state "
-                    "(a D2H copy, as upstream) and the exact-size feature copy"}
+                    "(no copy back for grey pixels since round 5: the host copy is kept while the kernels read the device one) "
+                    "and the exact-size feature copy"}
 
 
 def class_api_flow_leg(imgs, cams, size, nview_ms, cloud_py, iters=3):
@@ -373,8 +374,8 @@ def class_api_flow_leg(imgs, cams, size, nview_ms, cloud_py, iters=3):
         shutil.rmtree(d, ignore_errors=True)
     j.update({"nview_ms_per_step": nview_ms, "flow_over_nview": j["flow_ms"] / nview_ms if nview_ms else None,
               "cloud_equals_python_flow": same,
-              "note": "synchronous class-level calls, one image at a time, pixels in host memory (each generateFeatures uploads its image "
-                      "and restores the origin state); features stay on the device between the stages; RCCL communicator of one rank"})
+              "note": "synchronous class-level calls, one image at a time, pixels in pageable host memory (each generateFeatures uploads "
+                      "its image and restores the origin state); features stay on the device between the stages; RCCL communicator of one rank"})
     return j
 
 
