@@ -11,7 +11,8 @@ collectives are the two exchanges the flow really has:
 
 Arrays have different lengths per rank, so each exchange is one small size collective (with a single device-to-host
 copy of the size vector) followed by every rank's bytes at their exact size -- one broadcast per rank into its segment
-of a flat buffer, all in flight (round 3 padded an all-gather to the largest rank; the shares differ several-fold).
+of a flat buffer, queued together (they overlap under gloo; RCCL serialises them on the communicator's stream, which costs
+nothing at these sizes; round 3 padded an all-gather to the largest rank: the shares differ several-fold).
 Payloads are tens to hundreds of MB: the feature exchange of eight 4096^2 views moves 8 x 240 MB, ~10 ms on 7 x 153 GB/s
 xGMI links.
 
@@ -85,7 +86,7 @@ def all_reduce_sum(t, group=None):
 
 def _gather_segments(segments, flat, group=None):
     """Fills `flat` (1-D uint8 on the backend's device): segment r = flat[offsets[r] : offsets[r] + sizes[r]] is broadcast
-    from rank r.  Exact sizes on the wire -- one broadcast per rank, all in flight -- instead of an all-gather padded to
+    from rank r.  Exact sizes on the wire -- one broadcast per rank, queued together -- instead of an all-gather padded to
     the largest rank: the shares differ several-fold (a rank's features, or its LPT-assigned pairs)."""
     works = []
     for r, (off, size) in enumerate(segments):
@@ -122,7 +123,8 @@ def all_gather_bytes(local, group=None):
 def exchange_keyed(local_items, num_keys, owner_fn, group=None):
     """Generic keyed exchange: `local_items` maps key -> 1-D uint8 tensor for the keys this rank owns
     (owner_fn(key, world) == rank).  Every rank returns the full list [tensor for key 0, 1, ...].
-    One count all-gather + one padded payload all-gather per call (keys of a rank are concatenated)."""
+    One all-reduce of the key sizes + every rank's bytes at their exact size (the keys of a rank concatenated into its segment
+    of a flat buffer, one broadcast per rank: _gather_segments; nothing is padded to the largest rank)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     mine = [k for k in range(num_keys) if owner_fn(k, world) == rank]

@@ -57,21 +57,29 @@ class PoseEstimator {
     exit(-1);
   }
 
+  // PoseEstimator::LM_optimize (src/PoseEstimator.cu:314-341): the start position is the baseline between the two cameras
+  // expressed in the query camera's frame (its z, y, x rotations undone in that order), in the matcher's length unit
+  // (1 / 1000 of the cameras'); then at most kMaxLMIterations damped steps, stopping at the first one that does not
+  // improve the cost.  The damping starts at 100, as upstream.
+  static constexpr int kMaxLMIterations = 50;
+  float3 baselineInQueryFrame() const {
+    const float3 axis[3] = {{0, 0, 1}, {0, 1, 0}, {1, 0, 0}};
+    const float angle[3] = {query->camera.cam_rot.z, query->camera.cam_rot.y, query->camera.cam_rot.x};
+    float3 b = target->camera.cam_pos - query->camera.cam_pos;
+    for (int k = 0; k < 3; ++k) b = rotatePointArbitrary(b, axis[k], -angle[k]);
+    return b;
+  }
   void LM_optimize(Pose* pose) {
-    float lambda = 100;
-    float3 pos = target->camera.cam_pos - query->camera.cam_pos;
-    pos = rotatePointArbitrary(pos, {0, 0, 1}, -query->camera.cam_rot.z);
-    pos = rotatePointArbitrary(pos, {0, 1, 0}, -query->camera.cam_rot.y);
-    pos = rotatePointArbitrary(pos, {1, 0, 0}, -query->camera.cam_rot.x);
-    pose->x = pos.x / 1000;
-    pose->y = pos.y / 1000;
-    pose->z = pos.z / 1000;
-    int iterations = 0;
-    do {
+    const float3 start = baselineInQueryFrame();
+    pose->x = start.x / 1000;
+    pose->y = start.y / 1000;
+    pose->z = start.z / 1000;
+    float damping = 100;
+    for (int step = 1; step <= kMaxLMIterations; ++step) {
       logger.info.printf("Pose rotations: %f %f %f", pose->roll, pose->pitch, pose->yaw);
       logger.info.printf("Pose positions: %f %f %f", pose->x, pose->y, pose->z);
-      iterations++;
-    } while (LM_iteration(pose, &lambda) && iterations < 50);
+      if (!LM_iteration(pose, &damping)) break;
+    }
   }
 
   // public here (private upstream) so that tests can drive single iterations
