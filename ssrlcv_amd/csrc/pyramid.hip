@@ -338,6 +338,9 @@ __global__ __launch_bounds__(kTX) void k_gauss_fused(ConvArgs a) {
 // image) and then reads 17 MB.  The value of an upsampled pixel is the exact integer form of upsample_at (see
 // k_upsample2x_u8x4): 0.25 * (p[ym][xm] + p[ym][xp'] + p[yp'][xm] + p[yp'][xp']), with the mirror of the convolution
 // applied to the upsampled coordinates first.
+#ifndef SSRLCV_STRIP_VGPR_WEIGHTS
+#define SSRLCV_STRIP_VGPR_WEIGHTS 0  // measured in round 5: 178 -> 182 us per image over the 17-tap launches (profiles/r05_dogx_ab.txt)
+#endif
 template <int R, bool UPS>
 __global__ __launch_bounds__(kTX) void k_gauss_strip(ConvArgs a) {
   constexpr int RP = (R + 3) / 4 * 4;
@@ -370,6 +373,17 @@ __global__ __launch_bounds__(kTX) void k_gauss_strip(ConvArgs a) {
   float win[WIN];
 #pragma unroll
   for (int k = 0; k < WIN; ++k) win[k] = 0.0f;
+  // SSRLCV_STRIP_VGPR_WEIGHTS=1 keeps the R + 1 distinct weights in VECTOR registers (an FMA with a scalar source issues in
+  // ~4.2 cycles per SIMD against ~3.3 with three vector sources, tools/valu_rate.hip): no faster, the kernel is not bound
+  // by FMA issue; the default leaves them in SGPRs.
+  float wv[R + 1];
+#pragma unroll
+  for (int k = 0; k <= R; ++k) {
+    wv[k] = a.wgt[k];
+#if SSRLCV_STRIP_VGPR_WEIGHTS
+    asm volatile("" : "+v"(wv[k]));
+#endif
+  }
   float mn = FLT_MAX, mx = -FLT_MAX;
   const int steps = (nrows + 2 * R + kNR - 1) / kNR;
   float4 preI0, preI1;  // next step's two rows of this wave (named scalars: an indexed pair went to scratch)
@@ -457,7 +471,7 @@ __global__ __launch_bounds__(kTX) void k_gauss_strip(ConvArgs a) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const int k = 4 * q + j - (RP - R) - i;
-            if (k >= 0 && k <= 2 * R) o[i] = __builtin_fmaf(v[j], a.wgt[k <= R ? k : 2 * R - k], o[i]);
+            if (k >= 0 && k <= 2 * R) o[i] = __builtin_fmaf(v[j], wv[k <= R ? k : 2 * R - k], o[i]);
           }
         }
       }
@@ -474,7 +488,7 @@ __global__ __launch_bounds__(kTX) void k_gauss_strip(ConvArgs a) {
 #pragma unroll
       for (int k = 0; k <= 2 * R; ++k) {
 #pragma unroll
-        for (int i = 0; i < kNR; ++i) vs[i] = __builtin_fmaf(win[i + k], a.wgt[k <= R ? k : 2 * R - k], vs[i]);
+        for (int i = 0; i < kNR; ++i) vs[i] = __builtin_fmaf(win[i + k], wv[k <= R ? k : 2 * R - k], vs[i]);
       }
       float* orow = a.out + (size_t)(y0 + s * kNR - 2 * R) * W + gx;
 #pragma unroll
@@ -1240,6 +1254,12 @@ template <int NPX, int first, int last, int mmFirst, bool orFlags>
 #ifndef SSRLCV_DOGX_MINWAVES
 #define SSRLCV_DOGX_MINWAVES 1
 #endif
+#ifndef SSRLCV_DOGX_VGPR_MIN
+#define SSRLCV_DOGX_VGPR_MIN 0
+#endif
+#ifndef SSRLCV_DOGX_RING
+#define SSRLCV_DOGX_RING 1
+#endif
 __global__ __launch_bounds__(256, SSRLCV_DOGX_MINWAVES) void k_dogx(DogxArgs a) {
   typedef float vec __attribute__((ext_vector_type(NPX)));
   const int lane = threadIdx.x & 63;
@@ -1263,20 +1283,41 @@ __global__ __launch_bounds__(256, SSRLCV_DOGX_MINWAVES) void k_dogx(DogxArgs a) 
     if (b >= first && b <= last) {
       lmn[b] = a.lvlMinMax[2 * b];
       rg[b] = sv::make_divisor(a.lvlMinMax[2 * b + 1] - lmn[b]);
+#if SSRLCV_DOGX_VGPR_MIN
+      asm volatile("" : "+v"(lmn[b]));  // a vector source: a subtraction with a scalar source issues a cycle later (tools/valu_rate.hip)
+#endif
     }
   }
   float dmn[svp::kDog], dmx[svp::kDog];
 #pragma unroll
   for (int b = 0; b < svp::kDog; ++b) { dmn[b] = FLT_MAX; dmx[b] = -FLT_MAX; }
-  // carried state: level-combined 3-wide max / min of rows y - 2 and y - 1, centre values of row y - 1 (levels 1..3)
-  float gmxA[3][NPX], gmnA[3][NPX], gmxB[3][NPX], gmnB[3][NPX], ctrB[3][NPX];
+  // carried state: level-combined 3-wide max / min of rows y - 2 and y - 1, centre values of row y - 1 (levels 1..3).
+  // Three register sets take the roles {row y - 2, row y - 1, row y} in rotation and the row loop is unrolled three
+  // times, so that a row's result is formed in the set whose row has just gone out of use: carried as "A = B, B = new"
+  // the state cost 60 v_mov_b32 of the row's 430 vector instructions (the pass is VALU bound).
+  float gmxA[3][NPX], gmnA[3][NPX], gmxB[3][NPX], gmnB[3][NPX], gmxC[3][NPX], gmnC[3][NPX];
+  float ctrX[3][NPX], ctrY[3][NPX], ctrZ[3][NPX];
 #pragma unroll
   for (int k = 0; k < 3; ++k)
 #pragma unroll
-    for (int i = 0; i < NPX; ++i) { gmxA[k][i] = gmnA[k][i] = gmxB[k][i] = gmnB[k][i] = ctrB[k][i] = 0.0f; }
-  // The next row is loaded into the registers of the current one as soon as its values have been normalised (they are
-  // dead then): the loads fly under the ~300 instructions of the rest of the row.  (A separate `next` set, copied at the
-  // top of the loop, was 24 of the row's 430 vector instructions.)
+    for (int i = 0; i < NPX; ++i) {
+      gmxA[k][i] = gmnA[k][i] = gmxB[k][i] = gmnB[k][i] = gmxC[k][i] = gmnC[k][i] = 0.0f;
+      ctrX[k][i] = ctrY[k][i] = ctrZ[k][i] = 0.0f;
+    }
+  // The next row is brought into the registers of the current one as soon as its values have been normalised (they are
+  // dead then).  (A separate `next` set, copied at the top of the loop, was 24 of the row's 430 vector instructions.)
+  // NPX < 4 (rows that are not 16-byte aligned): by plain loads, one row ahead.
+  // NPX == 4: one row ahead was not enough -- a wave spends ~0.7 us on a row's arithmetic, two waves fit a SIMD (241
+  // registers) and a loaded row arrives after ~2 us: the pass ran at 2.7 us per row and wave, and taking 60 instructions
+  // out of the row's 430 changed nothing (round 5).  The rows y + 2 and y + 3 are therefore in flight as LDS-DMA transfers
+  // (global_load_lds: no registers) into a two-slot ring per wave, and row y + 1 is read from its slot where the plain
+  // load used to be issued; its slot then takes row y + 3.  6 KB per slot, 48 KB per block, two blocks per CU.
+  constexpr bool RING = SSRLCV_DOGX_RING && NPX == 4;
+  constexpr int NL = last - first + 1;
+  static_assert(!RING || (NL >= 4 && NL <= 6), "ring_take's wait counts are written out for 4..6 levels");
+  __shared__ float4 s_ring[RING ? 4 * 2 * NL * 64 : 1];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float4* const ring = s_ring + (RING ? wave * 2 * NL * 64 : 0);
   vec cur[svp::kGauss];
   auto fetch = [&](int y) {
     y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);  // rows -1 and H only neighbour border rows, which do not flag
@@ -1284,8 +1325,47 @@ __global__ __launch_bounds__(256, SSRLCV_DOGX_MINWAVES) void k_dogx(DogxArgs a) 
 #pragma unroll
     for (int b = first; b <= last; ++b) cur[b] = __builtin_nontemporal_load(reinterpret_cast<const vec*>(a.lvl[b] + row));
   };
-  fetch(r0 - 1);
-  for (int y = r0 - 1; y <= r1; ++y) {
+  auto ring_issue = [&](int y, int slot) {  // row y (clamped) -> slot; lane l's 16 bytes land at slot base + 16 l
+    y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
+    const size_t row = (size_t)y * W + xl;
+#pragma unroll
+    for (int b = first; b <= last; ++b)
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a.lvl[b] + row),
+                                       (void __attribute__((address_space(3)))*)(ring + (slot * NL + (b - first)) * 64), 16, 0, 2 /* nt */);
+  };
+  // The slot is read by ds_read_b128 in inline assembly: a read the compiler sees makes it wait for EVERY transfer in
+  // flight, not only this slot's.  vmcnt(NL): all but the NL youngest vector-memory operations have completed -- the NL
+  // transfers of the following row were issued behind this row's, and loads complete in order (flag stores in between only
+  // make the wait stricter); vmcnt(0) where no row follows.
+  auto ring_take = [&](int slot, bool followed) {
+    if (followed) {  // (NL transfers per row)
+      if (NL == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (NL == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const uint32_t addr = (uint32_t)(uintptr_t)(void __attribute__((address_space(3)))*)(ring + slot * NL * 64) + 16u * (uint32_t)lane;
+#pragma unroll
+    for (int b = first; b <= last; ++b)
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(cur[b]) : "v"(addr), "n"((b - first) * 1024) : "memory");
+    // (the values are outputs of the wait: no use of them can be scheduled in front of it)
+    if (NL == 6) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[first]), "+v"(cur[first + 1]), "+v"(cur[first + 2]), "+v"(cur[first + 3]), "+v"(cur[first + 4]), "+v"(cur[last]) : : "memory");
+    else if (NL == 5) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[first]), "+v"(cur[first + 1]), "+v"(cur[first + 2]), "+v"(cur[first + 3]), "+v"(cur[last]) : : "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[first]), "+v"(cur[first + 1]), "+v"(cur[first + 2]), "+v"(cur[last]) : : "memory");
+  };
+  const int yEnd = r0 - 1 + (r1 - r0 + 2 + 2) / 3 * 3 - 1;  // last row of the last trip of three (>= r1)
+  unsigned pendPacked = 0;
+  unsigned* pendPtr = nullptr;  // (per lane; null: nothing pending)
+  auto flush_flags = [&]() {
+    if (pendPtr) *pendPtr = orFlags ? (*pendPtr | pendPacked) : pendPacked;
+    pendPtr = nullptr;
+  };
+  // one row: (oMx, oMn) = state of row y - 2, (pMx, pMn) of row y - 1, (nMx, nMn) receives row y's; cPrev = centre values
+  // of row y - 1, cNew receives row y's
+  auto row = [&](int y, const float (&oMx)[3][NPX], const float (&oMn)[3][NPX], const float (&pMx)[3][NPX],
+                 const float (&pMn)[3][NPX], float (&nMx)[3][NPX], float (&nMn)[3][NPX], const float (&cPrev)[3][NPX],
+                 float (&cNew)[3][NPX]) __attribute__((always_inline)) {
     // normalised levels and DoG values of this row
     float d[svp::kDog][NPX];
     {
@@ -1310,7 +1390,18 @@ __global__ __launch_bounds__(256, SSRLCV_DOGX_MINWAVES) void k_dogx(DogxArgs a) 
 #pragma unroll
       for (int i = 0; i < NPX; ++i) asm volatile("" : "+v"(d[b][i]) : : "memory");
     }
-    if (y < r1) fetch(y + 1);
+    if (RING) {
+      if (y < yEnd) {  // (wave-uniform)
+        const int slot = (y + 1 - (r0 - 1)) & 1;
+        ring_take(slot, y + 2 <= yEnd);
+        flush_flags();
+        if (y + 3 <= yEnd) ring_issue(y + 3, slot);
+      } else {
+        flush_flags();
+      }
+    } else {
+      fetch(y + 1);  // (clamped: the row behind the last one is loaded and not used)
+    }
     // 3-wide max / min per level; the level's {min, max} ride on them (pixel i's triple covers i - 1 .. i + 1; the halo
     // rows and columns a wave sees beyond its own are pixels of the image too)
     float hmx[svp::kDog][NPX], hmn[svp::kDog][NPX];
@@ -1338,16 +1429,15 @@ __global__ __launch_bounds__(256, SSRLCV_DOGX_MINWAVES) void k_dogx(DogxArgs a) 
       }
     }
     // ... then across the levels k, k + 1, k + 2 (DoG level k + 1 and its two neighbours)
-    float gmx[3][NPX], gmn[3][NPX];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
 #pragma unroll
-      for (int i = 0; i < NPX; ++i) gmx[k][i] = gmn[k][i] = 0.0f;
+      for (int i = 0; i < NPX; ++i) nMx[k][i] = nMn[k][i] = 0.0f;
       if (k < first || k + 2 >= last) continue;
 #pragma unroll
       for (int i = 0; i < NPX; ++i) {
-        gmx[k][i] = dmax3(hmx[k][i], hmx[k + 1][i], hmx[k + 2][i]);
-        gmn[k][i] = dmin3(hmn[k][i], hmn[k + 1][i], hmn[k + 2][i]);
+        nMx[k][i] = dmax3(hmx[k][i], hmx[k + 1][i], hmx[k + 2][i]);
+        nMn[k][i] = dmin3(hmn[k][i], hmn[k + 1][i], hmn[k + 2][i]);
       }
     }
     // flags of row y - 1 (its three rows y - 2, y - 1, y are complete)
@@ -1361,16 +1451,21 @@ __global__ __launch_bounds__(256, SSRLCV_DOGX_MINWAVES) void k_dogx(DogxArgs a) 
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           if (k < first || k + 2 >= last) continue;
-          const float hi = dmax3(gmxA[k][i], gmxB[k][i], gmx[k][i]);
-          const float lo = dmin3(gmnA[k][i], gmnB[k][i], gmn[k][i]);
-          const float c = ctrB[k][i];
+          const float hi = dmax3(oMx[k][i], pMx[k][i], nMx[k][i]);
+          const float lo = dmin3(oMn[k][i], pMn[k][i], nMn[k][i]);
+          const float c = cPrev[k][i];
           const bool ext = in && (hi == c || lo == c);
           const bool loud = ext && !(__builtin_fabsf(c) < a.minAbs);
           packed |= (ext ? 1u << (8 * i + k) : 0u) | (loud ? 1u << (8 * i + svp::kNoiseFlagShift + k) : 0u);
         }
       }
       uint8_t* fp = a.flags + (size_t)yo * W + x;
-      if (NPX == 4) {
+      if (RING) {
+        // stored by the NEXT row, in front of its transfers: a store between two rows' transfers would be among the six
+        // youngest operations ring_take leaves in flight and make it wait for part of the row behind the one it needs
+        pendPacked = packed;
+        pendPtr = reinterpret_cast<unsigned*>(fp);
+      } else if (NPX == 4) {
         unsigned* p4 = reinterpret_cast<unsigned*>(fp);
         *p4 = orFlags ? (*p4 | packed) : packed;
       } else if (NPX == 2) {
@@ -1382,15 +1477,27 @@ __global__ __launch_bounds__(256, SSRLCV_DOGX_MINWAVES) void k_dogx(DogxArgs a) 
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      if (k < first || k + 2 >= last) continue;
 #pragma unroll
-      for (int i = 0; i < NPX; ++i) {
-        gmxA[k][i] = gmxB[k][i]; gmnA[k][i] = gmnB[k][i];
-        gmxB[k][i] = gmx[k][i]; gmnB[k][i] = gmn[k][i];
-        ctrB[k][i] = d[k + 1][i];
-      }
+      for (int i = 0; i < NPX; ++i) cNew[k][i] = (k < first || k + 2 >= last) ? 0.0f : d[k + 1][i];
     }
+  };
+  // rows r0 - 1 .. r1, rounded up to whole trips of three: the rows behind r1 write no flag, and what they add to the
+  // {min, max} are values of real pixels (launch_dogx makes rowsPerWave + 2 a multiple of 3: only a last segment pays)
+  if (RING) {
+    ring_issue(r0 - 1, 0);
+    ring_issue(r0, 1);
+    ring_take(0, true);
+    ring_issue(r0 + 1, 0);
+  } else {
+    fetch(r0 - 1);
   }
+  for (int y = r0 - 1; y <= r1; y += 3) {
+    row(y, gmxA, gmnA, gmxB, gmnB, gmxC, gmnC, ctrX, ctrY);
+    row(y + 1, gmxB, gmnB, gmxC, gmnC, gmxA, gmnA, ctrY, ctrZ);
+    row(y + 2, gmxC, gmnC, gmxA, gmnA, gmxB, gmnB, ctrZ, ctrX);
+  }
+  if (RING) flush_flags();
+  if (RING) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (every transfer issued has been taken; a wave must not end with one in flight)
   // per-wave {min, max} partials (k_dog_finalize reduces them: no atomics)
 #pragma unroll
   for (int b = mmFirst; b < last; ++b) {
@@ -1439,6 +1546,7 @@ int launch_dogx(const float* const levels[svp::kGauss], const float* levelMinMax
   if (segs < 1) segs = 1;
   unsigned rows = (h + segs - 1) / segs;
   if (rows < 16) rows = 16;
+  rows += (3 - (rows + 2) % 3) % 3;  // the kernel's row loop runs in trips of three rows over rows + 2
   a.rowsPerWave = (int)rows;
   segs = (h + rows - 1) / rows;
   const unsigned waves = segs * (unsigned)a.strips;
@@ -2118,6 +2226,10 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
   static const DogSchedule sched;
   static const bool overlapOctaves = svdev::env("SSRLCV_NO_OCTAVE_OVERLAP") == nullptr;
   static const int overlapFrom = svdev::env("SSRLCV_OCTAVE_OVERLAP_FROM") ? atoi(svdev::env("SSRLCV_OCTAVE_OVERLAP_FROM")) : 1;
+  static const int deferDog0 = [] {  // 1 or 2 (octave 3 has no successor to wait for), 0: off
+    const int n = svdev::env("SSRLCV_DOGX0_AFTER") ? atoi(svdev::env("SSRLCV_DOGX0_AFTER")) : 0;
+    return n == 1 || n == 2 ? n : 0;
+  }();
   // Developer build, SSRLCV_EARLY_POLAR=1: a fused extract starts an octave's gradient tables (k_polar, the first thing the
   // key-point stage needs) on a side stream as soon as that octave's DoG pass is through, beside the small octaves' launches.
   // Exact, measured in round 5 and NOT the default: the scale-space stage grows by 0.36 ms per 4096^2 image (the tables'
@@ -2225,7 +2337,7 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
     const hipStream_t so = (as && overlapOctaves && o >= overlapFrom && ((o - overlapFrom) & 1) == 0) ? as->chain : st;
     // DoG / extrema passes: octaves 0 and 1 on the side stream (beside the next octave's convolutions); with the overlap
     // the last two follow their own convolutions on those streams -- behind octave 1's in one in-order stream they were the tail
-    const hipStream_t sdo = (as && overlapOctaves && o >= 2) ? so : sd;  // (o >= 2 whatever the first overlapped octave)
+    const hipStream_t sdo = (as && overlapOctaves && o >= 2) ? so : ((deferDog0 && as && o == 1) ? as->chain2 : sd);  // (o >= 2 whatever the first overlapped octave)
     float* dogPartial = (float*)(ws + plan->off_dogPartial) + (size_t)o * 2 * svp::kDog * svp::kDogMaxWaves;
     uint8_t* flags = (uint8_t*)(ws + oc.off_flags);
     if (as && o >= 1) SSRLCV_HIP_TRY(hipStreamWaitEvent(so, as->binDone[o - 1], 0));
@@ -2252,6 +2364,19 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
         }
         in = nextIn[o];
         if (as) SSRLCV_HIP_TRY(hipEventRecord(as->binDone[o], so));
+        if (deferDog0 && as && o == deferDog0) {
+          // Developer build, SSRLCV_DOGX0_AFTER=n: octave 0's DoG pass (no one in this stage waits for it) is held back until
+          // level 3 of octave n is through, so that the octaves that do have successors get the machine first.  Exact, measured
+          // and NOT the default: build_dog 1.70 -> 1.76 ms per 4096^2 image for n = 1 and 2 (profiles/r05_dogx_ab.txt)
+          const svp::OctavePlan& o0 = plan->oct[0];
+          const float* lv0[svp::kGauss];
+          for (int q = 0; q < svp::kGauss; ++q) lv0[q] = (const float*)(ws + plan->off_gauss[0][q]);
+          SSRLCV_HIP_TRY(hipStreamWaitEvent(sd, as->binDone[o], 0));
+          rc = launch_dogx(lv0, mmAll, o0.w, o0.h, (uint8_t*)(ws + o0.off_flags), mmAll + 2 * svp::kGauss, (float*)(ws + plan->off_dogPartial), 0,
+                           svp::kDog, 0, false, firstNoise, sched.waves, sd);
+          if (rc) return rc;
+          SSRLCV_HIP_TRY(hipEventRecord(as->dogDone[0], sd));
+        }
       }
       if (split && b == 3) {  // DoG 0..2: extrema of level 1, min / max of 0..2
         SSRLCV_HIP_TRY(hipEventRecord(as->levelDone[o][b], so));
@@ -2264,6 +2389,7 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
       SSRLCV_HIP_TRY(hipEventRecord(as->convDone[o], so));
       SSRLCV_HIP_TRY(hipStreamWaitEvent(sdo, as->convDone[o], 0));
     }
+    if (deferDog0 && as && o == 0) continue;  // (its DoG pass is queued from octave deferDog0's iteration, see above)
     if (split) rc = launch_dogx(lv, mm, oc.w, oc.h, flags, mm + 2 * svp::kGauss, dogPartial, 1, svp::kDog, 3, true, firstNoise, sched.waves, sdo);
     else rc = launch_dogx(lv, mm, oc.w, oc.h, flags, mm + 2 * svp::kGauss, dogPartial, 0, svp::kDog, 0, false, firstNoise, sched.waves, sdo);
     if (rc) return rc;

@@ -341,6 +341,8 @@ print("PYRAMID OK")
     {"SSRLCV_NO_BIN_FUSION": "1"},                                  # 2x2 bin by k_bin2x instead of the level-3 convolution
     {"SSRLCV_DOG_SPLIT": "1"},                                      # the DoG / extrema pass split on every octave (levels 0-3 early, 1-5 late)
     {"SSRLCV_DOGX_WAVES": "65536"},                                 # the shortest row segments
+    {"SSRLCV_DOGX_WAVES": "2048"},                                  # long row segments (many trips of the LDS-DMA row ring)
+    {"SSRLCV_DOGX0_AFTER": "1"},                                    # octave 0's DoG pass held back behind octave 1's level 3
     {"SSRLCV_DOGX_NPX": "1", "SSRLCV_DOGX_WAVES": "512"},           # one pixel per lane, long row segments
     {"SSRLCV_DOGX_NPX": "2", "SSRLCV_DOG_SPLIT": "1"},              # two pixels per lane
     {"SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_SIFT_SERIAL": "1"},    # marching kernels only, one stream
