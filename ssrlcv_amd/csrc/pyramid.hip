@@ -411,10 +411,14 @@ __global__ __launch_bounds__(kTX) void k_gauss_strip(ConvArgs a) {
     const uint8_t* r0 = a.u8 + (size_t)ym * uw;
     const uint8_t* r1 = a.u8 + (size_t)yp * uw;
     r.p0 = *reinterpret_cast<const uint16_t*>(r0 + c0);
+#ifdef SSRLCV_LAB_UPS_LOADS  // timing lab (results invalid): one of the eight byte loads per row
+    r.p1 = r.p0; r.q0 = r.q1 = 0; (void)r1;
+#else
     r.p1 = *reinterpret_cast<const uint16_t*>(r1 + c0);
     r.q0 = r0[c2];
     r.q1 = r1[c2];
     if (halo) { r.h00 = r0[hxm]; r.h01 = r0[hxp]; r.h10 = r1[hxm]; r.h11 = r1[hxp]; }
+#endif
   };
   auto up_convert = [&](const RawRow& r, float4& o, float& oh) {
     const uint32_t a0 = (r.p0 & 255u) + (r.p1 & 255u), a1 = (r.p0 >> 8) + (r.p1 >> 8), a2 = r.q0 + r.q1;
