@@ -439,7 +439,7 @@ def run_nview(args, torch, dist, capi, world, rank, dev, views, size, steps, war
         res = step()
     barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if dist is None or dist.get_backend() != "gloo" else "cpu")
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -514,8 +514,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # SSRLCV_BENCH_BACKEND=gloo: rehearsal of the N > 1 legs on a box with fewer GPUs than ranks (every collective staged
+        # through the host, ranks share the cards); the driver's runs use RCCL, one rank per GPU
+        if os.environ.get("SSRLCV_BENCH_BACKEND", "nccl") == "gloo":
+            local_rank %= max(1, torch.cuda.device_count())
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -559,7 +566,7 @@ def main():
         step(events[k])
     barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if dist is None or dist.get_backend() != "gloo" else "cpu")
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
