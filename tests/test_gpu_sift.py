@@ -159,10 +159,12 @@ def test_keypoint_stages_match_oracle(capi, oracle_lib, image_small, stage):
     assert plan.count() == total
 
 
-@pytest.mark.parametrize("size", [None, (262, 260), (257, 263)])
+@pytest.mark.parametrize("size", [None, (262, 260), (257, 263), (256, 129), (264, 137), (776, 200)])
 def test_features_match_oracle(capi, oracle_lib, image_small, size):
-    """None = the 384 x 256 image; the other two sizes run with makeBinnable's zero border (even / odd branch):
-    locations are in the padded frame on both sides."""
+    """None = the 384 x 256 image; the next two sizes run with makeBinnable's zero border (even / odd branch):
+    locations are in the padded frame on both sides; the last three leave the fused DoG pass's last row segment with one, two
+    and a few rows (16-row segments over 2 x 129 / 2 x 137 rows; 22-row ones further down), i.e. short last trips of its
+    three-row loop and of the LDS-DMA row ring."""
     img = image_small if size is None else H.synthetic_image(size[0], size[1], seed=5)
     h, w = img.shape
     of = H.oracle_sift(oracle_lib, img)
