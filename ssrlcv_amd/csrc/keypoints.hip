@@ -490,6 +490,9 @@ __device__ __forceinline__ int round_coord(float v) {
 // independent, but not the reference's sum: thetas agreed to ~1e-6 and a handful of peak decisions per million key
 // points flipped.
 constexpr int kThetaChunk = 8;
+#ifndef SSRLCV_THETAS_DEPTH
+#define SSRLCV_THETAS_DEPTH 1  // chunks requested ahead of the one being evaluated (1 or 2; 2 measured in round 5: no faster)
+#endif
 
 // Work list of the two sampling kernels: the key points of ALL octaves in one launch.  Every octave's list is cut at
 // its blur-segment boundaries (a segment = one DoG level = one polar table = one class of window sizes: windows grow
@@ -656,58 +659,91 @@ __global__ __launch_bounds__(64) void k_thetas(const OctaveState* states, const 
   // every lane of the block is in the same blur segment (the ranges are cut there), so the polar table -- the buffer
   // descriptor -- is wave-uniform
   {
-    bool active = inside;
     // entry e of the table (flat index e - 1) is at byte 8 e; reads past the end return 0 (and belong to lanes whose
     // samples are not used: a window row stays inside the level)
     const float2* base = L.polar + (size_t)(useg - 1) * levelStride;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(uint32_t)(levelStride * 8), 0x00020000);  // < 4 GiB: checked by plan_create
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    float x = minx, y = miny;
-    // row state
-    float ty = y - ky;
-    float ty2 = ty * ty;
-    unsigned rowoff = (unsigned)round_pos(y) * (unsigned)W + 1u;
-    u32x4 nxt[kThetaChunk / 2];
-    auto fetch = [&](float fx, unsigned roff) {
+    // A cursor walks the window chunk by chunk in the reference's order (x += 1.0f eight times, then the next row); the
+    // chunk being evaluated is SSRLCV_THETAS_DEPTH chunks behind the one being requested.  One chunk ahead leaves ~0.25 of
+    // the kernel's 0.55 ms per 4096^2 image to the gathers (profiles/r05_sampling_gather_lab.txt); two chunks ahead
+    // (-DSSRLCV_THETAS_DEPTH=2, 91 instead of 69 registers) is no faster -- orientations + tables 1.306 / 1.309 ms against
+    // 1.275 / 1.282: the 2.4 GB of 64-byte pieces are a throughput cost, not a latency one.
+    struct Cursor { float x, y, ty2; unsigned rowoff; bool act; };
+    Cursor cf;  // the next chunk to request
+    cf.x = minx;
+    cf.y = miny;
+    cf.ty2 = (miny - ky) * (miny - ky);
+    cf.rowoff = (unsigned)round_pos(miny) * (unsigned)W + 1u;
+    cf.act = inside;
+    auto advance = [&](Cursor& c) {  // same row while the reference's loop condition holds, else the next row
+      float xn = c.x;
+#pragma unroll
+      for (int i = 0; i < kThetaChunk; ++i) xn += 1.0f;
+      if (c.act) {
+        if (xn <= maxx) {
+          c.x = xn;
+        } else {
+          c.x = minx;
+          c.y += 1.0f;
+          if (!(c.y <= maxy)) c.act = false;
+          const float ty = c.y - ky;
+          c.ty2 = ty * ty;
+          c.rowoff = (unsigned)round_pos(c.y) * (unsigned)W + 1u;
+        }
+      }
+    };
+    typedef u32x4 Chunk[kThetaChunk / 2];
+    auto fetch = [&](const Cursor& c, Chunk& into) {
+      if (!c.act) return;
 #ifdef SSRLCV_LAB_LOCAL_GATHER
-      const unsigned off = ((roff + (unsigned)round_pos(fx)) & 4095u) * 8u;
+      const unsigned off = ((c.rowoff + (unsigned)round_pos(c.x)) & 4095u) * 8u;
 #else
-      const unsigned off = (roff + (unsigned)round_pos(fx)) * 8u;  // byte offset, below 2^32
+      const unsigned off = (c.rowoff + (unsigned)round_pos(c.x)) * 8u;  // byte offset, below 2^32
 #endif
 #pragma unroll
-      for (int j = 0; j < kThetaChunk / 2; ++j) nxt[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off + 16u * j), 0, 0);
+      for (int j = 0; j < kThetaChunk / 2; ++j) into[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off + 16u * j), 0, 0);
     };
-    if (active) fetch(x, rowoff);
-    while (__any(active)) {
+    Chunk q0, q1;      // requested chunks, oldest first (q1 only at depth 2)
+    Cursor c0, c1;     // their cursors
+#pragma unroll
+    for (int j = 0; j < kThetaChunk / 2; ++j) q0[j] = q1[j] = u32x4{0u, 0u, 0u, 0u};
+    c0 = cf;
+    fetch(cf, q0);
+    advance(cf);
+    c1 = cf;
+    if (SSRLCV_THETAS_DEPTH == 2) {
+      fetch(cf, q1);
+      advance(cf);
+    }
+    while (__any(c0.act)) {
       u32x4 cur[kThetaChunk / 2];
 #pragma unroll
-      for (int j = 0; j < kThetaChunk / 2; ++j) cur[j] = nxt[j];
-      // the chunk's coordinates: the reference's `x += 1.0f`, kThetaChunk + 1 times
-      float xs[kThetaChunk + 1];
-      xs[0] = x;
+      for (int j = 0; j < kThetaChunk / 2; ++j) cur[j] = q0[j];
+      const Cursor cc = c0;
+      if (SSRLCV_THETAS_DEPTH == 2) {
 #pragma unroll
-      for (int i = 1; i <= kThetaChunk; ++i) xs[i] = xs[i - 1] + 1.0f;
-      const float cty2 = ty2;
-      const unsigned crow = rowoff;
-      const bool cact = active;
+        for (int j = 0; j < kThetaChunk / 2; ++j) q0[j] = q1[j];
+        c0 = c1;
+        c1 = cf;
+        fetch(cf, q1);
+      } else {
+        c0 = cf;
+        fetch(cf, q0);
+      }
+      advance(cf);
+      // the chunk's coordinates: the reference's `x += 1.0f`, kThetaChunk times
+      float xs[kThetaChunk];
+      xs[0] = cc.x;
+#pragma unroll
+      for (int i = 1; i < kThetaChunk; ++i) xs[i] = xs[i - 1] + 1.0f;
+      const float cty2 = cc.ty2;
+      const unsigned crow = cc.rowoff;
+      const bool cact = cc.act;
       // Entry i of the chunk is the sample's pixel iff llroundf(xs[i]) == llroundf(xs[0]) + i.  In exact arithmetic it
       // is; `+= 1.0f` rounds only when it crosses a binade, the perturbation then stays for the rest of the row, and
       // from x >= 4 a chunk crosses at most one: checking the last entry covers them all.
       const bool aligned = xs[0] >= 4.0f && round_pos(xs[kThetaChunk - 1]) == round_pos(xs[0]) + (kThetaChunk - 1);
-      // next chunk: same row while the reference's loop condition holds, else the next row
-      if (active) {
-        if (xs[kThetaChunk] <= maxx) {
-          x = xs[kThetaChunk];
-        } else {
-          x = minx;
-          y += 1.0f;
-          if (!(y <= maxy)) active = false;
-          ty = y - ky;
-          ty2 = ty * ty;
-          rowoff = (unsigned)round_pos(y) * (unsigned)W + 1u;
-        }
-      }
-      if (active) fetch(x, rowoff);
       // Two phases per chunk.  (1) The eight samples' Gaussian weights and bins are independent of each other and of the
       // histogram: evaluated together they overlap their long dependent chains (the f64 Horner steps, the divisions) --
       // a lone wave, all the short octaves ever have, otherwise spends most of its time waiting on its own results.
