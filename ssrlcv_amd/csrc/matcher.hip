@@ -46,12 +46,6 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int kKPad = 144;       // fp16 elements per packed row
 constexpr int kKSteps = 9;       // 144 / 16
-#ifndef SSRLCV_MATCH_F16_LDS
-#define SSRLCV_MATCH_F16_LDS 0  // measured in round 5: 15.3 ms against 13.1-13.2 (profiles/r05_dogx_ab.txt)
-#endif
-#ifndef SSRLCV_MATCH_F16_ROLLING
-#define SSRLCV_MATCH_F16_ROLLING 0  // measured in round 5: 14.3 ms against 13.2-13.3 (profiles/r05_dogx_ab.txt)
-#endif
 #ifndef SSRLCV_MATCH_F16_ORDER
 #define SSRLCV_MATCH_F16_ORDER 1
 #endif
@@ -631,38 +625,6 @@ __global__ __launch_bounds__(256, SSRLCV_MATCH_WPS) void k_match(const _Float16*
   };
   // The MFMA chain of query tile qt+1 is issued before the epilogue of tile qt: the matrix pipe runs the 9 MFMAs
   // (9 x 32 cycles) while the VALU does the ~20-instruction min tree of the previous accumulator.
-  // process_tile_rolling: the same, and K step s of the NEXT tile is requested into a[s] right behind the last chain's MFMA s
-  // (the last reader of a[s]): the next tile's operands have the last chain and two epilogues of head start on an L2 round trip
-  auto process_tile_rolling = [&](uint32_t tt, half8 (&a)[kKSteps], bool more) {
-    floatx16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1;
-#pragma unroll
-    for (int s = 0; s < kKSteps; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], bq[0][s], acc0, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int qt = 1; qt < kQT; ++qt) {
-      floatx16& cur = (qt & 1) ? acc1 : acc0;
-      floatx16& prev = (qt & 1) ? acc0 : acc1;
-      cur = floatx16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      if (qt == kQT - 1 && more) {  // (wave-uniform)
-        const _Float16* trow = packedT + ((size_t)(tt + 1) * 32 + col) * kKPad + kgrp * 8;
-#pragma unroll
-        for (int s = 0; s < kKSteps; ++s) {
-          cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], bq[qt][s], cur, 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          a[s] = *reinterpret_cast<const half8*>(trow + s * 16);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      } else {
-#pragma unroll
-        for (int s = 0; s < kKSteps; ++s) cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], bq[qt][s], cur, 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      epilogue(tt, qt - 1, prev);
-    }
-    asm volatile("s_nop 15");
-    asm volatile("s_nop 3");
-    epilogue(tt, kQT - 1, ((kQT - 1) & 1) ? acc1 : acc0);
-  };
   auto process_tile = [&](uint32_t tt, const half8 (&a)[kKSteps]) {
     floatx16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1;
 #pragma unroll
@@ -693,8 +655,6 @@ __global__ __launch_bounds__(256, SSRLCV_MATCH_WPS) void k_match(const _Float16*
   // Target tiles stream straight from L2 into registers (all blocks walk the same tiles at about the same time, so
   // the 75 MB target set is served by L2 / Infinity Cache).  Staging them through LDS with one barrier per tile
   // measured 25 % slower at one wave per SIMD.
-  (void)process_tile;
-  (void)process_tile_rolling;
   auto load_tile = [&](uint32_t tt, half8 (&dst)[kKSteps]) {
     const _Float16* trow = packedT + ((size_t)tt * 32 + col) * kKPad + kgrp * 8;
 #pragma unroll
@@ -736,44 +696,10 @@ __global__ __launch_bounds__(256, SSRLCV_MATCH_WPS) void k_match(const _Float16*
 #ifndef SSRLCV_MATCH_DB
 #define SSRLCV_MATCH_DB (SSRLCV_MATCH_WPS < 2)
 #endif
-#if !SSRLCV_MATCH_DB && SSRLCV_MATCH_F16_LDS
-  // Two waves per SIMD, and the NEXT tile in flight: its 9 KB travel by LDS-DMA (global_load_lds: no registers; a second
-  // register buffer would not fit beside four resident query tiles) into the wave's own slot while this tile's 36 MFMAs
-  // and epilogues run; a tile is read from the slot into registers right before its chains and the next transfer is queued
-  // behind those reads.  Lane l's 16 bytes of K step s land at slot[s][l] and are read back by the same lane: no
-  // conflicts, no barrier.  (With plain loads at the top of the tile the partner wave's 1 152 MFMA cycles did not cover
-  // an L2 round trip: the matrix pipe was 57 % busy.)
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  __shared__ u32x4 s_tile[kWaves][kKSteps * 64];
-  u32x4* slot = s_tile[wave];
-  auto dma_tile = [&](uint32_t tt) {
-    const _Float16* trow = packedT + ((size_t)tt * 32 + col) * kKPad + kgrp * 8;
-#pragma unroll
-    for (int s2 = 0; s2 < kKSteps; ++s2)
-      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(trow + s2 * 16),
-                                       (void __attribute__((address_space(3)))*)(slot + s2 * 64), 16, 0, 0);
-  };
-  if (tile0 < tile1) dma_tile(tile0);
-  for (uint32_t tt = tile0; tt < tile1; ++tt) {
-    half8 a[kKSteps];
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the tile has landed
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int s2 = 0; s2 < kKSteps; ++s2) a[s2] = __builtin_bit_cast(half8, slot[s2 * 64 + lane]);
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the slot has been read before the next transfer may write it
-    asm volatile("" ::: "memory");
-    if (tt + 1 < tile1) dma_tile(tt + 1);
-    process_tile(tt, a);
-  }
-#elif !SSRLCV_MATCH_DB && SSRLCV_MATCH_F16_ROLLING
-  // two waves per SIMD, one register buffer that the next tile enters K step by K step behind the last chain
-  if (tile0 < tile1) {
-    half8 a[kKSteps];
-    load_tile(tile0, a);
-    for (uint32_t tt = tile0; tt < tile1; ++tt) process_tile_rolling(tt, a, tt + 1 < tile1);
-  }
-#elif !SSRLCV_MATCH_DB
-  // two waves per SIMD: the partner wave hides the load latency, one register buffer suffices
+#if !SSRLCV_MATCH_DB
+  // two waves per SIMD: the partner wave hides the load latency, one register buffer suffices.  (Round 5 measured two ways of
+  // having the next tile in flight -- LDS-DMA into a per-wave slot, and K step by K step behind the last chain -- both exact,
+  // both slower: 15.3 / 14.3 ms against 13.2, profiles/r05_dogx_ab.txt; the code is in the history.)
   for (uint32_t tt = tile0; tt < tile1; ++tt) {
     half8 a[kKSteps];
     load_tile(tt, a);
