@@ -699,7 +699,7 @@ __global__ __launch_bounds__(256, SSRLCV_MATCH_WPS) void k_match(const _Float16*
 #if !SSRLCV_MATCH_DB
   // two waves per SIMD: the partner wave hides the load latency, one register buffer suffices.  (Round 5 measured two ways of
   // having the next tile in flight -- LDS-DMA into a per-wave slot, and K step by K step behind the last chain -- both exact,
-  // both slower: 15.3 / 14.3 ms against 13.2, profiles/r05_dogx_ab.txt; the code is in the history.)
+  // both slower: 15.3 / 14.3 ms against 13.2, profiles/r05_kernel_ab.txt; the code is in the history.)
   for (uint32_t tt = tile0; tt < tile1; ++tt) {
     half8 a[kKSteps];
     load_tile(tt, a);

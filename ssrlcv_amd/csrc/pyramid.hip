@@ -339,7 +339,7 @@ __global__ __launch_bounds__(kTX) void k_gauss_fused(ConvArgs a) {
 // k_upsample2x_u8x4): 0.25 * (p[ym][xm] + p[ym][xp'] + p[yp'][xm] + p[yp'][xp']), with the mirror of the convolution
 // applied to the upsampled coordinates first.
 #ifndef SSRLCV_STRIP_VGPR_WEIGHTS
-#define SSRLCV_STRIP_VGPR_WEIGHTS 0  // measured in round 5: 178 -> 182 us per image over the 17-tap launches (profiles/r05_dogx_ab.txt)
+#define SSRLCV_STRIP_VGPR_WEIGHTS 0  // measured in round 5: 178 -> 182 us per image over the 17-tap launches (profiles/r05_kernel_ab.txt)
 #endif
 template <int R, bool UPS>
 __global__ __launch_bounds__(kTX) void k_gauss_strip(ConvArgs a) {
@@ -2371,7 +2371,7 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
         if (deferDog0 && as && o == deferDog0) {
           // Developer build, SSRLCV_DOGX0_AFTER=n: octave 0's DoG pass (no one in this stage waits for it) is held back until
           // level 3 of octave n is through, so that the octaves that do have successors get the machine first.  Exact, measured
-          // and NOT the default: build_dog 1.70 -> 1.76 ms per 4096^2 image for n = 1 and 2 (profiles/r05_dogx_ab.txt)
+          // and NOT the default: build_dog 1.70 -> 1.76 ms per 4096^2 image for n = 1 and 2 (profiles/r05_kernel_ab.txt)
           const svp::OctavePlan& o0 = plan->oct[0];
           const float* lv0[svp::kGauss];
           for (int q = 0; q < svp::kGauss; ++q) lv0[q] = (const float*)(ws + plan->off_gauss[0][q]);
