@@ -1703,7 +1703,26 @@ int stage_sampling_pipelined(const ssrlcv_sift_plan* plan, char* ws, ssrlcv_sift
   return SSRLCV_OK;
 }
 
+// the list chain of one octave (S8 tail - S12) up to the plan's stop stage, on `s`
+int run_list_chain(const ssrlcv_sift_plan* plan, char* ws, int o, hipStream_t s) {
+  const int stop = plan->stopStage;
+  const ListCtx c = make_ctx(plan, ws, o, s);
+  int rc = stage_extrema(c, stop >= 1);
+  if (!rc && stop >= 2) rc = stage_refine(c);
+  // stages 3-5 (noise, edges, window check) collapse into one discard when the run goes past them: the three tests are
+  // independent per key point and the compaction is stable
+  if (!rc && stop >= 5) rc = stage_noise_edges_window(c);
+  else {
+    if (!rc && stop >= 3) rc = stage_noise(c, svp::kNoiseThreshold);
+    if (!rc && stop >= 4) rc = stage_edges(c);
+  }
+  return rc;
+}
+
 }  // namespace
+namespace svp {
+int launch_chain_octave(const ssrlcv_sift_plan* plan, char* ws, int octave, hipStream_t st) { return run_list_chain(plan, ws, octave, st); }
+}  // namespace svp
 extern "C" {
 
 int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrlcv_sift_feature* features,
@@ -1735,22 +1754,19 @@ int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrl
   for (int o = 0; o < svp::kOctaves; ++o) {
     // octave 1's chain on one side stream, those of octaves 2 and 3 one after the other on a second (round 3: the three
     // short chains in a row on one stream, ~25 launch-bound kernels each, ended after the polar tables)
-    const ListCtx c = make_ctx(plan, ws, o, !as || o == 0 ? caller : (o == 1 ? as->chain : as->chain2));
-    int rc = stage_extrema(c, stop >= 1);
-    if (!rc && stop >= 2) rc = stage_refine(c);
-    // stages 3-5 (noise, edges, window check) collapse into one discard when the run goes past them: the three tests are
-    // independent per key point and the compaction is stable
-    if (!rc && stop >= 5) rc = stage_noise_edges_window(c);
-    else {
-      if (!rc && stop >= 3) rc = stage_noise(c, svp::kNoiseThreshold);
-      if (!rc && stop >= 4) rc = stage_edges(c);
+    const hipStream_t cs = !as || o == 0 ? caller : (o == 1 ? as->chain : as->chain2);
+    // (bit o of chain0InFlight: the octave's chain is already in flight on `chain2`, queued by build_dog of the same fused extract
+    // behind that octave's DoG pass: the in-order stream runs it in front of the chains of octaves 2-3, whose join event covers it)
+    if (!((plan->chain0InFlight >> o) & 1)) {
+      const int rc = run_list_chain(plan, ws, o, cs);
+      if (rc) return rc;
     }
-    if (rc) return rc;
     if (as && (o == 1 || o == svp::kOctaves - 1)) {  // the side streams are in order: their last events join them
-      SSRLCV_HIP_TRY(hipEventRecord(as->join[o], c.s));
+      SSRLCV_HIP_TRY(hipEventRecord(as->join[o], cs));
       SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->join[o], 0));
     }
   }
+  plan->chain0InFlight = 0;
   if (as) {  // the polar stream joins too (its tables are read by the sampling kernels below)
     SSRLCV_HIP_TRY(hipEventRecord(as->join[svp::kOctaves], (svp::stream_priority_mode() & 1) ? as->polar : as->table));
     SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->join[svp::kOctaves], 0));

@@ -1261,6 +1261,9 @@ template <int NPX, int first, int last, int mmFirst, bool orFlags>
 #ifndef SSRLCV_DOGX_VGPR_MIN
 #define SSRLCV_DOGX_VGPR_MIN 0
 #endif
+#ifndef SSRLCV_EARLY_CHAIN0
+#define SSRLCV_EARLY_CHAIN0 1  // mask of the octaves whose list chain a fused extract starts from inside build_dog
+#endif
 #ifndef SSRLCV_DOGX_RING
 #define SSRLCV_DOGX_RING 1
 #endif
@@ -2059,6 +2062,7 @@ int ssrlcv_sift_plan_create(uint32_t w, uint32_t h, const ssrlcv_sift_params* pa
   p->stopStage = 7;
   p->fusedCall = 0;
   p->polarInFlight = 0;
+  p->chain0InFlight = 0;
   p->stageEvent = nullptr;
   p->async = nullptr;
   p->asyncState = 0;
@@ -2398,6 +2402,22 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
     else rc = launch_dogx(lv, mm, oc.w, oc.h, flags, mm + 2 * svp::kGauss, dogPartial, 0, svp::kDog, 0, false, firstNoise, sched.waves, sdo);
     if (rc) return rc;
     if (as) SSRLCV_HIP_TRY(hipEventRecord(as->dogDone[o], sdo));
+#if SSRLCV_EARLY_CHAIN0
+    // Fused extract (round 5): octave 0's list chain (60 % of the key points: ~0.3 ms of small launches) starts behind its DoG
+    // pass on the one side stream build_dog does not use, beside the latency-bound tail of the small octaves, instead of
+    // beside the HBM-bound gradient tables at the head of the key-point stage.  Exact (tests/test_gpu_sift.py); bench step
+    // 9.99 / 10.00 -> 9.86 / 9.92 ms: the scale-space stage as the stage event sees it grows by 0.07 ms per 4096^2 image (its
+    // tail shares the machine now), the key-point stage shrinks by 0.13.  Octave 1's chain as well (mask 3: 10.19 / 10.25)
+    // or all four (mask 15: 10.27 / 10.26) lose: behind octave 0's chain on the same stream they give up their own.
+    // Developer build: SSRLCV_NO_EARLY_CHAIN=1 keeps every chain in describe.
+    static const bool noEarlyChain = svdev::env("SSRLCV_NO_EARLY_CHAIN") != nullptr;
+    if (as && !noEarlyChain && ((SSRLCV_EARLY_CHAIN0 >> o) & 1) && plan->fusedCall && plan->stopStage >= 6) {
+      SSRLCV_HIP_TRY(hipStreamWaitEvent(as->chain2, as->dogDone[o], 0));
+      rc = svp::launch_chain_octave(plan, ws, o, as->chain2);
+      if (rc) return rc;
+      plan->chain0InFlight |= 1 << o;
+    }
+#endif
     if (earlyPolar) {  // fused extract: this octave's gradient tables start now, on their own stream
       SSRLCV_HIP_TRY(hipStreamWaitEvent(as->polar, as->dogDone[o], 0));
       svp::launch_polar_octave(plan, ws, o, as->polar);

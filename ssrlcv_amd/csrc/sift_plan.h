@@ -128,6 +128,7 @@ struct ssrlcv_sift_plan {
   // launching them.  The stand-alone stage calls keep their stream-ordered contract: nothing of theirs is left in flight.
   mutable int fusedCall;          // set by extract around its two stage calls
   mutable int polarInFlight;      // build_dog has queued the polar tables (events polarDone[])
+  mutable int chain0InFlight;     // bit o: build_dog has queued octave o's list chain on `chain2` (see SSRLCV_EARLY_CHAIN0)
   mutable hipEvent_t stageEvent;  // nullable: recorded by extract on the caller's stream between the two stages
   mutable svp::PlanAsync* async;  // created on first use (needs a device); see svp::plan_async
   mutable int asyncState;         // 0 not tried, 1 ready, -1 serial (SSRLCV_SIFT_SERIAL set or creation failed)
@@ -139,4 +140,6 @@ PlanAsync* plan_async(const ssrlcv_sift_plan* plan);
 int stream_priority_mode();  // developer build: SSRLCV_PRIO (0 in the release build)
 // k_polar (keypoints.hip) for ONE octave on `st`: the gradient tables of its DoG levels 1..3
 void launch_polar_octave(const ssrlcv_sift_plan* plan, char* ws, int octave, hipStream_t st);
+// the list chain (S8 tail - S12, keypoints.hip) of ONE octave on `st`, up to the plan's stop stage
+int launch_chain_octave(const ssrlcv_sift_plan* plan, char* ws, int octave, hipStream_t st);
 }  // namespace svp

@@ -390,6 +390,7 @@ print("FEATURES OK")
     {"SSRLCV_SAMPLING_PIPELINED": "1", "SSRLCV_SAMPLING_IRREGULAR": "1"},  # ... its fallback for blur indices that are not an ordered partition
     {"SSRLCV_EARLY_POLAR": "1"},                                           # gradient tables started from inside build_dog (fused extract)
     {"SSRLCV_EARLY_POLAR": "1", "SSRLCV_SAMPLING_PIPELINED": "1"},
+    {"SSRLCV_NO_EARLY_CHAIN": "1"},                                        # octave 0's list chain in describe instead of behind its DoG pass
     {"SSRLCV_PHASED": "1"}, {"SSRLCV_PHASED": "2"},                        # build_dog: the octave chain on one stream, levels 4-5 + DoG passes beside it
 ], ids=lambda v: "+".join(k.replace("SSRLCV_", "") + "=" + x for k, x in v.items()))
 def test_every_sampling_schedule_is_bit_exact(variant):
