@@ -628,7 +628,8 @@ def main():
                                    "that forms the 5 DoG levels in registers, reduces their min / max and finds the extrema: the "
                                    "DoG levels are never written); algorithmic bytes = B_pyr = 362.25*W*H per image (SURVEY 8d, S1-S7); "
                                    "the stage is timed inside the fused ssrlcv_hip_sift_extract: HIP events on the launching stream, the one between "
-                                   "the two stages recorded by the library itself (ssrlcv_sift_plan_set_stage_event)",
+                                   "the two stages recorded by the library itself (ssrlcv_sift_plan_set_stage_event); since round 5 octave 0's key-point list chain "
+                                   "runs beside the end of this stage (see stage_alone)",
                          "algorithmic_bytes": b_pyr,
                          "frac_s1_s8": (b_pyr + b_ext) / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes_s1_s8": b_pyr + b_ext,
