@@ -1,7 +1,8 @@
 
 """Kernel timeline of the last image of a `rocprofv3 --kernel-trace` run of bench.py (rocpd .db output): start, end,
 duration (us), stream and kernel name, so that overlaps and waits between streams can be read off.
-usage: timeline.py <results.db> [max_rows]"""
+usage: timeline.py <results.db> [max_rows] [back]      back = which build_dog from the end (1 = the last one; bench.py ends with
+14 stand-alone build_dog calls -- its stage_alone timing -- so the last fused image of its timed loop is back = 15)"""
 import sqlite3
 import sys
 
@@ -17,7 +18,8 @@ def main():
     rows = c.execute("select name,start,end,stream_id from kernels order by start").fetchall()
     # every build_dog call starts with k_init_minmax
     ups = [i for i, r in enumerate(rows) if "k_init_minmax" in r[0]]
-    i0 = ups[-1]
+    back = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    i0 = ups[-back]
     t0 = rows[i0][1]
     for r in rows[i0:i0 + lim]:
         if "k_pack_i8" in r[0] or "k_match" in r[0]:
