@@ -2246,6 +2246,7 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
   static const bool wantEarlyPolar = svdev::env("SSRLCV_EARLY_POLAR") != nullptr;
   const bool earlyPolar = as && plan->fusedCall && plan->stopStage >= 6 && wantEarlyPolar;
   plan->polarInFlight = 0;
+  plan->chain0InFlight = 0;  // (a describe that failed half-way may have left it set)
   if (earlyPolar) {  // the tables may still be read by the sampling kernels of the previous extract on this plan: behind the caller's stream
     SSRLCV_HIP_TRY(hipEventRecord(as->fork, st));
     SSRLCV_HIP_TRY(hipStreamWaitEvent(as->polar, as->fork, 0));
