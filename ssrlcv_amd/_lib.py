@@ -30,6 +30,14 @@ class HipExtensionMissing(RuntimeError):
     pass
 
 
+class HipAbiMismatch(RuntimeError):
+    pass
+
+
+# the SSRLCV_HIP_ABI_VERSION of include/ssrlcv_hip.h this package's ctypes signatures (capi.py) were written against
+ABI_VERSION = 3
+
+
 def load():
     global _lib
     if _lib is None:
@@ -37,7 +45,14 @@ def load():
             raise HipExtensionMissing(
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
                 "`make -C ssrlcv_amd/csrc all release` (there is no CPU fallback)" % LIB_PATH)
-        _lib = ctypes.CDLL(LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        # refuse a library of another ABI before the first call into it (a build from before the entry point existed has
+        # no ssrlcv_hip_abi_version at all)
+        got = lib.ssrlcv_hip_abi_version() if hasattr(lib, "ssrlcv_hip_abi_version") else 1
+        if got != ABI_VERSION:
+            raise HipAbiMismatch("%s has ABI version %d, this package binds version %d (include/ssrlcv_hip.h "
+                                 "SSRLCV_HIP_ABI_VERSION): rebuild the library" % (LIB_PATH, got, ABI_VERSION))
+        _lib = lib
         _lib.ssrlcv_hip_version.restype = ctypes.c_char_p
         _lib.ssrlcv_hip_status_string.restype = ctypes.c_char_p
         for name in ("ssrlcv_hip_match_workspace_bytes", "ssrlcv_sift_plan_workspace_bytes",
@@ -50,7 +65,7 @@ def load():
 
 # every symbol include/ssrlcv_hip.h declares (checked by tests/test_capi_symbols.py without a GPU)
 EXPORTED = [
-    "ssrlcv_hip_version", "ssrlcv_hip_status_string",
+    "ssrlcv_hip_abi_version", "ssrlcv_hip_version", "ssrlcv_hip_status_string",
     "ssrlcv_hip_device_count", "ssrlcv_hip_malloc", "ssrlcv_hip_free", "ssrlcv_hip_host_malloc",
     "ssrlcv_hip_host_free", "ssrlcv_hip_memcpy", "ssrlcv_hip_memset", "ssrlcv_hip_device_synchronize",
     "ssrlcv_hip_generate_bundles", "ssrlcv_hip_generate_pushbroom_bundles", "ssrlcv_hip_triangulate2",

@@ -456,11 +456,7 @@ __device__ __forceinline__ float fmod_2pi_above(float v, float p) { return v >= 
 // pixel (x, y) of a polar table by its flat index y * W + x (-1 .. W*H + W: see svp::polar_level_stride; `pl` points at
 // flat index 0): the index fits 32 bits for any level up to 32768^2, which keeps the multiply 32-bit
 __device__ __forceinline__ float2 polar_px(const float2* __restrict__ pl, int W, int x, int y) {
-#ifdef SSRLCV_LAB_LOCAL_GATHER  // timing lab (results invalid): every gather hits the same 32 KB -- what is left is the kernel without its table traffic
-  return pl[(y * W + x) & 4095];
-#else
   return pl[y * W + x];
-#endif
 }
 // llroundf of a window coordinate v > -1: v_cvt_rpi_i32_f32 is floor(v + 0.5) evaluated exactly (tools/f64_rate.hip:
 // equal to round-half-up for every float in (-1, 2^31)), which is llroundf except at v == -0.5 (half away from zero)
@@ -696,11 +692,7 @@ __global__ __launch_bounds__(64) void k_thetas(const OctaveState* states, const 
     typedef u32x4 Chunk[kThetaChunk / 2];
     auto fetch = [&](const Cursor& c, Chunk& into) {
       if (!c.act) return;
-#ifdef SSRLCV_LAB_LOCAL_GATHER
-      const unsigned off = ((c.rowoff + (unsigned)round_pos(c.x)) & 4095u) * 8u;
-#else
       const unsigned off = (c.rowoff + (unsigned)round_pos(c.x)) * 8u;  // byte offset, below 2^32
-#endif
 #pragma unroll
       for (int j = 0; j < kThetaChunk / 2; ++j) into[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off + 16u * j), 0, 0);
     };

@@ -195,13 +195,15 @@ struct ConvArgs {
   // k_gauss_mfma2 / k_gauss_tile: also emit the 2x2 bin of the output (S5, the next octave's input) from the accumulators
   float* binOut;  // (w/2) x (h/2), nullptr: no bin
   float wgt[33];  // taps are symmetric (w[k] == w[2R-k] bit for bit): only k = 0..R travel, in SGPRs
-#ifdef SSRLCV_LAB
+#ifdef SSRLCV_STAMPS
   long long* stamps;  // tools/gauss_lab.hip: s_memtime stamps of one block, [wave][step][8]
 #endif
 };
-#ifdef SSRLCV_LAB
+// Instrumentation (results unchanged): -DSSRLCV_STAMPS builds write s_memtime stamps of one block into a buffer of their own.
+// Only the tools/ lab programs build that way (csrc/dev_switch.h refuses the define in a library build).
+#ifdef SSRLCV_STAMPS
 long long* g_lab_stamps = nullptr;
-#define LAB_STAMP(slot)                                                                                   \
+#define SV_STAMP(slot)                                                                                   \
   do {                                                                                                    \
     if (a.stamps && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && it < 64) {              \
       const long long t_ = (long long)__builtin_amdgcn_s_memtime();                                       \
@@ -209,7 +211,7 @@ long long* g_lab_stamps = nullptr;
     }                                                                                                     \
   } while (0)
 #else
-#define LAB_STAMP(slot) do { } while (0)
+#define SV_STAMP(slot) do { } while (0)
 #endif
 
 constexpr int kTX = 256;  // strip width = threads per block
@@ -411,14 +413,10 @@ __global__ __launch_bounds__(kTX) void k_gauss_strip(ConvArgs a) {
     const uint8_t* r0 = a.u8 + (size_t)ym * uw;
     const uint8_t* r1 = a.u8 + (size_t)yp * uw;
     r.p0 = *reinterpret_cast<const uint16_t*>(r0 + c0);
-#ifdef SSRLCV_LAB_UPS_LOADS  // timing lab (results invalid): one of the eight byte loads per row
-    r.p1 = r.p0; r.q0 = r.q1 = 0; (void)r1;
-#else
     r.p1 = *reinterpret_cast<const uint16_t*>(r1 + c0);
     r.q0 = r0[c2];
     r.q1 = r1[c2];
     if (halo) { r.h00 = r0[hxm]; r.h01 = r0[hxp]; r.h10 = r1[hxm]; r.h11 = r1[hxp]; }
-#endif
   };
   auto up_convert = [&](const RawRow& r, float4& o, float& oh) {
     const uint32_t a0 = (r.p0 & 255u) + (r.p1 & 255u), a1 = (r.p0 >> 8) + (r.p1 >> 8), a2 = r.q0 + r.q1;
@@ -794,7 +792,7 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma2(ConvArgs a) {
   __syncthreads();
   int tphase = NT - 1;  // ((it - 1) mod NT) for it = 0
   for (int it = 0; it <= steps; ++it) {
-    LAB_STAMP(0);
+    SV_STAMP(0);
     const int tnext = tphase + 1 == NT ? 0 : tphase + 1;  // (it mod NT) = tphase of step it + 1
     if (role == 0) {
       if (it < steps) {
@@ -819,19 +817,19 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma2(ConvArgs a) {
           for (int t4 = 0; t4 < TPW; ++t4) acc[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks % 3][t4], tz[ks], acc[t4], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
-        LAB_STAMP(1);
+        SV_STAMP(1);
 #pragma unroll
         for (int t4 = 0; t4 < TPW; ++t4) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) lds_st(hRow[r] + (unsigned)(t4 * 16) * 4u, acc[t4][r]);
         }
-        LAB_STAMP(2);
+        SV_STAMP(2);
         if (it + 1 < steps) {
           stage_write(sRow, gRow);
-          LAB_STAMP(3);
+          SV_STAMP(3);
           if (it + 2 < steps) fetch(it + 2);
         }
-        LAB_STAMP(4);
+        SV_STAMP(4);
         if (it + 1 < steps) h_addresses(it + 1, tnext);
       }
     } else {
@@ -855,13 +853,13 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma2(ConvArgs a) {
           for (int t4 = 0; t4 < TPW; ++t4) pend[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[ks % 3][t4], tz[ks], pend[t4], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
-        LAB_STAMP(1);
+        SV_STAMP(1);
         pendJ = jbase;
         store_pending();
       }
-      LAB_STAMP(2);
+      SV_STAMP(2);
       if (it < steps) v_addresses(tnext);
-      LAB_STAMP(3);
+      SV_STAMP(3);
     }
     tphase = tnext;
     __syncthreads();
@@ -870,6 +868,7 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma2(ConvArgs a) {
 }
 
 #include "gauss_rm.inc"
+#include "gauss_pair.inc"
 
 // ---- S4 for the small levels: one tile per block, no marching ---------------------------------------------------------
 // The marching kernels pay a 2R-row warm-up and one barrier per 8 or 16 rows; a 1024^2 or 2048^2 level gives them 64 to
@@ -1637,6 +1636,11 @@ size_t& rm_min_px() {
   static size_t v = svdev::env("SSRLCV_GAUSS_RM_MINPX") ? (size_t)atoll(svdev::env("SSRLCV_GAUSS_RM_MINPX")) : ((size_t)1 << 24);
   return v;
 }
+// which radii take the one-barrier form of the register-marching kernel (two H buffers, see RmCfg): same bits as rm_mask()
+int& rm_oneb_mask() {
+  static int m = svdev::env("SSRLCV_GAUSS_RM_ONEB") ? atoi(svdev::env("SSRLCV_GAUSS_RM_ONEB")) : 0;
+  return m;
+}
 int& rm_rows() {
   static int r = svdev::env("SSRLCV_GAUSS_RM_ROWS") ? atoi(svdev::env("SSRLCV_GAUSS_RM_ROWS")) : 0;
   return r;
@@ -1663,7 +1667,7 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
   if (binned) *binned = false;
   static const bool noBinFold = svdev::env("SSRLCV_NO_BIN_FUSION") != nullptr;
   const bool canBin = binOut && !noBinFold && (w & 3) == 0 && (h & 1) == 0 && (reinterpret_cast<size_t>(binOut) & 7) == 0;
-#ifdef SSRLCV_LAB
+#ifdef SSRLCV_STAMPS
   a.stamps = g_lab_stamps;
 #endif
   a.u8 = u8src;
@@ -1727,17 +1731,17 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
     if (canBin && cov == w) { r.binOut = binOut; if (binned) *binned = true; }
     memset(r.wgt, 0, sizeof r.wgt);
     for (int k = 0; k <= R; ++k) r.wgt[(R2 - R) + k] = weights_host[k];
-#define SSRLCV_LAUNCH_RM(RR)                                                                                        \
+#define SSRLCV_LAUNCH_RM_V(RR, OB)                                                                                  \
   do {                                                                                                              \
+    constexpr size_t ldsB = OB ? RmCfg<RR>::ldsBytesOneB : RmCfg<RR>::ldsBytes;                                    \
     static int blocksPerCu = 0, cus = 0;                                                                            \
     if (!blocksPerCu) {                                                                                             \
-      SSRLCV_HIP_TRY(hipFuncSetAttribute((const void*)k_gauss_rm<RR>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                         (int)RmCfg<RR>::ldsBytes));                                                \
+      SSRLCV_HIP_TRY(hipFuncSetAttribute((const void*)k_gauss_rm<RR, OB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         (int)ldsB));                                                               \
       int dev = 0, occ = 0;                                                                                         \
       SSRLCV_HIP_TRY(hipGetDevice(&dev));                                                                           \
       SSRLCV_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));                      \
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_gauss_rm<RR>, 256,                    \
-                                                       RmCfg<RR>::ldsBytes) != hipSuccess || occ < 1)               \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_gauss_rm<RR, OB>, 256, ldsB) != hipSuccess || occ < 1) \
         occ = 1;                                                                                                    \
       blocksPerCu = occ;                                                                                            \
     }                                                                                                               \
@@ -1747,7 +1751,12 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
     if (rmRows > 0) rows = (uint32_t)rmRows;                                                                        \
     rows = (rows + 15) / 16 * 16;                                                                                   \
     r.rowsPerBlock = rows;                                                                                          \
-    hipLaunchKernelGGL(k_gauss_rm<RR>, dim3(nS, (h + rows - 1) / rows), dim3(256), RmCfg<RR>::ldsBytes, st, r); \
+    hipLaunchKernelGGL((k_gauss_rm<RR, OB>), dim3(nS, (h + rows - 1) / rows), dim3(256), ldsB, st, r);              \
+  } while (0)
+#define SSRLCV_LAUNCH_RM(RR)                                  \
+  do {                                                        \
+    if (rm_oneb_mask() & r2bit) SSRLCV_LAUNCH_RM_V(RR, true); \
+    else SSRLCV_LAUNCH_RM_V(RR, false);                       \
   } while (0)
     switch (R2) {
       case 6: SSRLCV_LAUNCH_RM(6); break;
@@ -1758,6 +1767,7 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
       default: SSRLCV_LAUNCH_RM(32); break;
     }
 #undef SSRLCV_LAUNCH_RM
+#undef SSRLCV_LAUNCH_RM_V
     if (cov < w) launch_valu(a, RT, cov, st);
     SSRLCV_LAUNCH_CHECK();
     return SSRLCV_OK;

@@ -28,6 +28,23 @@ inline void __hipSafeCall(int status, const char* file, const int line) {
 #define CudaSafeCall(err) HipSafeCall(err)
 #define CudaCheckError() HipCheckError()
 
+// ABI check (round 6): the mirror was compiled against SSRLCV_HIP_ABI_VERSION of include/ssrlcv_hip.h; a library built from
+// another revision of that header is refused before the first call that touches the device (every allocation of the
+// mirror goes through detail::blockCache(), whose constructor calls this).  Same convention as a failed device call:
+// logger.err + exit(-1).
+inline void requireAbi() {
+  static const bool ok = [] {
+    const int got = ssrlcv_hip_abi_version();
+    if (got != SSRLCV_HIP_ABI_VERSION) {
+      logger.err.printf("libssrlcv_hip reports ABI version %d (%s), these headers are version %d: rebuild one of them", got,
+                        ssrlcv_hip_version(), SSRLCV_HIP_ABI_VERSION);
+      std::exit(-1);
+    }
+    return true;
+  }();
+  (void)ok;
+}
+
 // Size-class cache of device and pinned-host blocks.  The reference's Unity<T> allocates and frees on every memory-state
 // change (setMemoryState is "hard": it frees the side it leaves), which its factories do around every call -- image
 // up, image back to its origin state, exact-size result lists.  cudaMalloc / cudaMallocHost of 16..50 MB cost
@@ -43,7 +60,7 @@ class BlockCache {
   bool enabled;
 
  public:
-  BlockCache() : enabled(std::getenv("SSRLCV_NO_BLOCK_CACHE") == nullptr) {}
+  BlockCache() : enabled(std::getenv("SSRLCV_NO_BLOCK_CACHE") == nullptr) { requireAbi(); }
   ~BlockCache() {  // process exit: the runtime may already be gone, so return codes are not checked
     for (int k = 0; k < 3; ++k)
       for (auto& e : freeList[k])

@@ -165,3 +165,48 @@ def test_matcher_kernels_register_budget():
     assert brute[0]["ScratchSize [bytes/lane]"] == 0 and brute[0]["VGPRs"] <= 256 and brute[0]["Occupancy [waves/SIMD]"] == 2
     assert seed[0]["ScratchSize [bytes/lane]"] == 0 and seed[0]["Occupancy [waves/SIMD]"] == 2
     assert band[0]["ScratchSize [bytes/lane]"] == 0 and band[0]["Occupancy [waves/SIMD]"] == 5, band[0]
+
+
+_WRONG_ABI_STUB = r"""
+int ssrlcv_hip_abi_version(void) { return 999; }
+const char* ssrlcv_hip_version(void) { return "stub (abi 999)"; }
+const char* ssrlcv_hip_status_string(int s) { (void)s; return "stub"; }
+"""
+
+
+def _wrong_abi_library(tmp_path):
+    import subprocess
+    src = tmp_path / "stub.c"
+    src.write_text(_WRONG_ABI_STUB)
+    so = tmp_path / "libssrlcv_hip_release.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)])
+    return so
+
+
+def test_library_of_another_abi_version_is_refused(tmp_path):
+    """include/ssrlcv_hip.h SSRLCV_HIP_ABI_VERSION is bumped on every signature / layout change.  Both binders compare
+    it with what the library they loaded reports before the first real call: the Python loader raises HipAbiMismatch, the
+    C++ mirror logs and exits(-1) (host/Memory.hpp requireAbi, reached from the first allocation)."""
+    import subprocess
+    import sys
+    from ssrlcv_amd import _lib
+    header = open(os.path.join(ROOT, "include", "ssrlcv_hip.h")).read()
+    declared = int(re.search(r"#define SSRLCV_HIP_ABI_VERSION (\d+)", header).group(1))
+    assert declared == _lib.ABI_VERSION == _lib.load().ssrlcv_hip_abi_version()
+    assert ("abi %d" % declared).encode() in _lib.load().ssrlcv_hip_version()
+    so = _wrong_abi_library(tmp_path)
+    probe = ("import sys; sys.path.insert(0, %r)\nfrom ssrlcv_amd import _lib\n"
+             "try:\n    _lib.load()\nexcept _lib.HipAbiMismatch as e:\n    print('refused:', e)\n" % ROOT)
+    out = subprocess.check_output([sys.executable, "-c", probe], env=dict(os.environ, SSRLCV_HIP_LIB=str(so)), text=True)
+    assert "refused:" in out and "ABI version 999" in out and "version %d" % declared in out
+    # the C++ mirror: a program that only allocates, linked against the stub
+    cpp = tmp_path / "abi_probe.cpp"
+    cpp.write_text('#include "Unity.hpp"\nint main() { ssrlcv::ptr::device<float> d(16); return d.get() ? 0 : 1; }\n')
+    exe = tmp_path / "abi_probe"
+    host = os.path.join(ROOT, "ssrlcv_amd", "host")
+    subprocess.check_call(["g++", "-O0", "-std=c++14", "-I" + os.path.join(ROOT, "include"), "-I" + host, "-o", str(exe), str(cpp),
+                           "-L" + str(tmp_path), "-lssrlcv_hip_release", "-Wl,-rpath," + str(tmp_path),
+                           "-Wl,--unresolved-symbols=ignore-all"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 255, (r.returncode, r.stderr)
+    assert "ABI version 999" in r.stderr and "version %d" % declared in r.stderr

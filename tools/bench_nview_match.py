@@ -36,7 +36,7 @@ for _ in range(args.iters):
     times.append((time.perf_counter() - t0) * 1e3)
 times.sort()
 lib = capi.LIB
-if hasattr(lib, "ssrlcv_dbg_match_stats"):  # a -DSSRLCV_MATCH_STATS build (SSRLCV_HIP_LIB=ssrlcv_amd/libssrlcv_hip_stats.so)
+if hasattr(lib, "ssrlcv_dbg_match_stats"):  # a -DSSRLCV_MATCH_STATS build (make -C ssrlcv_amd/csrc instrumented; SSRLCV_HIP_LIB=ssrlcv_amd/libssrlcv_hip_instrumented.so)
     import ctypes
     out = (ctypes.c_ulonglong * 12)()
     lib.ssrlcv_dbg_match_stats(out)  # clear

@@ -1,10 +1,11 @@
 // Developer lab: phase timing inside one block of the marching MFMA Gaussian kernel (s_memtime stamps per wave and step).
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -DSSRLCV_LAB -Iinclude -Issrlcv_amd/csrc \
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -DSSRLCV_STAMPS -DSSRLCV_INSTRUMENTED_BUILD -Iinclude -Issrlcv_amd/csrc \
 //        tools/gauss_lab.hip ssrlcv_amd/csrc/capi_common.hip -o tools/_build/gauss_lab
 // usage: gauss_lab [size=8192] [stamps=0] ; prints, for taps 23/33/47/65, the kernel time and the average cycles between stamps
 // horizontal-role waves: 0 top, 1 after the MFMA loop, 2 after the ring write, 3 after the stage write, 4 after the next fetch
 // vertical-role waves:   0 top, 1 after the store of the previous result, 2 after the MFMA loop
 #include "../ssrlcv_amd/csrc/pyramid.hip"
+#include "lab_stubs.h"
 #include <vector>
 
 int main(int argc, char** argv) {

@@ -4,6 +4,7 @@
 //        tools/gauss_rm_lab.hip ssrlcv_amd/csrc/capi_common.hip -o tools/_build/gauss_rm_lab
 // usage: gauss_rm_lab [width=8192] [height=width] [rowsPerBlock=0]
 #include "../ssrlcv_amd/csrc/pyramid.hip"
+#include "lab_stubs.h"
 #include <vector>
 
 int main(int argc, char** argv) {
@@ -11,6 +12,7 @@ int main(int argc, char** argv) {
   const uint32_t H = argc > 2 ? (uint32_t)atoi(argv[2]) : W;
   rm_rows() = argc > 3 ? atoi(argv[3]) : 0;
   rm_min_px() = 0;
+  rm_oneb_mask() = getenv("RM_LAB_ONEB") ? atoi(getenv("RM_LAB_ONEB")) : 0;
   const size_t n = (size_t)W * H;
   float *in, *outA, *outB, *binA, *binB, *mm;
   hipMalloc(&in, n * 4); hipMalloc(&outA, n * 4); hipMalloc(&outB, n * 4);
@@ -24,7 +26,7 @@ int main(int argc, char** argv) {
   hipEventCreate(&e0); hipEventCreate(&e1);
   const float sigmas[6] = {0.70710678f, 1.0f, 1.41421356f, 2.0f, 2.82842712f, 4.0f};
   std::vector<float> a(n), b(n), ba(n / 4), bb(n / 4);
-#ifdef SSRLCV_LAB
+#ifdef SSRLCV_STAMPS
   long long* stamps;
   const size_t ns = 8 * 64 * 8;
   hipMalloc(&stamps, ns * 8);
@@ -56,7 +58,7 @@ int main(int argc, char** argv) {
       hipEventElapsedTime(&ms[v], e0, e1);
       ms[v] /= 5;
     }
-#ifdef SSRLCV_LAB
+#ifdef SSRLCV_STAMPS
     {  // one more launch of the register-marching kernel with s_memtime stamps (100 MHz ticks) in one block
       hipMemset(stamps, 0, ns * 8);
       g_lab_stamps = stamps;
