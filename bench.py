@@ -384,7 +384,9 @@ def describe_roofline(ms_per_image, features, size):
     little data, so the stage is priced against the VALU issue peak with the wave-instruction count of the committed PMC
     reduction (instructions per feature do not depend on the run; the time does), and its algorithmic bytes against HBM
     beside it.  Per-kernel fractions come from the PMC run's own image and time (profiles/r05_describe_pmc.json)."""
-    path = os.path.join(ROOT, "profiles", "r05_describe_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r06_describe_pmc.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r05_describe_pmc.json")
     out = {"ms_per_image": ms_per_image, "features_per_image": features,
            "ns_per_feature": ms_per_image * 1e6 / max(features, 1),
            "kernels": "flag-byte compaction, k_refine, k_flag_*, list partitions, k_polar, k_thetas, k_desc_consts, k_descriptors "
@@ -408,12 +410,32 @@ def describe_roofline(ms_per_image, features, size):
                                                         "valu_frac": None if v.get("valu_frac") is None else round(v["valu_frac"], 3),
                                                         "hbm_frac": None if v.get("hbm_frac") is None else round(v["hbm_frac"], 3)}
                                                     for k, v in pmc.get("per_kernel", {}).items()},
-                        "pmc_source": "profiles/r05_describe_pmc.json @ %s (its own image: %d features)" % (pmc.get("commit"), pmc.get("features_per_image", 0))})
+                        "pmc_source": "profiles/%s @ %s (its own image: %d features)" % (os.path.basename(path), pmc.get("commit"), pmc.get("features_per_image", 0))})
     return out
 
 
+def checksum64(x):
+    """Order-sensitive 64-bit checksum of a byte buffer (torch tensor on any device, or numpy array): sum of the 32-bit words
+    times an odd, position-dependent multiplier, in wrapping int64 arithmetic.  The N > 1 legs compare it across ranks and with
+    the world-1 value committed under tests/golden/ (the scene and every kernel are deterministic)."""
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(x).view(np.uint8).reshape(-1)) if isinstance(x, np.ndarray) else x.contiguous().view(torch.uint8).reshape(-1)
+    pad = (-t.numel()) % 4
+    if pad:
+        t = torch.cat([t, torch.zeros(pad, dtype=torch.uint8, device=t.device)])
+    w = t.view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    mult = torch.arange(w.numel(), dtype=torch.int64, device=w.device) * 2654435761 + 1
+    return int((w * mult).sum().item()) & 0xFFFFFFFFFFFFFFFF
+
+
+NVIEW_GOLDEN = os.path.join(ROOT, "tests", "golden", "nview_checksums.json")
+
+
 def run_nview(args, torch, dist, capi, world, rank, dev, views, size, steps, warmup):
-    """config[3]: V views, image/pair sharding over the ranks with the RCCL exchanges (ssrlcv_amd/pipeline.py)."""
+    """config[3]: V views, image/pair sharding over the ranks with the RCCL exchanges (ssrlcv_amd/pipeline.py).
+    Every step is timed on its own (the flow ends in host arrays: it is synchronous); the leg reports median / min / max per
+    step and per stage over `steps` >= 6 steps, and says so (`stall`) when the slowest step took more than twice the median --
+    round 5's driver run had a 30 ms host-allocation stall in one of two steps and reported their mean."""
     import helpers as H
     import scene
     from ssrlcv_amd import pipeline
@@ -430,25 +452,38 @@ def run_nview(args, torch, dist, capi, world, rank, dev, views, size, steps, war
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-    for _ in range(warmup):
-        step()
+    # warm-up the way the timed loop runs: the previous result is still alive while the next step is made, so the result
+    # pool (pipeline._result_buffer) needs its second buffer before the clock starts
+    res = None
+    for _ in range(max(warmup, 2)):
+        res = step()
     ws.times.clear()
     barrier()
+    per_step, per_stage = [], []
     t0 = time.perf_counter()
     for _ in range(steps):
+        before = dict(ws.times)
+        ts = time.perf_counter()
         res = step()
+        per_step.append((time.perf_counter() - ts) * 1e3)
+        per_stage.append({k: (v - before.get(k, 0.0)) * 1e3 for k, v in ws.times.items()})
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev if dist is None or dist.get_backend() != "gloo" else "cpu")
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    mine = {k: v / steps * 1e3 for k, v in ws.times.items()}
+    stage_names = list(per_stage[0].keys())
+
+    def stats(vals):
+        return {"median": float(np.median(vals)), "min": float(np.min(vals)), "max": float(np.max(vals))}
+    mine = {k: float(np.median([st[k] for st in per_stage])) for k in stage_names}
+    mine_stats = {k: stats([st[k] for st in per_stage]) for k in stage_names}
+    step_stats = stats(per_step)
     per_rank = [mine]
     if dist is not None:   # every rank's stage times: the spread is the load imbalance (pairs of different cost, images per rank)
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
-    stage_names = list(mine.keys())
     spread = {k: {"min": min(r.get(k, 0.0) for r in per_rank), "max": max(r.get(k, 0.0) for r in per_rank)} for k in stage_names}
     nf = [int(f.numel() // 152) for f in res["features"]]
     owners = sd.assign_pairs(nf, world)
@@ -456,31 +491,135 @@ def run_nview(args, torch, dist, capi, world, rank, dev, views, size, steps, war
     cost = [float(nf[i]) * nf[j] for i, j in pairs]
     load = [sum(c for c, o in zip(cost, owners) if o == r) for r in range(world)]
     step_ms = dt / steps * 1e3
+    # ---- result check: the cloud, the MatchSet and the BA sums of this rank, across ranks and against the world-1 golden
+    sums = res["ba_sums"].detach().float().cpu().numpy() if "ba_sums" in res else np.zeros(0, np.float32)
+    check = {"cloud": checksum64(res["points"]), "multi_matches": checksum64(res["matches"]), "keypoints": checksum64(res["keypoints"]),
+             "ba_sums": checksum64(sums)}
+    all_checks = [check]
+    if dist is not None:
+        all_checks = [None] * world
+        dist.all_gather_object(all_checks, check)
+    same = all(c == all_checks[0] for c in all_checks)
+    key = "views%d_size%d" % (views, size)
+    golden = json.load(open(NVIEW_GOLDEN)) if os.path.exists(NVIEW_GOLDEN) else {}
+    g = golden.get(key)
+    exact = ("cloud", "multi_matches", "keypoints")  # the BA sums are float sums in a sharding-dependent order: compared by value
+    result_check = {"checksums": {k: "%016x" % v for k, v in check.items()}, "equal_across_ranks": same,
+                    "golden": "tests/golden/nview_checksums.json[%s]" % key if g else None,
+                    "equal_to_world1": None if not g else all(("%016x" % check[k]) == g[k] for k in exact),
+                    "ba_sums_max_rel_dev_from_world1": None if not g or not len(sums) else float(np.max(np.abs(sums[:len(g["ba_sums_head"])] - np.array(g["ba_sums_head"], np.float32)) /
+                                                                                                   np.maximum(np.abs(np.array(g["ba_sums_head"], np.float32)), 1e-30))),
+                    "bundles": int(len(res["matches"])), "points": int(res["points"].shape[0])}
+    if rank == 0 and world == 1 and os.environ.get("SSRLCV_WRITE_NVIEW_GOLDEN"):
+        golden[key] = dict({k: "%016x" % check[k] for k in check}, ba_sums_head=[float(x) for x in sums[:8]], bundles=result_check["bundles"],
+                           features_per_image=nf, written_by="bench.py --gpus 1 (SSRLCV_WRITE_NVIEW_GOLDEN=1) @ %s" % git_head())
+        with open(NVIEW_GOLDEN, "w") as f:
+            json.dump(golden, f, indent=1, sort_keys=True)
+    if not same or result_check["equal_to_world1"] is False:
+        result_check["FAILED"] = "ranks disagree" if not same else "differs from the world-1 result"
     # stages every rank repeats on the whole problem (the rest shrinks with the rank count): the serial fraction of the flow
     replicated = sum(mine.get(k, 0.0) for k in ("merge", "filter"))
     wire = {"exchange_features_bytes": int(sum(f.numel() for f in res["features"])),
             "exchange_pairs_bytes": int(sum(p.numel() for p in res["pairs"])),
             "cloud_all_gather_bytes": int(res["points"].shape[0] * 12),
             "ba_all_reduce_bytes": 612 * 4,
-            "note": "payload every rank ends up holding, per step; each rank sends its own share once at its exact size "
-                    "(one grouped broadcast per rank, dist._gather_segments); world 1 moves nothing"}
+            "mode": sd.exchange_mode(),
+            "note": "payload every rank ends up holding, per step; SSRLCV_EXCHANGE=bcast (default): each rank sends its own share once "
+                    "at its exact size (one grouped broadcast per rank, dist._gather_segments); =allgather: one all-gather padded to the "
+                    "largest share; world 1 moves nothing"}
+    comm = {"backend": dist.get_backend() if dist is not None else None, "rccl_world": dist.get_world_size() if dist is not None else 1}
+    if dist is not None and dist.get_backend() == "nccl":
+        try:
+            comm["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            pass
     return {"metric": "Mpix/s N-view reconstruction (SIFT + exhaustive orbit match + merge + N-view triangulate + BA sweep)",
             "value": views * size * size * steps / dt / 1e6, "unit": "Mpix/s", "n_gpus": world, "steps": steps,
-            "ms_per_step": step_ms, "scaling": "strong", "views": views, "pairs": len(pairs),
+            "ms_per_step": step_ms, "ms_per_step_stats_rank0": step_stats, "stall": bool(step_stats["max"] > 2.0 * step_stats["median"]),
+            "scaling": "strong", "views": views, "pairs": len(pairs),
             "workload": "%d-view %dx%d scene, image/pair shard over %d GPU(s): all-gather of features, pairs balanced by "
                         "nq*nt, all-gather of uint2_pair arrays, replicated merge on the device (ssrlcv_hip_merge_matches), bundle-range "
                         "triangulation + all-gather of the cloud, 612-point BA error sweep + all-reduce" % (views, size, size, world),
-            "stage_ms_per_step_rank0": mine,
+            "stage_ms_per_step_rank0": mine, "stage_ms_stats_rank0": mine_stats,
             "stage_ms_per_step_over_ranks": spread,
-            "replicated_stage_ms": replicated, "replicated_share_of_step": replicated / step_ms if step_ms else None,
+            "replicated_stage_ms": replicated, "replicated_share_of_step": replicated / step_stats["median"] if step_stats["median"] else None,
             "pair_cost_share_per_rank": [l / max(sum(cost), 1.0) for l in load],
             "pair_balance_max_over_mean": max(load) / (sum(load) / world) if sum(load) else None,
             "images_per_rank": [sum(1 for v in range(views) if sd.image_owner(v, world) == r) for r in range(world)],
-            "wire": wire,
+            "wire": wire, "comm": comm, "result_check": result_check,
             "multi_matches": int(len(res["matches"])), "points": int(res["points"].shape[0]),
             "ba_bundles": int(res.get("ba_bundles", 0)),
             "features_per_image": nf,
             "_inputs": (imgs, cams, res["points"].cpu().numpy())}   # for the class-API flow leg (popped before printing)
+
+
+def run_pushbroom(args, torch, dist, world, rank, dev, size, views):
+    """BASELINE config[4]: `views` pushbroom strips of size^2 -> SIFT per strip (one plan reused: a workspace is 22 GB at
+    8192^2) -> the exhaustive brute-force + seed-ratio matching of all strip pairs -> merge -> generatePushbroomBundle
+    (src/PointCloudFactory.cu:875-903, :4201-4283) + N-view triangulation -> statistical filters on the device.  One warm-up
+    step, one timed step (the match stage of 28 pairs of 2-3 million features each is ~20 s on one GPU), per-stage times,
+    and the scale-space stage of one strip alone against the HBM roofline (`roofline_8192`)."""
+    import helpers as H
+    import scene
+    from ssrlcv_amd import capi, pipeline
+    imgs, pbs, _, _ = scene.pushbroom_views(views, size, device=dev)
+    seed, _ = H.load_seed_features()
+    ws = pipeline.Workspace()
+    filters = [("statistical", 3.0, 0.1)] * 4
+
+    def step():
+        return pipeline.reconstruct(imgs, None, seed_features=seed, mode=0, pushbroom=pbs, ws=ws, filters=filters)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    step()
+    ws.times.clear()
+    barrier()
+    t0 = time.perf_counter()
+    res = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if dist is None or dist.get_backend() != "gloo" else "cpu")
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    stages = {k: v * 1e3 for k, v in ws.times.items()}
+    nf = [int(f.numel() // 152) for f in res["features"]]
+    check = {"cloud": "%016x" % checksum64(res["points"]), "multi_matches": "%016x" % checksum64(res["matches"])}
+    out = {"metric": "Mpix/s pushbroom N-view reconstruction (SIFT + exhaustive brute-force match + merge + pushbroom bundles + N-view triangulate + filters)",
+           "value": views * size * size / dt / 1e6, "unit": "Mpix/s", "n_gpus": world, "steps": 1, "ms_per_step": dt * 1e3, "scaling": "strong",
+           "workload": "config[4]: %d pushbroom strips of %dx%d (tools/scene.py pushbroom_views), image/pair shard over %d GPU(s); %d pairs" %
+                       (views, size, size, world, views * (views - 1) // 2),
+           "stage_ms": stages, "features_per_strip": nf, "multi_matches_unfiltered": int(res["matches_unfiltered"]),
+           "multi_matches": int(len(res["matches"])), "points": int(res["points"].shape[0]), "filters": "4 x statistical (3 sigma, 10 %) on the device",
+           "checksums_rank0": check}
+    del res
+    if rank == 0:
+        # the scale-space stage of ONE strip alone (ssrlcv_hip_sift_build_dog, HIP events on the launching stream)
+        plan = ws.plan(size, size, 0)
+        for _ in range(2):
+            plan.build_dog(imgs[0])
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            plan.build_dog(imgs[0])
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        b_pyr = 362.25 * size * size
+        rl = {"bound": "hbm", "achieved": b_pyr / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_pyr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+              "ms_per_image": ms, "algorithmic_bytes": b_pyr, "traffic": None,
+              "kernel": "scale-space stage (ssrlcv_hip_sift_build_dog) of one %dx%d strip alone; same definition as `roofline.stage_alone`" % (size, size)}
+        tpath = os.path.join(ROOT, "profiles", "r06_8192_pyramid_traffic.json")
+        if size == 8192 and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            rl["traffic"], rl["traffic_source"] = tj["pyramid_stage_bytes_per_image"], "profiles/r06_8192_pyramid_traffic.json @ %s" % tj.get("commit")
+        out["roofline_8192" if size == 8192 else "roofline_strip"] = rl
+    return out
 
 
 def main():
@@ -503,7 +642,10 @@ def main():
                     help="views of the N-view leg; 0 = max(4, world): config[3]'s four views (6 pairs) up to four ranks, eight views "
                          "(28 pairs, src/MatchFactory.cu:907-1028 order) on eight, so that no rank is left without an image or a pair")
     ap.add_argument("--nview-size", type=int, default=4096, help="edge of the N-view leg's images (config[3]: 4-view 4096x4096)")
-    ap.add_argument("--nview-steps", type=int, default=2)
+    ap.add_argument("--nview-steps", type=int, default=6, help="timed steps of the N-view leg (median / min / max are reported; two warm-up steps)")
+    ap.add_argument("--no-pushbroom", action="store_true", help="skip the config[4] leg (eight 8192^2 pushbroom strips: ~1 minute)")
+    ap.add_argument("--pushbroom-size", type=int, default=8192)
+    ap.add_argument("--pushbroom-views", type=int, default=0, help="0 = max(8, world)")
     ap.add_argument("--noise-input", action="store_true", help="round-1 input: multi-scale noise instead of the scene generator")
     args = ap.parse_args()
 
@@ -596,12 +738,12 @@ def main():
     line = None
     if rank == 0:
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r05_pyramid_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r06_pyramid_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r06_pyramid_traffic.json")) else "r05_pyramid_traffic.json")
         if W == 4096 and H_ == 4096 and os.path.exists(tpath):
             # HBM bytes of the pyramid stage per image from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the stage
             # benchmark (collected off-line: counters cannot be read from inside the timed run)
             tj = json.load(open(tpath))
-            traffic, traffic_src = tj["pyramid_stage_bytes_per_image"], "profiles/r05_pyramid_traffic.json @ %s" % tj.get("commit")
+            traffic, traffic_src = tj["pyramid_stage_bytes_per_image"], "profiles/%s @ %s" % (os.path.basename(tpath), tj.get("commit"))
         pixels_per_step = world * args.images * W * H_
         value = pixels_per_step * args.steps / dt / 1e6
         # Algorithmic bytes of the stage.  `frac` is priced on SURVEY.md 8(d)'s / BASELINE.md section 4's own figure,
@@ -642,6 +784,20 @@ def main():
                                                  "stage's tail (round 5: the step gains what the stage-boundary event loses)"}},
             "describe": describe_roofline(desc_ms, int(np.mean(nfeat)), W),
         }
+        fpath = os.path.join(ROOT, "profiles", "r06_pyramid_floor.json")
+        if W == 4096 and H_ == 4096 and os.path.exists(fpath):
+            # per-launch floor table of the stage (tools/collect_floor.sh + tools/pyramid_floor.py, serial run under rocprofv3):
+            # solo time, counter traffic, copy floor (traffic / 5.3 TB/s), issue floor, gap -- summarised here, rows in the file
+            fj = json.load(open(fpath))
+            rows = [r for r in fj["launches"] if "gap_us" in r]
+            line["roofline"]["floor"] = {
+                "source": "profiles/r06_pyramid_floor.json @ %s" % fj.get("commit"),
+                "serial_sum_us": fj["serial_sum_us"], "copy_floor_sum_us": fj["copy_floor_sum_us"], "floor_sum_us": fj["floor_sum_us"],
+                "gap_sum_us": fj["gap_sum_us"], "traffic_bytes": fj["traffic_bytes"], "algorithmic_bytes_as_built": fj["algorithmic_bytes"],
+                "octave0_levels_0_3": fj["octave0_levels_0_3"],
+                "largest_gaps": [{"kernel": r["kernel"], "octave": r.get("octave"), "level": r.get("level"), "solo_us": r["solo_us"],
+                                  "copy_floor_us": r.get("copy_floor_us"), "issue_floor_us": r.get("issue_floor_us"), "gap_us": r["gap_us"]}
+                                 for r in sorted(rows, key=lambda r: -r["gap_us"])[:6]]}
     img0 = imgs[0]
     del imgs[1:]
     torch.cuda.empty_cache()
@@ -649,15 +805,22 @@ def main():
         # every rank enters the N-view leg together (the barrier inside run_nview): the rank-0-only legs come after it,
         # so that its stage times are not polluted by rank skew
         nviews = args.nview_views if args.nview_views > 0 else max(4, world)
-        nv = run_nview(args, torch, dist, capi, world, rank, dev, nviews, args.nview_size, args.nview_steps, 1)
+        nv = run_nview(args, torch, dist, capi, world, rank, dev, nviews, args.nview_size, max(args.nview_steps, 1), 2)
         nv_inputs = nv.pop("_inputs")
         if rank == 0:
             line["nview"] = nv
+    if not args.no_pushbroom:
+        # config[4]; every rank enters together (its exchanges are collectives), before the rank-0-only legs
+        torch.cuda.empty_cache()
+        pb = run_pushbroom(args, torch, dist, world, rank, dev, args.pushbroom_size, args.pushbroom_views if args.pushbroom_views > 0 else max(8, world))
+        if rank == 0:
+            line["pushbroom8"] = pb
+        torch.cuda.empty_cache()
     if rank == 0:
         if not args.no_class_api:
             line["class_api"] = class_api_leg(img0, W, line["value"] / world)
             if not args.no_nview and world == 1:
-                line["class_api"]["flow"] = class_api_flow_leg(nv_inputs[0], nv_inputs[1], args.nview_size, nv["ms_per_step"], nv_inputs[2])
+                line["class_api"]["flow"] = class_api_flow_leg(nv_inputs[0], nv_inputs[1], args.nview_size, nv["ms_per_step_stats_rank0"]["median"], nv_inputs[2])
         if not args.no_matcher:
             line["matcher"] = bench_matcher(capi, torch, args.match_n, args.match_n, args.match_iters)
             line["matcher_f16"] = bench_matcher(capi, torch, args.match_n, args.match_n, args.match_iters, "f16")

@@ -203,6 +203,7 @@ int oracle_sift_keypoints(oracle_sift* s, int stage, o_sskeypoint** out, int blu
 /* generateBW (src/Image.cu:1277-1296): colorDepth 2, 3 or 4 interleaved bytes -> grey */
 void oracle_convert_to_bw(const uint8_t* color, uint32_t colorDepth, uint8_t* bw, size_t numPixels);
 /* element-wise evaluation of oracle_libm.h (fn: 0 expf(a), 1 atan2f(a,b), 2 sinf, 3 cosf, 4 tanf, 5 powf(a,b)) */
+void oracle_rotate_points(const float* pts, const float* angles, float* out, size_t n);
 void oracle_math_eval(int fn, const float* a, const float* b, float* out, size_t n);
 
 /* P5: V S' U^T of calculateImageHessianInverse (src/PointCloudFactory.cu:1511-1824), n <= 12, row-major */

@@ -292,6 +292,8 @@ def merge_matches_device(num_features, pair_counts, pairs_d, workspace=None):
     check(LIB.ssrlcv_hip_merge_matches(c_u32(V), nf, c_u32(len(pair_counts)), pc, ptr(pairs_d) if total else None, ptr(workspace),
                                        c_sz(workspace.numel()), ptr(mm), ptr(mem), ptr(counts), stream_ptr()))
     n_mm, n_mem, bad, rounds = [int(x) for x in counts.cpu().tolist()]  # the one synchronisation of the (asynchronous) call
+    if bad & 4:  # (bit 2: a block of the persistent walk was not resident and its grid barrier gave up, csrc/merge.hip)
+        raise SsrlcvError("ssrlcv_hip_merge_matches: the persistent walk could not keep all its blocks resident (grid barrier timed out)")
     if bad:
         raise MalformedPairList("ssrlcv_hip_merge_matches: malformed pair list (status word %d)" % bad)
     return mm[: 8 * n_mm], mem[: 8 * n_mem], n_mm, n_mem, rounds, workspace

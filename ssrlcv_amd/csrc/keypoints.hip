@@ -1717,7 +1717,30 @@ int launch_chain_octave(const ssrlcv_sift_plan* plan, char* ws, int octave, hipS
 }  // namespace svp
 extern "C" {
 
-int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrlcv_sift_feature* features,
+// A stage call that fails half-way may have left work queued on the plan's side streams (octave 0's list chain on `chain2`,
+// the gradient tables on `polar` / `table`, queued by build_dog of a fused extract, or the chains this call forked): the
+// caller's stream is ordered behind all of it and the in-flight marks are cleared, so that whatever the caller does next
+// with the workspace (another extract, a stand-alone describe, freeing it behind a stream synchronisation) is ordered
+// behind those writes.  Errors of the drain itself are ignored: the call already has one to report.
+static void drain_side_streams(const ssrlcv_sift_plan* plan, hipStream_t st) {
+  svp::PlanAsync* as = plan->asyncState == 1 ? plan->async : nullptr;
+  if (as) {
+    for (hipStream_t side : {as->chain, as->table, as->chain2, as->polar}) {
+      if (hipEventRecord(as->fork, side) == hipSuccess) (void)hipStreamWaitEvent(st, as->fork, 0);
+    }
+    (void)hipGetLastError();
+  }
+  plan->chain0InFlight = 0;
+  plan->polarInFlight = 0;
+}
+static int describe_impl(const ssrlcv_sift_plan* plan, void* workspace, ssrlcv_sift_feature* features, uint32_t* numFeatures, ssrlcv_stream_t stream);
+int ssrlcv_hip_sift_describe(const ssrlcv_sift_plan* plan, void* workspace, ssrlcv_sift_feature* features, uint32_t* numFeatures,
+                             ssrlcv_stream_t stream) {
+  const int rc = describe_impl(plan, workspace, features, numFeatures, stream);
+  if (rc && plan) drain_side_streams(plan, (hipStream_t)stream);
+  return rc;
+}
+static int describe_impl(const ssrlcv_sift_plan* plan, void* workspace, ssrlcv_sift_feature* features,
                              uint32_t* numFeatures, ssrlcv_stream_t stream) {
   if (!plan || !workspace || !numFeatures) return SSRLCV_ERR_INVALID_ARG;
   char* ws = (char*)workspace;
@@ -2223,7 +2246,10 @@ int ssrlcv_hip_sift_extract(const ssrlcv_sift_plan* plan, const uint8_t* pixels,
   plan->fusedCall = 1;  // build_dog may leave the polar tables in flight: describe joins them below
   int rc = ssrlcv_hip_sift_build_dog(plan, pixels, workspace, stream);
   plan->fusedCall = 0;
-  if (rc) return rc;
+  if (rc) {  // build_dog may already have queued octave 0's list chain (or the tables) on a side stream
+    drain_side_streams(plan, (hipStream_t)stream);
+    return rc;
+  }
   if (plan->stageEvent && hipEventRecord(plan->stageEvent, (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
   return ssrlcv_hip_sift_describe(plan, workspace, features, numFeatures, stream);
 }

@@ -22,6 +22,8 @@
 //             look-back (scan_lookback.h); the records are written from them directly.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <map>
+#include <mutex>
 #include "device_math.h"
 #include "scan_lookback.h"
 #include "ssrlcv_hip.h"
@@ -151,7 +153,7 @@ struct WalkCtl {
   uint32_t* barrier;      // [0] groups arrived (monotone); [64 (1 + g)] arrivals of group g, each on its own 256-byte line
   uint32_t* unresolved;   // [(V - 2) x (kMaxRounds + 2)] one slot per (image, round), zeroed before the launch
   uint32_t* counts;       // counts[3] receives the number of rounds
-  const int* bad;         // set by k_merge_masks on malformed input: the walk is skipped
+  int* bad;               // set by k_merge_masks on malformed input: the walk is skipped; bit 2 (value 4) = a grid barrier timed out (below)
 };
 // Same-address atomics serialise at ~50 ns each on this part, so 256 blocks arriving on ONE counter cost 13 us per
 // barrier (the first version: 60 barriers = 3.7 ms for a merge whose kernels take 0.4).  Arrival is two-level: a block
@@ -161,7 +163,14 @@ struct WalkCtl {
 // release / acquire writes back / invalidates the caches for the whole CU, not for one wave.
 constexpr uint32_t kBarrierGroups = 16;
 constexpr size_t kBarrierBytes = 256 * (1 + kBarrierGroups);
-__device__ __forceinline__ void grid_barrier(uint32_t* ctr, uint32_t& passed) {
+// The launch is a plain one (a cooperative launch makes processes sharing the GPU time-slice against each other, round 5), so
+// nothing but the host-side sizing (one block per CU, at most what the occupancy query grants) guarantees that every block
+// is resident.  Should a block ever not be (CU masking, another persistent kernel holding the CUs), the spin is BOUNDED:
+// after ~2^22 polls (a few hundred milliseconds; a barrier normally takes microseconds) the waiter sets bit 2 of *bad and every
+// block leaves -- the call returns SSRLCV_ERR_UNSUPPORTED instead of hanging the GPU.  -> false: the walk is abandoned.
+constexpr uint32_t kBarrierSpinLimit = 1u << 22;
+__device__ __forceinline__ bool grid_barrier(uint32_t* ctr, uint32_t& passed, int* bad) {
+  __shared__ int s_abort;
   __syncthreads();
   ++passed;
   if (threadIdx.x == 0) {
@@ -171,10 +180,21 @@ __device__ __forceinline__ void grid_barrier(uint32_t* ctr, uint32_t& passed) {
     const uint32_t groupSize = (gridDim.x - g + kBarrierGroups - 1) / kBarrierGroups;  // blocks with this residue
     if (atomicAdd(ctr + 64 * (1 + g), 1u) == passed * groupSize - 1u) atomicAdd(ctr, 1u);
     const uint32_t target = passed * groups;
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    int abort = 0;
+    for (uint32_t spins = 0; __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spins) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((spins & 1023u) == 1023u && (__hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4)) { abort = 1; break; }
+      if (spins >= kBarrierSpinLimit) {
+        atomicOr(bad, 4);
+        abort = 1;
+        break;
+      }
+    }
+    s_abort = abort;
     __threadfence();
   }
   __syncthreads();
+  return s_abort == 0;
 }
 // state[f]: 1 = unresolved, 2 = ready this round
 __global__ __launch_bounds__(256) void k_merge_walk(Lists L, uint32_t numLists, uint8_t* __restrict__ state, uint8_t* __restrict__ outcome,
@@ -191,7 +211,7 @@ __global__ __launch_bounds__(256) void k_merge_walk(Lists L, uint32_t numLists, 
       outcome[f] = kSkip;
     }
     for (uint32_t l = later + tid; l < numLists; l += nthreads) minReader[l] = minWriter[l] = 0xffffffffu;
-    grid_barrier(ctl.barrier, passed);
+    if (!grid_barrier(ctl.barrier, passed, ctl.bad)) return;
     for (uint32_t r = 0;; ++r) {
       // mark: R(f) and W(f) of every unresolved seed on the current state
       uint32_t* slot = ctl.unresolved + i * (kMaxRounds + 2) + (r < (uint32_t)kMaxRounds + 1 ? r : (uint32_t)kMaxRounds + 1);
@@ -206,7 +226,7 @@ __global__ __launch_bounds__(256) void k_merge_walk(Lists L, uint32_t numLists, 
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
       if ((threadIdx.x & 63) == 0 && mine) atomicAdd(slot, mine);
-      grid_barrier(ctl.barrier, passed);
+      if (!grid_barrier(ctl.barrier, passed, ctl.bad)) return;
       const uint32_t left = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the same for every thread
       if (!left) break;
       if (r >= (uint32_t)kMaxRounds) {  // what is left after kMaxRounds, in upstream's order, by one thread
@@ -220,7 +240,7 @@ __global__ __launch_bounds__(256) void k_merge_walk(Lists L, uint32_t numLists, 
             state[f] = 0;
           }
         }
-        grid_barrier(ctl.barrier, passed);
+        if (!grid_barrier(ctl.barrier, passed, ctl.bad)) return;
         break;
       }
       // ready: no unresolved lower seed clears what f reads, none reads what f clears (the marks of f itself are f)
@@ -232,7 +252,7 @@ __global__ __launch_bounds__(256) void k_merge_walk(Lists L, uint32_t numLists, 
         for_each_cleared(L, a, [&](uint32_t l) { ready = ready && minReader[l] >= f; });
         if (ready) state[f] = 2;
       }
-      grid_barrier(ctl.barrier, passed);
+      if (!grid_barrier(ctl.barrier, passed, ctl.bad)) return;
       // commit the ready seeds (independent of each other and of every earlier unresolved seed), reset the marks
       for (uint32_t f = tid; f < nf; f += nthreads) {
         if (state[f] != 2) continue;
@@ -244,7 +264,7 @@ __global__ __launch_bounds__(256) void k_merge_walk(Lists L, uint32_t numLists, 
       }
       for (uint32_t l = later + tid; l < numLists; l += nthreads) minReader[l] = minWriter[l] = 0xffffffffu;
       ++rounds;
-      grid_barrier(ctl.barrier, passed);
+      if (!grid_barrier(ctl.barrier, passed, ctl.bad)) return;
     }
     // tally: an accepted seed's own list is final (only seeds of earlier images clear it)
     for (uint32_t f = tid; f < nf; f += nthreads) {
@@ -253,7 +273,7 @@ __global__ __launch_bounds__(256) void k_merge_walk(Lists L, uint32_t numLists, 
       members[seedBase + f] = g ? L.len[L.list_of(i, f)] + 1u : 0u;
     }
     seedBase += nf;
-    if (i + 3 < L.V) grid_barrier(ctl.barrier, passed);  // the next image reuses state / outcome
+    if (i + 3 < L.V && !grid_barrier(ctl.barrier, passed, ctl.bad)) return;  // the next image reuses state / outcome
   }
   if (tid == 0) ctl.counts[3] = rounds;
 }
@@ -431,14 +451,23 @@ int ssrlcv_hip_merge_matches(uint32_t numImages, const uint32_t* numFeatures_hos
 
   // ---- the walk, image by image (only images 0..V-3 seed multi-matches, :969), in one persistent launch (at most one block per CU)
   if (numSeeds) {
-    static int s_blocks = 0;  // co-resident blocks of k_merge_walk on this device (all devices of a node are alike)
-    if (s_blocks == 0) {
-      int dev = 0, cus = 0, perCu = 0;
-      SSRLCV_HIP_TRY(hipGetDevice(&dev));
-      SSRLCV_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-      SSRLCV_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_merge_walk, 256, 0));
-      if (cus <= 0 || perCu <= 0) return SSRLCV_ERR_UNSUPPORTED;
-      s_blocks = cus;  // one block per CU: more only lengthen the barrier
+    // co-resident blocks of k_merge_walk, per device (a process may drive devices of different size or partition mode)
+    static std::mutex s_mu;
+    static std::map<int, int> s_blocksOf;
+    int dev = 0, s_blocks = 0;
+    SSRLCV_HIP_TRY(hipGetDevice(&dev));
+    {
+      std::lock_guard<std::mutex> lock(s_mu);
+      auto it = s_blocksOf.find(dev);
+      if (it == s_blocksOf.end()) {
+        int cus = 0, perCu = 0;
+        SSRLCV_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        SSRLCV_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_merge_walk, 256, 0));
+        if (cus <= 0 || perCu <= 0) return SSRLCV_ERR_UNSUPPORTED;
+        // one block per CU (more only lengthen the barrier), never more than the occupancy query grants in all
+        it = s_blocksOf.emplace(dev, cus < cus * perCu ? cus : cus * perCu).first;
+      }
+      s_blocks = it->second;
     }
     unsigned blocks = (maxSeeds + 255) / 256;
     if (blocks > (unsigned)s_blocks) blocks = (unsigned)s_blocks;

@@ -869,6 +869,7 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma2(ConvArgs a) {
 
 #include "gauss_rm.inc"
 #include "gauss_pair.inc"
+#include "gauss_pair_rm.inc"
 
 // ---- S4 for the small levels: one tile per block, no marching ---------------------------------------------------------
 // The marching kernels pay a 2R-row warm-up and one barrier per 8 or 16 rows; a 1024^2 or 2048^2 level gives them 64 to
@@ -2366,7 +2367,20 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
     const bool split = as && sched.split == 1;
     // (Round 3 handed the row chunks of odd levels out bottom-up, so that a level starts on the rows its predecessor wrote
     // last and finds them in the 256 MB memory-side cache: build_dog 2.07-2.11 ms against 2.05-2.08 top-down, no gain.)
-    for (int b = 0; b < svp::kGauss; ++b) {
+    // Levels 0 + 1 in one launch (gauss_pair_rm.inc) where that wins: the u8-sourced first octave from 2^26 pixels up (per
+    // 8192^2 level pair 220 us against 253 for the two launches; a 4096^2 pair 77 against 68, and with a float source the
+    // fused form only breaks even at 8192^2: tools/gauss_pair_lab.hip, profiles/r06_kernel_ab.txt).
+    // SSRLCV_GAUSS_PAIR_MINPX=<pixels> moves the threshold (developer build), SSRLCV_NO_GAUSS_PAIR=1 turns it off.
+    static const size_t pairMinPx = svdev::env("SSRLCV_GAUSS_PAIR_MINPX") ? (size_t)atoll(svdev::env("SSRLCV_GAUSS_PAIR_MINPX")) : ((size_t)1 << 26);
+    int firstLevel = 0;
+    if (o == 0 && fuseUpsample && (size_t)oc.w * oc.h >= pairMinPx && pair_rm_usable(oc.w, oc.h) &&
+        pair_usable(oc.w, oc.h, oc.taps[0], oc.taps[1], (const float*)(ws + offGauss[0]), (float*)(ws + offGauss[0]), (float*)(ws + offGauss[1]))) {
+      rc = launch_pair_rm(nullptr, pixels, (float*)(ws + offGauss[0]), (float*)(ws + offGauss[1]), oc.w, oc.h, oc.weights[0], oc.weights[1], mm, mm + 2, so);
+      if (rc) return rc;
+      src = (const float*)(ws + offGauss[1]);
+      firstLevel = 2;
+    }
+    for (int b = firstLevel; b < svp::kGauss; ++b) {
       float* dst = (float*)(ws + offGauss[b]);
       // next octave input = 2x2 bin of the UN-normalised level 3 (src/FeatureFactory.cu:392-399): written by level 3's
       // convolution itself where that kernel can (see launch_conv), by k_bin2x otherwise

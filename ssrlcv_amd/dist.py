@@ -84,10 +84,39 @@ def all_reduce_sum(t, group=None):
     return t
 
 
+def exchange_mode():
+    """How the variable-length exchanges move their bytes (SSRLCV_EXCHANGE, read at every exchange so that a bench run can
+    A/B the two on the same communicator):
+      "bcast"      (default) every rank's segment at its exact size: one broadcast per rank, queued together;
+      "allgather"  ONE all-gather of segments padded to the largest rank's (the collective the north star names:
+                   ncclAllGather; more bytes on the wire when the shares differ, one launch instead of world-many).
+    Same result either way (tests/test_dist_gloo.py runs both)."""
+    import os
+    m = os.environ.get("SSRLCV_EXCHANGE", "bcast")
+    if m not in ("bcast", "allgather"):
+        raise ValueError("SSRLCV_EXCHANGE must be 'bcast' or 'allgather', not %r" % m)
+    return m
+
+
 def _gather_segments(segments, flat, group=None):
-    """Fills `flat` (1-D uint8 on the backend's device): segment r = flat[offsets[r] : offsets[r] + sizes[r]] is broadcast
-    from rank r.  Exact sizes on the wire -- one broadcast per rank, queued together -- instead of an all-gather padded to
-    the largest rank: the shares differ several-fold (a rank's features, or its LPT-assigned pairs)."""
+    """Fills `flat` (1-D uint8 on the backend's device): segment r = flat[offsets[r] : offsets[r] + sizes[r]] comes from
+    rank r.  Default: exact sizes on the wire -- one broadcast per rank, queued together -- instead of an all-gather padded
+    to the largest rank: the shares differ several-fold (a rank's features, or its LPT-assigned pairs).
+    SSRLCV_EXCHANGE=allgather: one padded all-gather (see exchange_mode)."""
+    if exchange_mode() == "allgather":
+        world = dist.get_world_size(group)
+        rank = dist.get_rank(group)
+        pad = max(max(size for _, size in segments), 1)
+        pad = (pad + 15) // 16 * 16
+        send = torch.zeros(pad, dtype=torch.uint8, device=flat.device)
+        off, size = segments[rank]
+        send[:size] = flat[off: off + size]
+        recv = torch.empty(world * pad, dtype=torch.uint8, device=flat.device)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        for r, (off, size) in enumerate(segments):
+            if size and r != rank:
+                flat[off: off + size] = recv[r * pad: r * pad + size]
+        return
     works = []
     for r, (off, size) in enumerate(segments):
         if size:

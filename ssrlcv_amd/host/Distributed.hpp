@@ -154,6 +154,10 @@ inline void bundleRange(unsigned long numBundles, int world, int rank, unsigned 
   hi = std::min(lo + per, numBundles);
 }
 inline ptr::value<Unity<float3>> nViewTriangulateSharded(Comm& c, MatchSet* matchSet, std::vector<ptr::value<Image>> images) {
+  // (a Unity<T> cannot be empty: a MatchSet without bundles has null members, and there is no cloud to return -- every rank
+  // sees the same replicated MatchSet, so all of them leave here together and no collective is left half-entered)
+  if (matchSet == nullptr || matchSet->matches == nullptr || matchSet->keyPoints == nullptr || matchSet->matches->size() == 0)
+    return ptr::value<Unity<float3>>();
   const unsigned long M = matchSet->matches->size(), K = matchSet->keyPoints->size();
   if (images.empty() || images.at(0)->isPushbroom) throw std::invalid_argument("nViewTriangulateSharded: projective cameras only");
   matchSet->matches->transferMemoryTo(gpu);
@@ -205,6 +209,8 @@ inline ptr::value<Unity<float3>> nViewTriangulateSharded(Comm& c, MatchSet* matc
 // The two-view bundles of image pair (a, b) of an N-view MatchSet as a two-camera MatchSet on the DEVICE
 // (ssrlcv_hip_select_pair_bundles): what BundleAdjustTwoView, a two-view method, is given in the N-view flows.
 inline MatchSet selectPairBundles(MatchSet* matchSet, int imageA, int imageB) {
+  if (matchSet == nullptr || matchSet->matches == nullptr || matchSet->keyPoints == nullptr || matchSet->matches->size() == 0)
+    return MatchSet();  // (null members = no bundle of that pair; no zero-length allocation)
   const unsigned long M = matchSet->matches->size(), K = matchSet->keyPoints->size();
   const MemoryState mmOrigin = matchSet->matches->getMemoryState(), kpOrigin = matchSet->keyPoints->getMemoryState();
   if (matchSet->matches->getFore() == cpu) matchSet->matches->transferMemoryTo(gpu);
@@ -240,6 +246,9 @@ inline std::vector<float> evaluateCameraSetsSharded(Comm& c, MatchSet* pairSet, 
   std::vector<float> sums((size_t)K, 0.0f);
   ptr::device<float> sums_d((long)K);
   HipSafeCall(ssrlcv_hip_memset(sums_d.get(), 0, (size_t)K * sizeof(float)));
+  // the memset runs on the null stream and is not documented as host-synchronous: c.stream may be a non-blocking stream,
+  // and a rank without bundles queues nothing else in front of the all-reduce -- order the two explicitly
+  HipSafeCall(ssrlcv_hip_device_synchronize());
   if (pairSet->matches != nullptr && pairSet->matches->size()) {
     if (pairSet->matches->getFore() == cpu) pairSet->matches->transferMemoryTo(gpu);
     if (pairSet->keyPoints->getFore() == cpu) pairSet->keyPoints->transferMemoryTo(gpu);

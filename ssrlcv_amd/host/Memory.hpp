@@ -56,7 +56,7 @@ class BlockCache {
   std::mutex mtx;
   std::map<size_t, std::vector<void*>> freeList[3];  // [0] device, [1] pinned host, [2] pageable host (round 5)
   size_t cached[3] = {0, 0, 0};
-  const size_t budget[3] = {(size_t)24 << 30, (size_t)2 << 30, (size_t)2 << 30};
+  const size_t budget[3] = {(size_t)24 << 30, (size_t)2 << 30, (size_t)1 << 30};  // (pageable blocks: 1 GB; trimBlockCache() releases them)
   bool enabled;
 
  public:
@@ -128,6 +128,13 @@ inline BlockCache& blockCache() {
   return c;
 }
 }  // namespace detail
+
+// Returns every parked block of the cache to the system: kind 0 device, 1 pinned host, 2 pageable host, -1 all of them.
+// (The cache otherwise gives blocks back only when an allocation fails.)
+inline void trimBlockCache(int kind = -1) {
+  for (int k = 0; k < 3; ++k)
+    if (kind < 0 || kind == k) detail::blockCache().trim(k);
+}
 
 template <typename T> struct device_delete {
   size_t cls;
@@ -201,12 +208,17 @@ class host : public base<T> {
   void setForOverwrite(long n, bool pinned = false) { alloc(n, pinned, false); }
 
  private:
+  // The cached pageable blocks (and with them the "do not construct what is about to be overwritten" path) only serve
+  // element types for which raw storage IS a valid array: trivially copyable (a device-to-host memcpy makes the objects)
+  // and trivially destructible (the deleter has nothing to run over elements nobody constructed).  Everything on the hot
+  // path is (float, KeyPoint, MultiMatch, Feature<SIFT_Descriptor>, float3 ...); anything else takes plain new[] / delete[].
+  static constexpr bool kRawStorageOk = std::is_trivially_copyable<T>::value && std::is_trivially_destructible<T>::value;
   void alloc(long n, bool pinned, bool construct) {
     if (pinned) {
       size_t cls = 0;
       void* tmp = detail::blockCache().take(1, (size_t)n * sizeof(T), cls);
       ptr.reset((T*)tmp, host_pinned_delete<T>{cls});
-    } else if ((size_t)n * sizeof(T) >= ((size_t)1 << 20) && alignof(T) <= 16) {
+    } else if (kRawStorageOk && (size_t)n * sizeof(T) >= ((size_t)1 << 20) && alignof(T) <= 16) {
       size_t cls = 0;
       T* tmp = (T*)detail::blockCache().take(2, (size_t)n * sizeof(T), cls);
       if (construct && !std::is_trivially_default_constructible<T>::value)

@@ -211,9 +211,12 @@ class Unity {
     if (s == gpu || (s == both && device != nullptr)) {
       if (s == both && host != nullptr) {
         h2d();
-      } else if (std::is_trivially_default_constructible<T>::value) {
+      } else if (std::is_trivially_default_constructible<T>::value && std::is_trivially_copyable<T>::value && !std::is_member_pointer<T>::value) {
         // value-initialised PODs are zero bytes: the same device content without building the array on the host and
-        // copying it over (6 MB per image pair for a uint2_pair list of 4 x 10^5 queries, every matcher call)
+        // copying it over (6 MB per image pair for a uint2_pair list of 4 x 10^5 queries, every matcher call).  (T() of a
+        // trivially default-constructible type is zero-initialisation; the one scalar whose zero value is not all-zero bytes,
+        // a pointer to member, is excluded -- a struct holding one takes the general branch's semantics only by accident,
+        // and no type on this path does.)
         HipSafeCall(ssrlcv_hip_memset(device.get(), 0, bytes()));
       } else {
         T* z = new T[numElements]();

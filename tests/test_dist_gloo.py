@@ -50,9 +50,10 @@ def _feature_counts(num_images):
     return [int(x) for x in rng.integers(60000, 95000, num_images)]
 
 
-def _worker(rank, world, port, tmp, num_images):
+def _worker(rank, world, port, tmp, num_images, mode="bcast"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["SSRLCV_EXCHANGE"] = mode   # per-rank exact-size broadcasts, or one padded all-gather (dist.exchange_mode)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from ssrlcv_amd import dist as sd
     try:
@@ -107,10 +108,11 @@ def _worker(rank, world, port, tmp, num_images):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,num_images", [(2, 4), (2, 8), (3, 8), (4, 8)])
-def test_exchanges_and_replicated_merge_on_several_ranks(tmp_path, oracle_lib, world, num_images):
+@pytest.mark.parametrize("world,num_images,mode", [(2, 4, "bcast"), (2, 8, "bcast"), (3, 8, "bcast"), (4, 8, "bcast"),
+                                                   (2, 4, "allgather"), (3, 8, "allgather"), (4, 8, "allgather")])
+def test_exchanges_and_replicated_merge_on_several_ranks(tmp_path, oracle_lib, world, num_images, mode):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path), num_images), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), num_images, mode), nprocs=world, join=True)
     mms = [np.load(tmp_path / ("mm_%d.npy" % r)) for r in range(world)]
     mems = [np.load(tmp_path / ("mem_%d.npy" % r)) for r in range(world)]
     mm0, mem0 = mms[0], mems[0]

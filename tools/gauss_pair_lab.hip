@@ -57,24 +57,56 @@ int main(int argc, char** argv) {
     for (int r = 0; r < 5; ++r) { launch_conv(in, a0, nullptr, W, H, tA, wA, nullptr, nullptr, src); launch_conv(a0, a1, nullptr, W, H, tB, wB, nullptr, nullptr); }
     hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(&msRef, e0, e1); msRef /= 5;
+    for (int form = 0; form < 2; ++form) {  // 0: vector formulation (k_gauss_pair), 1: matrix pipe (k_gauss_pair_rm)
+    if (form == 1 && !pair_rm_usable(W, H)) { printf("matrix-pipe form not usable at this size\n"); continue; }
+    auto launch = [&](float* mA, float* mB) { return form ? launch_pair_rm(in, src, b0, b1, W, H, wA, wB, mA, mB, nullptr) : launch_pair(in, src, b0, b1, W, H, wA, wB, mA, mB, nullptr); };
     // fused
     hipMemset(b0, 0xff, n * 4); hipMemset(b1, 0xff, n * 4);
     hipMemcpy(mm, init, 16, hipMemcpyHostToDevice);
-    rc = launch_pair(in, src, b0, b1, W, H, wA, wB, mm, mm + 2, nullptr);
+    rc = launch(mm, mm + 2);
     if (rc || hipDeviceSynchronize() != hipSuccess) { printf("pair failed rc %d: %s\n", rc, hipGetErrorString(hipGetLastError())); return 1; }
     hipMemcpy(mmPair, mm, 16, hipMemcpyDeviceToHost);
     hipEventRecord(e0);
-    for (int r = 0; r < 5; ++r) launch_pair(in, src, b0, b1, W, H, wA, wB, nullptr, nullptr, nullptr);
+    for (int r = 0; r < 5; ++r) launch(nullptr, nullptr);
     hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(&msPair, e0, e1); msPair /= 5;
     hipMemcpy(ra.data(), a0, n * 4, hipMemcpyDeviceToHost); hipMemcpy(rb.data(), a1, n * 4, hipMemcpyDeviceToHost);
     hipMemcpy(pa.data(), b0, n * 4, hipMemcpyDeviceToHost); hipMemcpy(pb.data(), b1, n * 4, hipMemcpyDeviceToHost);
+#ifdef SSRLCV_STAMPS
+    if (form == 1) {  // one more launch with s_memtime stamps in the middle block
+      static long long* stamps = nullptr;
+      const size_t ns = 8 * 64 * 8;
+      if (!stamps) hipMalloc(&stamps, ns * 8);
+      hipMemset(stamps, 0, ns * 8);
+      g_lab_stamps = stamps;
+      launch(nullptr, nullptr);
+      hipDeviceSynchronize();
+      g_lab_stamps = nullptr;
+      std::vector<long long> st(ns);
+      hipMemcpy(st.data(), stamps, ns * 8, hipMemcpyDeviceToHost);
+      for (int wv = 0; wv < 4; wv += 3) {
+        double d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int cnt = 0;
+        for (int it = 6; it < 20; ++it) {
+          const long long* s0 = &st[((size_t)wv * 64 + it) * 8];
+          const long long* s1 = &st[((size_t)wv * 64 + it + 1) * 8];
+          if (!s0[0] || !s1[0] || !s0[7]) continue;
+          ++cnt;
+          for (int k = 0; k < 7; ++k) d[k] += s0[k + 1] - s0[k];
+          d[7] += s1[0] - s0[0];
+        }
+        if (cnt) printf("   wave %d: H_A %.0f | H_B %.0f | barrier %.0f | bv + stage + fetch %.0f | V_A %.0f | V_B %.0f | barrier %.0f | step %.0f clocks\n", wv, d[0] / cnt, d[1] / cnt, d[2] / cnt,
+                        d[3] / cnt, d[4] / cnt, d[5] / cnt, d[6] / cnt, d[7] / cnt);
+      }
+    }
+#endif
     const size_t dA = diffs(ra, pa, W, "level a"), dB = diffs(rb, pb, W, "level b");
     const bool mmOk = memcmp(mmRef, mmPair, 16) == 0;
     const double bytes = (ups ? n / 4.0 : n * 4.0) + 2.0 * n * 4;
-    printf("%s input %ux%u: two launches %.3f ms, fused %.3f ms (%.2f TB/s on %.0f MB)  diffs a %zu b %zu  minmax %s (%g %g %g %g | %g %g %g %g)\n", ups ? "u8 " : "f32", W, H, msRef, msPair,
+    printf("%s input %ux%u %s: two launches %.3f ms, fused %.3f ms (%.2f TB/s on %.0f MB)  diffs a %zu b %zu  minmax %s (%g %g %g %g | %g %g %g %g)\n", ups ? "u8 " : "f32", W, H, form ? "matrix" : "vector", msRef, msPair,
            bytes / (msPair * 1e-3) / 1e12, bytes / 1e6, dA, dB, mmOk ? "equal" : "DIFFERENT", mmRef[0], mmRef[1], mmRef[2], mmRef[3], mmPair[0], mmPair[1], mmPair[2], mmPair[3]);
     bad += dA != 0 || dB != 0 || !mmOk;
+    }
   }
   printf(bad ? "FAILED\n" : "all equal\n");
   return bad != 0;
