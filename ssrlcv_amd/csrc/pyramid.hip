@@ -2375,7 +2375,10 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
     int firstLevel = 0;
     if (o == 0 && fuseUpsample && (size_t)oc.w * oc.h >= pairMinPx && pair_rm_usable(oc.w, oc.h) &&
         pair_usable(oc.w, oc.h, oc.taps[0], oc.taps[1], (const float*)(ws + offGauss[0]), (float*)(ws + offGauss[0]), (float*)(ws + offGauss[1]))) {
-      rc = launch_pair_rm(nullptr, pixels, (float*)(ws + offGauss[0]), (float*)(ws + offGauss[1]), oc.w, oc.h, oc.weights[0], oc.weights[1], mm, mm + 2, so);
+      // (developer build, SSRLCV_GAUSS_PAIR_FORM=valu: the vector formulation of the fused pair, gauss_pair.inc -- exact, slower)
+      static const bool valuForm = svdev::env("SSRLCV_GAUSS_PAIR_FORM") != nullptr && svdev::env("SSRLCV_GAUSS_PAIR_FORM")[0] == 'v';
+      rc = valuForm ? launch_pair(nullptr, pixels, (float*)(ws + offGauss[0]), (float*)(ws + offGauss[1]), oc.w, oc.h, oc.weights[0], oc.weights[1], mm, mm + 2, so)
+                    : launch_pair_rm(nullptr, pixels, (float*)(ws + offGauss[0]), (float*)(ws + offGauss[1]), oc.w, oc.h, oc.weights[0], oc.weights[1], mm, mm + 2, so);
       if (rc) return rc;
       src = (const float*)(ws + offGauss[1]);
       firstLevel = 2;

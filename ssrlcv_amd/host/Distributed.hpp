@@ -72,6 +72,51 @@ inline void allReduceCounts(Comm& c, std::vector<uint32_t>& v) {
   HipSafeCall(ssrlcv_hip_memcpy(v.data(), d.get(), v.size() * sizeof(uint32_t), 1));
 }
 
+// One variable-length exchange: segment k (a device array of `bytes` bytes, allocated on every rank) is filled on every rank
+// with rank `owner`'s content.  Two ways to move the bytes, chosen per call by SSRLCV_EXCHANGE (like ssrlcv_amd/dist.py):
+//   bcast (default)  one ncclBroadcast per segment at its exact size, all in one group;
+//   allgather        ONE ncclAllGather -- the collective the north star names -- of every rank's segments packed back to
+//                    back and padded to the largest rank's total (two device-to-device copies per segment on top).
+// Same result; which is faster on xGMI is for a world > 1 run to say (bench.py's nview leg reports the mode).
+struct Segment { void* ptr; size_t bytes; int owner; };
+inline bool exchangeByAllGather() {
+  const char* m = std::getenv("SSRLCV_EXCHANGE");
+  if (m == nullptr || std::string(m) == "bcast") return false;
+  if (std::string(m) == "allgather") return true;
+  throw std::invalid_argument("SSRLCV_EXCHANGE must be 'bcast' or 'allgather'");
+}
+inline void exchangeSegments(Comm& c, const std::vector<Segment>& segs, const char* what) {
+  if (c.world == 1) return;
+  if (!exchangeByAllGather()) {
+    ncclCheck(ncclGroupStart(), "group");
+    for (const Segment& s : segs)
+      if (s.bytes) ncclCheck(ncclBroadcast(s.ptr, s.ptr, s.bytes, ncclChar, s.owner, c.comm, c.stream), what);
+    ncclCheck(ncclGroupEnd(), "group");
+    hipCheck(hipStreamSynchronize(c.stream), what);
+    return;
+  }
+  std::vector<size_t> perRank((size_t)c.world, 0);
+  for (const Segment& s : segs) perRank[(size_t)s.owner] += s.bytes;
+  size_t pad = 16;
+  for (size_t b : perRank) pad = std::max(pad, (b + 15) / 16 * 16);
+  ptr::device<unsigned char> send((long)pad), recv((long)(pad * (size_t)c.world));
+  size_t off = 0;
+  for (const Segment& s : segs)
+    if (s.owner == c.rank && s.bytes) {
+      HipSafeCall(ssrlcv_hip_memcpy(send.get() + off, s.ptr, s.bytes, 2));
+      off += s.bytes;
+    }
+  HipSafeCall(ssrlcv_hip_device_synchronize());  // (the copies ran on the null stream, the collective runs on c.stream)
+  ncclCheck(ncclAllGather(send.get(), recv.get(), pad, ncclChar, c.comm, c.stream), what);
+  hipCheck(hipStreamSynchronize(c.stream), what);
+  std::vector<size_t> cursor((size_t)c.world, 0);
+  for (const Segment& s : segs) {
+    if (s.owner != c.rank && s.bytes)
+      HipSafeCall(ssrlcv_hip_memcpy(s.ptr, recv.get() + (size_t)s.owner * pad + cursor[(size_t)s.owner], s.bytes, 2));
+    cursor[(size_t)s.owner] += s.bytes;
+  }
+}
+
 // Sharded generateMatchesExhaustive.  features[v] is this rank's own result for the images it owns (v mod world == rank)
 // and may be null for the others: they are received.  On return every rank holds every image's features (gpu state) in
 // `features` and the same MatchSet.  epsilon / delta as upstream (GEO_ORBIT == 1: the double-constrained matcher).
@@ -99,13 +144,11 @@ MatchSet generateMatchesExhaustiveSharded(Comm& c, MatchFactory<T>& matchFactory
       f = ptr::value<Unity<Feature<T>>>(nullptr, (unsigned long)nf[(size_t)v], gpu);
     }
   }
-  ncclCheck(ncclGroupStart(), "group");
-  for (int v = 0; v < V; ++v)
-    if (nf[(size_t)v])
-      ncclCheck(ncclBroadcast(features[(size_t)v]->device.get(), features[(size_t)v]->device.get(), (size_t)nf[(size_t)v] * sizeof(Feature<T>),
-                              ncclChar, imageOwner(v, c.world), c.comm, c.stream), "broadcast of a feature array");
-  ncclCheck(ncclGroupEnd(), "group");
-  hipCheck(hipStreamSynchronize(c.stream), "feature exchange");
+  {
+    std::vector<Segment> segs;
+    for (int v = 0; v < V; ++v) segs.push_back({features[(size_t)v]->device.get(), (size_t)nf[(size_t)v] * sizeof(Feature<T>), imageOwner(v, c.world)});
+    exchangeSegments(c, segs, "feature exchange");
+  }
   // ---- this rank's pairs
   const std::vector<uint32_t> owners = assignPairs(nf, c.world);
   std::vector<ptr::value<Unity<uint2_pair>>> matchIndices(owners.size());
@@ -131,13 +174,11 @@ MatchSet generateMatchesExhaustiveSharded(Comm& c, MatchFactory<T>& matchFactory
     if ((int)owners[k] != c.rank) matchIndices[k] = ptr::value<Unity<uint2_pair>>(nullptr, (unsigned long)pairCounts[k], gpu);
     else if (matchIndices[k]->getMemoryState() != gpu && matchIndices[k]->getMemoryState() != both) matchIndices[k]->setMemoryState(gpu);
   }
-  ncclCheck(ncclGroupStart(), "group");
-  for (size_t k = 0; k < owners.size(); ++k)
-    if (pairCounts[k])
-      ncclCheck(ncclBroadcast(matchIndices[k]->device.get(), matchIndices[k]->device.get(), (size_t)pairCounts[k] * sizeof(uint2_pair), ncclChar,
-                              (int)owners[k], c.comm, c.stream), "broadcast of a pair array");
-  ncclCheck(ncclGroupEnd(), "group");
-  hipCheck(hipStreamSynchronize(c.stream), "pair exchange");
+  {
+    std::vector<Segment> segs;
+    for (size_t k = 0; k < owners.size(); ++k) segs.push_back({matchIndices[k]->device.get(), (size_t)pairCounts[k] * sizeof(uint2_pair), (int)owners[k]});
+    exchangeSegments(c, segs, "pair exchange");
+  }
   // ---- replicated merge + KeyPoint table
   return matchFactory.assembleMatchSet(images, features, matchIndices, totalMatches);
 }
@@ -184,16 +225,13 @@ inline ptr::value<Unity<float3>> nViewTriangulateSharded(Comm& c, MatchSet* matc
     hipCheck(hipStreamSynchronize(c.stream), "triangulation");  // (the device blocks above are released at scope exit)
   }
   if (c.world > 1) {
-    ncclCheck(ncclGroupStart(), "group");
+    std::vector<Segment> segs;
     for (int r = 0; r < c.world; ++r) {
       unsigned long rlo = 0, rhi = 0;
       bundleRange(M, c.world, r, rlo, rhi);
-      if (rhi > rlo)
-        ncclCheck(ncclBroadcast(cloud->device.get() + rlo, cloud->device.get() + rlo, (size_t)(rhi - rlo) * sizeof(float3), ncclChar, r, c.comm,
-                                c.stream), "broadcast of a cloud range");
+      segs.push_back({cloud->device.get() + rlo, (size_t)(rhi - rlo) * sizeof(float3), r});
     }
-    ncclCheck(ncclGroupEnd(), "group");
-    hipCheck(hipStreamSynchronize(c.stream), "cloud exchange");
+    exchangeSegments(c, segs, "cloud exchange");
   }
   matchSet->matches->setFore(gpu);
   matchSet->keyPoints->setFore(gpu);

@@ -23,6 +23,7 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm);
 const char* ncclGetErrorString(ncclResult_t result);
 ncclResult_t ncclBroadcast(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, int root, ncclComm_t comm,
                            hipStream_t stream);
+ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream);
 ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, ncclComm_t comm,
                            hipStream_t stream);
 ncclResult_t ncclGroupStart();
