@@ -513,7 +513,8 @@ def run_nview(args, torch, dist, capi, world, rank, dev, views, size, steps, war
     if rank == 0 and world == 1 and os.environ.get("SSRLCV_WRITE_NVIEW_GOLDEN"):
         golden[key] = dict({k: "%016x" % check[k] for k in check}, ba_sums_head=[float(x) for x in sums[:8]], bundles=result_check["bundles"],
                            features_per_image=nf, written_by="bench.py --gpus 1 (SSRLCV_WRITE_NVIEW_GOLDEN=1) @ %s" % git_head())
-        with open(NVIEW_GOLDEN, "w") as f:
+        out_path = os.environ["SSRLCV_WRITE_NVIEW_GOLDEN"]   # "1": in place; anything else: that path (gpurun only brings gpurun_out/ back)
+        with open(NVIEW_GOLDEN if out_path == "1" else out_path, "w") as f:
             json.dump(golden, f, indent=1, sort_keys=True)
     if not same or result_check["equal_to_world1"] is False:
         result_check["FAILED"] = "ranks disagree" if not same else "differs from the world-1 result"

@@ -1267,6 +1267,9 @@ template <int NPX, int first, int last, int mmFirst, bool orFlags>
 #ifndef SSRLCV_DOGX_RING
 #define SSRLCV_DOGX_RING 1
 #endif
+#ifndef SSRLCV_PAIR_F32_MINPX
+#define SSRLCV_PAIR_F32_MINPX (~(size_t)0)  // float-sourced octaves keep their two launches (see build_dog)
+#endif
 __global__ __launch_bounds__(256, SSRLCV_DOGX_MINWAVES) void k_dogx(DogxArgs a) {
   typedef float vec __attribute__((ext_vector_type(NPX)));
   const int lane = threadIdx.x & 63;
@@ -2372,13 +2375,19 @@ int ssrlcv_hip_sift_build_dog(const ssrlcv_sift_plan* plan, const uint8_t* pixel
     // fused form only breaks even at 8192^2: tools/gauss_pair_lab.hip, profiles/r06_kernel_ab.txt).
     // SSRLCV_GAUSS_PAIR_MINPX=<pixels> moves the threshold (developer build), SSRLCV_NO_GAUSS_PAIR=1 turns it off.
     static const size_t pairMinPx = svdev::env("SSRLCV_GAUSS_PAIR_MINPX") ? (size_t)atoll(svdev::env("SSRLCV_GAUSS_PAIR_MINPX")) : ((size_t)1 << 26);
+    // float-sourced octaves (o >= 1): SSRLCV_GAUSS_PAIR_MINPX_F32=<pixels>
+    static const size_t pairMinPxF32 = svdev::env("SSRLCV_GAUSS_PAIR_MINPX_F32") ? (size_t)atoll(svdev::env("SSRLCV_GAUSS_PAIR_MINPX_F32")) : SSRLCV_PAIR_F32_MINPX;
     int firstLevel = 0;
-    if (o == 0 && fuseUpsample && (size_t)oc.w * oc.h >= pairMinPx && pair_rm_usable(oc.w, oc.h) &&
-        pair_usable(oc.w, oc.h, oc.taps[0], oc.taps[1], (const float*)(ws + offGauss[0]), (float*)(ws + offGauss[0]), (float*)(ws + offGauss[1]))) {
+    const bool u8Pair = o == 0 && fuseUpsample && (size_t)oc.w * oc.h >= pairMinPx;
+    const bool f32Pair = !(o == 0 && fuseUpsample) && (size_t)oc.w * oc.h >= pairMinPxF32;
+    if ((u8Pair || f32Pair) && pair_rm_usable(oc.w, oc.h) &&
+        pair_usable(oc.w, oc.h, oc.taps[0], oc.taps[1], f32Pair ? in : (const float*)(ws + offGauss[0]), (float*)(ws + offGauss[0]), (float*)(ws + offGauss[1]))) {
       // (developer build, SSRLCV_GAUSS_PAIR_FORM=valu: the vector formulation of the fused pair, gauss_pair.inc -- exact, slower)
       static const bool valuForm = svdev::env("SSRLCV_GAUSS_PAIR_FORM") != nullptr && svdev::env("SSRLCV_GAUSS_PAIR_FORM")[0] == 'v';
-      rc = valuForm ? launch_pair(nullptr, pixels, (float*)(ws + offGauss[0]), (float*)(ws + offGauss[1]), oc.w, oc.h, oc.weights[0], oc.weights[1], mm, mm + 2, so)
-                    : launch_pair_rm(nullptr, pixels, (float*)(ws + offGauss[0]), (float*)(ws + offGauss[1]), oc.w, oc.h, oc.weights[0], oc.weights[1], mm, mm + 2, so);
+      const float* pin = f32Pair ? in : nullptr;
+      const uint8_t* pu8 = f32Pair ? nullptr : pixels;
+      rc = valuForm ? launch_pair(pin, pu8, (float*)(ws + offGauss[0]), (float*)(ws + offGauss[1]), oc.w, oc.h, oc.weights[0], oc.weights[1], mm, mm + 2, so)
+                    : launch_pair_rm(pin, pu8, (float*)(ws + offGauss[0]), (float*)(ws + offGauss[1]), oc.w, oc.h, oc.weights[0], oc.weights[1], mm, mm + 2, so);
       if (rc) return rc;
       src = (const float*)(ws + offGauss[1]);
       firstLevel = 2;

@@ -8,11 +8,11 @@ import glob
 import json
 import sys
 
-PYRAMID = ("k_upsample2x", "k_add_border", "k_gauss_strip", "k_gauss_fused", "k_gauss_mfma", "k_gauss_rm", "k_gauss_tile", "k_bin2x", "k_dogx", "k_dog_finalize", "k_dog", "k_init_minmax")
+PYRAMID = ("k_upsample2x", "k_add_border", "k_gauss_pair", "k_gauss_strip", "k_gauss_fused", "k_gauss_mfma", "k_gauss_rm", "k_gauss_tile", "k_bin2x", "k_dogx", "k_dog_finalize", "k_dog", "k_init_minmax")
 
 
 def short(name):
-    for tok in ("k_upsample2x", "k_add_border", "k_gauss_strip", "k_gauss_fused", "k_gauss_mfma", "k_gauss_rm", "k_gauss_tile", "k_bin2x", "k_dogx", "k_dog_finalize", "k_dog", "k_init_minmax", "k_descriptors",
+    for tok in ("k_upsample2x", "k_add_border", "k_gauss_pair", "k_gauss_strip", "k_gauss_fused", "k_gauss_mfma", "k_gauss_rm", "k_gauss_tile", "k_bin2x", "k_dogx", "k_dog_finalize", "k_dog", "k_init_minmax", "k_descriptors",
                 "k_thetas", "k_polar", "k_extrema_flags", "k_refine", "k_scatter", "k_count", "k_scan", "k_flag_",
                 "k_book_", "k_state_reset"):
         if tok in name:

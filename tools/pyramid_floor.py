@@ -125,7 +125,19 @@ def main():
         traffic = (2 * 1024 * fb + 1024 * wb) if fb is not None and wb is not None else None
         alg = None
         issue = None
-        if any(t in name for t in CONV):
+        if "k_gauss_pair" in name:  # levels 0 + 1 of an octave in one launch: the level between them is written, not read back
+            o, b = conv_i // 6, conv_i % 6
+            conv_i += 2
+            px = (2 * size >> o) ** 2
+            row.update(octave=o, level="%d+%d" % (b, b + 1), taps="13+17", pixels=px)
+            alg = px * 8 + (px // 4 if (o == 0 and "true" in name) else px * 4)
+            if "_rm" in name:   # two register-marching engines, level a on 256 of every 240 columns, level b on 240 of 256 lanes
+                spp, rate = (2 * 16 + 2 * 20) * 256.0 / 240.0, RATE_MFMA4
+            else:
+                spp, rate = (2 * 13) * 256.0 / 240.0 + 2 * 17, RATE_VALU
+            issue = px * spp / rate * 1e6
+            row["useful_mac_share"] = round(2 * (13 + 17) / spp, 3)
+        elif any(t in name for t in CONV):
             o, b = conv_i // 6, conv_i % 6
             conv_i += 1
             px = (2 * size >> o) ** 2
@@ -165,7 +177,7 @@ def main():
             row["gap_us"] = round(solo - max(floors), 1)
         rows.append(row)
     tot = lambda k: round(sum(r.get(k, 0.0) or 0.0 for r in rows), 1)
-    o0chain = [r for r in rows if r.get("octave") == 0 and "level" in r and r["level"] <= 3]
+    o0chain = [r for r in rows if r.get("octave") == 0 and "level" in r and (isinstance(r["level"], str) or r["level"] <= 3)]
     out = collections.OrderedDict(
         source="tools/collect_floor.sh + tools/pyramid_floor.py: SSRLCV_SIFT_SERIAL=1 tools/bench_sift_stages.py --size %d --scene (developer build); "
                "rocprofv3 --kernel-trace, --pmc FETCH_SIZE, --pmc WRITE_SIZE, --pmc SQ_VALU_MFMA_BUSY_CYCLES ... in separate passes; "
