@@ -16,7 +16,8 @@
 // rounds 4-5 whose RESULTS were invalid -- matcher without epilogue / operand reads, gathers folded into 32 KB, one byte
 // load of eight in the upsampling loader -- served their measurements, profiles/r05_matcher_lab_pmc.txt,
 // r05_sampling_gather_lab.txt, r05_kernel_ab.txt section 6, and were removed from the sources in round 6: git history.)
-#if (defined(SSRLCV_STAMPS) || defined(SSRLCV_MATCH_STATS)) && !defined(SSRLCV_INSTRUMENTED_BUILD)
+// SSRLCV_TIMING_VARIANT (tools/ lab programs only): builds that leave work OUT to time what remains -- results invalid.
+#if (defined(SSRLCV_STAMPS) || defined(SSRLCV_MATCH_STATS) || defined(SSRLCV_TIMING_VARIANT)) && !defined(SSRLCV_INSTRUMENTED_BUILD)
 #error "SSRLCV_STAMPS / SSRLCV_MATCH_STATS only build through `make instrumented` or the tools/ lab programs (-DSSRLCV_INSTRUMENTED_BUILD)"
 #endif
 #if defined(SSRLCV_LAB) || defined(SSRLCV_MATCH_LAB) || defined(SSRLCV_LAB_LOCAL_GATHER) || defined(SSRLCV_LAB_UPS_LOADS)
