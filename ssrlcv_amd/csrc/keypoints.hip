@@ -620,17 +620,24 @@ struct OctaveSet {  // per-octave arguments of the combined sampling kernels
   const void* consts[svp::kOctaves];
 };
 
-template <int MAXO>
+template <int MAXO, int LPKS>
 __global__ __launch_bounds__(64) void k_thetas(const OctaveState* states, const RangeTable* tab, OctaveSet set, float lambda,
                                                float orientationThreshold) {
-  __shared__ float s_hist[36][64];
+  // LPKS: log2 of the lanes that share a key point (round 6).  The lanes of a group walk the window together, a chunk
+  // being 8 << LPKS samples of a row: every lane weighs eight of them (the expensive, order-free part), then the votes
+  // enter the group's ONE histogram column in raster order, lane after lane under the execution mask (LDS executes a
+  // wave's instructions in order).  The chain a key point's run time hangs on is 1 << LPKS times shorter, and the lanes
+  // of a group fetch neighbouring 16-byte pieces (one 16 << LPKS byte run per instruction instead of 1 << LPKS runs).
+  constexpr int LANES = 1 << LPKS, PER_BLOCK = 64 >> LPKS, CW = kThetaChunk * LANES;
+  __shared__ float s_hist[36][PER_BLOCK];  // one column per key point: the lanes that vote at the same time sit in different banks
   if (blockIdx.x >= tab->total) return;  // block-uniform
   const int range = __builtin_amdgcn_readfirstlane(range_of(tab, blockIdx.x));
   const int octave = range & 3, useg = kSegOrder[range >> 2];
   const LevelSet& L = set.L[octave];
   const float pixelWidth = set.pixelWidth[octave];
-  const int t = threadIdx.x;
-  const uint32_t local = (blockIdx.x - tab->start[range]) * 64 + t;
+  const int t = threadIdx.x, sub = t & (LANES - 1), col = t >> LPKS;
+  const float fsub2 = (float)(2 * sub);
+  const uint32_t local = (blockIdx.x - tab->start[range]) * PER_BLOCK + (uint32_t)(t >> LPKS);
   const bool have = local < tab->count[range];
   const int gi = (int)(tab->first[range] + local);
   const float pi = SSRLCV_PI_F;
@@ -647,7 +654,7 @@ __global__ __launch_bounds__(64) void k_thetas(const OctaveState* states, const 
   const bool inside = have && useg >= 1 && useg <= 3 &&
                       !(minx < 0.0f || miny < 0.0f || maxx >= (unsigned)(L.w - 1) || maxy >= (unsigned)(L.h - 1));
 #pragma unroll
-  for (int i = 0; i < 36; ++i) s_hist[i][t] = 0.0f;
+  for (int i = 0; i < 36 * PER_BLOCK / 64; ++i) (&s_hist[0][0])[i * 64 + t] = 0.0f;
   const float weight = 2.0f * lambda * lambda * kp.sigma * kp.sigma;
   const float rweight = 1.0f / weight;
   const int W = L.w;
@@ -660,11 +667,10 @@ __global__ __launch_bounds__(64) void k_thetas(const OctaveState* states, const 
     const float2* base = L.polar + (size_t)(useg - 1) * levelStride;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(uint32_t)(levelStride * 8), 0x00020000);  // < 4 GiB: checked by plan_create
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    // A cursor walks the window chunk by chunk in the reference's order (x += 1.0f eight times, then the next row); the
-    // chunk being evaluated is SSRLCV_THETAS_DEPTH chunks behind the one being requested.  One chunk ahead leaves ~0.25 of
-    // the kernel's 0.55 ms per 4096^2 image to the gathers (profiles/r05_sampling_gather_lab.txt); two chunks ahead
-    // (-DSSRLCV_THETAS_DEPTH=2, 91 instead of 69 registers) is no faster -- orientations + tables 1.306 / 1.309 ms against
-    // 1.275 / 1.282: the 2.4 GB of 64-byte pieces are a throughput cost, not a latency one.
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    // A cursor walks the window chunk by chunk in the reference's order (x += 1.0f CW times, then the next row); the
+    // chunk being evaluated is SSRLCV_THETAS_DEPTH chunks behind the one being requested.  The cursor is the same in
+    // every lane of a group.
     struct Cursor { float x, y, ty2; unsigned rowoff; bool act; };
     Cursor cf;  // the next chunk to request
     cf.x = minx;
@@ -672,10 +678,19 @@ __global__ __launch_bounds__(64) void k_thetas(const OctaveState* states, const 
     cf.ty2 = (miny - ky) * (miny - ky);
     cf.rowoff = (unsigned)round_pos(miny) * (unsigned)W + 1u;
     cf.act = inside;
+    // The reference's `x += 1.0f`, k times, is one correctly rounded x + k whenever the k steps cross at most one
+    // binade boundary: the steps in front of the crossing are exact, the crossing rounds x + k* once to the coarser grid
+    // (on which every later + 1.0f is exact again), and rounding to that grid commutes with adding the integer k - k*
+    // (an even multiple of its spacing, which is at most 1/2 up to 2^23: ties break the same way).  From x >= CW a chunk
+    // of CW steps cannot hold two powers of two.  Below (windows at the level's left edge) the chain is walked.
     auto advance = [&](Cursor& c) {  // same row while the reference's loop condition holds, else the next row
-      float xn = c.x;
-#pragma unroll
-      for (int i = 0; i < kThetaChunk; ++i) xn += 1.0f;
+      float xn = c.x + (float)CW;
+      if (__any(c.act && !(c.x >= (float)CW))) {
+        float ch = c.x;
+#pragma unroll 8
+        for (int i = 0; i < CW; ++i) ch += 1.0f;
+        xn = c.x >= (float)CW ? xn : ch;
+      }
       if (c.act) {
         if (xn <= maxx) {
           c.x = xn;
@@ -689,12 +704,14 @@ __global__ __launch_bounds__(64) void k_thetas(const OctaveState* states, const 
         }
       }
     };
+    // Load j of lane `sub` is the 16-byte piece j * LANES + sub of the chunk: the samples 2 (j LANES + sub) and the one
+    // behind it.  The group's pieces of one instruction are neighbours in memory.
     typedef u32x4 Chunk[kThetaChunk / 2];
     auto fetch = [&](const Cursor& c, Chunk& into) {
       if (!c.act) return;
-      const unsigned off = (c.rowoff + (unsigned)round_pos(c.x)) * 8u;  // byte offset, below 2^32
+      const unsigned off = (c.rowoff + (unsigned)round_pos(c.x)) * 8u + 16u * (unsigned)sub;  // byte offset, below 2^32
 #pragma unroll
-      for (int j = 0; j < kThetaChunk / 2; ++j) into[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off + 16u * j), 0, 0);
+      for (int j = 0; j < kThetaChunk / 2; ++j) into[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off + 16u * LANES * j), 0, 0);
     };
     Chunk q0, q1;      // requested chunks, oldest first (q1 only at depth 2)
     Cursor c0, c1;     // their cursors
@@ -724,66 +741,83 @@ __global__ __launch_bounds__(64) void k_thetas(const OctaveState* states, const 
         fetch(cf, q0);
       }
       advance(cf);
-      // the chunk's coordinates: the reference's `x += 1.0f`, kThetaChunk times
+      // the chunk's coordinates (sample s of the chunk: x_0 `+= 1.0f` s times; see advance); this lane keeps those of its
+      // eight samples s = 2 (j LANES + sub) + h
       float xs[kThetaChunk];
-      xs[0] = cc.x;
+      float xlast = cc.x + (float)(CW - 1);
 #pragma unroll
-      for (int i = 1; i < kThetaChunk; ++i) xs[i] = xs[i - 1] + 1.0f;
+      for (int i = 0; i < kThetaChunk; ++i) xs[i] = cc.x + (fsub2 + (float)(((i >> 1) << (1 + LPKS)) | (i & 1)));
+      if (__any(cc.act && !(cc.x >= (float)CW))) {
+        float ch = cc.x;
+        float xc[kThetaChunk];
+#pragma unroll
+        for (int sIdx = 0; sIdx < CW; ++sIdx) {
+          const int q = (sIdx >> 1) & (LANES - 1), i = ((sIdx >> (1 + LPKS)) << 1) | (sIdx & 1);
+          if (LANES == 1 || q == 0) xc[i] = ch;  // (first writer of xc[i])
+          else xc[i] = sub == q ? ch : xc[i];
+          if (sIdx + 1 < CW) ch += 1.0f;
+        }
+        const bool direct = cc.x >= (float)CW;
+#pragma unroll
+        for (int i = 0; i < kThetaChunk; ++i) xs[i] = direct ? xs[i] : xc[i];
+        xlast = direct ? xlast : ch;
+      }
       const float cty2 = cc.ty2;
       const unsigned crow = cc.rowoff;
       const bool cact = cc.act;
-      // Entry i of the chunk is the sample's pixel iff llroundf(xs[i]) == llroundf(xs[0]) + i.  In exact arithmetic it
-      // is; `+= 1.0f` rounds only when it crosses a binade, the perturbation then stays for the rest of the row, and
-      // from x >= 4 a chunk crosses at most one: checking the last entry covers them all.
-      const bool aligned = xs[0] >= 4.0f && round_pos(xs[kThetaChunk - 1]) == round_pos(xs[0]) + (kThetaChunk - 1);
-      // Two phases per chunk.  (1) The eight samples' Gaussian weights and bins are independent of each other and of the
-      // histogram: evaluated together they overlap their long dependent chains (the f64 Horner steps, the divisions) --
-      // a lone wave, all the short octaves ever have, otherwise spends most of its time waiting on its own results.
-      // (2) The histogram updates, strictly in raster order, branch-free: a sample that does not count (past the row's
-      // end, or bin 36 from an angle one ulp below 2 pi, which the reference's array has no slot for) adds
-      // fmaf(0, 0, h) = h to bin 0.
+      // Entry s of the chunk is sample s's pixel iff llroundf(x_s) == llroundf(x_0) + s.  In exact arithmetic it is;
+      // `+= 1.0f` rounds only when it crosses a binade, and then only towards a fraction that every coarser binade still
+      // represents: a fraction below one half can be lifted onto it (the rounded coordinate then is one more than the
+      // entry's, for the rest of the row), never back -- checking the chunk's last entry covers them all.
+      const bool aligned = cc.x >= 4.0f && round_pos(xlast) == round_pos(cc.x) + (CW - 1);
+      // rare (a chunk that crosses a binade with an unlucky fraction, or starts below x = 4): the group's samples are
+      // gathered one by one (behind the request for the next chunk in program order: its wait is also that request's)
+      if (__any(cact && !aligned)) {
+        if (cact && !aligned) {
+#pragma unroll
+          for (int i = 0; i < kThetaChunk; ++i) {
+            u32x2 e = u32x2{0u, 0u};
+            if (xs[i] <= maxx) e = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)((crow + (unsigned)round_pos(xs[i])) * 8u), 0, 0);
+            cur[i >> 1][(i & 1) * 2] = e[0];
+            cur[i >> 1][(i & 1) * 2 + 1] = e[1];
+          }
+        }
+      }
+      // Two phases per chunk.  (1) The samples' Gaussian weights and bins are independent of each other and of the
+      // histogram: evaluated together they overlap their long dependent chains (the Horner steps, the divisions).
+      // (2) The histogram updates, strictly in raster order, branch-free within a lane: a sample that does not count
+      // (past the row's end, or bin 36 from an angle one ulp below 2 pi, which the reference's array has no slot for)
+      // adds fmaf(0, 0, h) = h to bin 0.
       auto weigh = [&](float ang, float xi, float& wgt, int& bin) {
         const float angle = fmod_2pi_above(ang + (2.0f * pi), 2.0f * pi);
         bin = (int)floorf(sv::exact_div3(angle, rad10, inv10));
         const float tx = xi - kx;
         wgt = sv::expf_nonpos(sv::exact_div5(-((tx * tx) + cty2), weight, rweight));
       };
-      auto vote = [&](float mag, float wgt, int bin, bool valid) {
-        const bool counts = valid && (unsigned)bin < 36u;
-        float* slot = &s_hist[counts ? bin : 0][t];
-        *slot = fmaf(counts ? mag : 0.0f, counts ? wgt : 0.0f, *slot);
-      };
-      const bool fast = cact && aligned;
-      {
-        float wg[kThetaChunk], mg[kThetaChunk];
-        int bn[kThetaChunk];
+      float wg[kThetaChunk], mg[kThetaChunk];
+      float* slot[kThetaChunk];
 #pragma unroll
-        for (int i = 0; i < kThetaChunk; ++i) {
-          // (element first, cast second: __builtin_bit_cast applied directly to a vector-element lvalue reads element 0)
-          const unsigned um = cur[i >> 1][(i & 1) * 2], ua = cur[i >> 1][(i & 1) * 2 + 1];
-          mg[i] = __builtin_bit_cast(float, um);
-          weigh(__builtin_bit_cast(float, ua), xs[i], wg[i], bn[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < kThetaChunk; ++i) vote(mg[i], wg[i], bn[i], fast && xs[i] <= maxx);
+      for (int i = 0; i < kThetaChunk; ++i) {
+        // (element first, cast second: __builtin_bit_cast applied directly to a vector-element lvalue reads element 0)
+        const unsigned um = cur[i >> 1][(i & 1) * 2], ua = cur[i >> 1][(i & 1) * 2 + 1];
+        int bin;
+        weigh(__builtin_bit_cast(float, ua), xs[i], wg[i], bin);
+        const bool counts = cact && xs[i] <= maxx && (unsigned)bin < 36u;
+        slot[i] = &s_hist[counts ? bin : 0][col];
+        mg[i] = counts ? __builtin_bit_cast(float, um) : 0.0f;
+        wg[i] = counts ? wg[i] : 0.0f;
       }
-      // rare (a chunk that crosses a binade with an unlucky fraction, or starts below x = 4): the lane's samples are
-      // gathered one by one.  After the fast path in program order, so that its loads do not sit between the prefetch
-      // and the fast path's wait; a lane takes exactly one of the two paths per chunk, so its raster order is kept.
-      if (__any(cact && !aligned)) {
-        if (cact && !aligned) {
-          const float2* lvl = L.polar + (size_t)(useg - 1) * levelStride;
-          float xi = xs[0];  // re-walked with += 1.0f: the same values as xs[]
-#pragma unroll 1
-          for (int i = 0; i < kThetaChunk; ++i) {
-            if (xi <= maxx) {
-              const float2 e = lvl[crow + (unsigned)round_pos(xi)];
-              float wgt;
-              int bin;
-              weigh(e.y, xi, wgt, bin);
-              vote(e.x, wgt, bin, true);
-            }
-            xi += 1.0f;
+#pragma unroll
+      for (int j = 0; j < kThetaChunk / 2; ++j) {
+#pragma unroll
+        for (int q = 0; q < LANES; ++q) {
+          if (LANES == 1 || sub == q) {
+            // two votes per LDS round trip: both slots are read first, the second takes the first's sum when it is the same slot
+            const float h0 = *slot[2 * j], h1 = *slot[2 * j + 1];
+            const float n0 = fmaf(mg[2 * j], wg[2 * j], h0);
+            const float n1 = fmaf(mg[2 * j + 1], wg[2 * j + 1], slot[2 * j + 1] == slot[2 * j] ? n0 : h1);
+            *slot[2 * j] = n0;
+            *slot[2 * j + 1] = n1;  // (LDS keeps a wave's stores in order: the same slot ends up holding n1)
           }
         }
       }
@@ -793,19 +827,19 @@ __global__ __launch_bounds__(64) void k_thetas(const OctaveState* states, const 
   float outTheta[MAXO];
 #pragma unroll
   for (int i = 0; i < MAXO; ++i) outTheta[i] = -FLT_MAX;
-  if (inside) {
+  if (inside && sub == 0) {
     float maxHist = 0.0f;
     for (int i = 0; i < 36; ++i) {
-      const float h = s_hist[i][t];
+      const float h = s_hist[i][col];
       if (h > maxHist) maxHist = h;
     }
     maxHist *= orientationThreshold;
     float bestMag[MAXO], bestTh[MAXO];
 #pragma unroll
     for (int i = 0; i < MAXO; ++i) { bestMag[i] = 0.0f; bestTh[i] = 0.0f; }
-    float hprev = s_hist[35][t], hb = s_hist[0][t];
+    float hprev = s_hist[35][col], hb = s_hist[0][col];
     for (int b = 0; b < 36; ++b) {
-      const float hnext = s_hist[b == 35 ? 0 : b + 1][t];
+      const float hnext = s_hist[b == 35 ? 0 : b + 1][col];
       // tests of :1064-1068 (circular neighbours) and the weakest kept peak
       if (!(hb < maxHist || hb < hprev || hb < hnext || hb < bestMag[MAXO - 1])) {
         float tmag = hb;
@@ -835,7 +869,7 @@ __global__ __launch_bounds__(64) void k_thetas(const OctaveState* states, const 
       if (bestMag[i] != 0.0f) { outTheta[i] = bestTh[i]; cnt = i + 1; }
     }
   }
-  if (have) {
+  if (have && sub == 0) {
 #pragma unroll
     for (int i = 0; i < MAXO; ++i) set.thetas[octave][(size_t)gi * svp::kMaxOrient + i] = outTheta[i];
     set.thetaCnt[octave][gi] = cnt;
@@ -1391,9 +1425,8 @@ int stage_noise_edges_window(const ListCtx& c) {  // the three of them with one 
   return discard_flagged(c);
 }
 
-OctaveSet make_set(const ssrlcv_sift_plan* plan, char* ws, uint32_t* unitBlocks) {
+OctaveSet make_set(const ssrlcv_sift_plan* plan, char* ws) {
   OctaveSet set;
-  uint32_t blocks = 20;  // upper bound of the orientation kernel's grid: one block per 64 key points of a range
   for (int o = 0; o < svp::kOctaves; ++o) {
     const svp::OctavePlan& oc = plan->oct[o];
     set.L[o] = make_levels(plan, ws, o);
@@ -1402,9 +1435,7 @@ OctaveSet make_set(const ssrlcv_sift_plan* plan, char* ws, uint32_t* unitBlocks)
     set.thetas[o] = (float*)(ws + oc.off_theta);
     set.thetaCnt[o] = (uint32_t*)(ws + oc.off_thetaCnt);
     set.consts[o] = ws + oc.off_descConst;
-    blocks += (oc.cap + 63) / 64;
   }
-  if (unitBlocks) *unitBlocks = blocks;
   return set;
 }
 
@@ -1515,13 +1546,41 @@ inline RangeTable* theta_tab(const ssrlcv_sift_plan* plan, char* ws, int g) { re
 inline RangeTable* desc_tab(const ssrlcv_sift_plan* plan, char* ws, int g) { return (RangeTable*)(ws + plan->off_groups + 256 * (svp::kSampleGroups + g)); }
 inline GroupCtl* group_ctl(const ssrlcv_sift_plan* plan, char* ws, int o) { return (GroupCtl*)(ws + plan->off_groups + 2048) + o; }
 
-template <typename... Args>
-void launch_thetas(uint32_t maxO, unsigned blocks, hipStream_t st, Args... args) {
+// lanes per key point of the orientation kernel, as a shift (see k_thetas).  Developer build: SSRLCV_THETAS_LANES=1|2|4.
+#ifndef SSRLCV_THETAS_LANES_SHIFT
+#define SSRLCV_THETAS_LANES_SHIFT 2
+#endif
+inline int thetas_lanes_shift() {
+  static const int shift = [] {
+    const char* e = svdev::env("SSRLCV_THETAS_LANES");
+    if (!e) return SSRLCV_THETAS_LANES_SHIFT;
+    const int lanes = atoi(e);
+    return lanes >= 4 ? 2 : (lanes >= 2 ? 1 : 0);
+  }();
+  return shift;
+}
+// upper bound of the orientation kernel's grid: one block per 64 >> shift key points of a range
+inline unsigned thetas_grid(const ssrlcv_sift_plan* plan, int oFirst, int oLast, int shift) {
+  unsigned blocks = 20;
+  const uint32_t per = 64u >> shift;
+  for (int o = oFirst; o <= oLast; ++o) blocks += (plan->oct[o].cap + per - 1) / per;
+  return blocks;
+}
+template <int LPKS, typename... Args>
+void launch_thetas_l(uint32_t maxO, unsigned blocks, hipStream_t st, Args... args) {
   switch (maxO) {
-    case 1: hipLaunchKernelGGL(k_thetas<1>, dim3(blocks), dim3(64), 0, st, args...); break;
-    case 2: hipLaunchKernelGGL(k_thetas<2>, dim3(blocks), dim3(64), 0, st, args...); break;
-    case 3: hipLaunchKernelGGL(k_thetas<3>, dim3(blocks), dim3(64), 0, st, args...); break;
-    default: hipLaunchKernelGGL(k_thetas<4>, dim3(blocks), dim3(64), 0, st, args...); break;
+    case 1: hipLaunchKernelGGL((k_thetas<1, LPKS>), dim3(blocks), dim3(64), 0, st, args...); break;
+    case 2: hipLaunchKernelGGL((k_thetas<2, LPKS>), dim3(blocks), dim3(64), 0, st, args...); break;
+    case 3: hipLaunchKernelGGL((k_thetas<3, LPKS>), dim3(blocks), dim3(64), 0, st, args...); break;
+    default: hipLaunchKernelGGL((k_thetas<4, LPKS>), dim3(blocks), dim3(64), 0, st, args...); break;
+  }
+}
+template <typename... Args>
+void launch_thetas(uint32_t maxO, int shift, unsigned blocks, hipStream_t st, Args... args) {
+  switch (shift) {
+    case 0: launch_thetas_l<0>(maxO, blocks, st, args...); break;
+    case 1: launch_thetas_l<1>(maxO, blocks, st, args...); break;
+    default: launch_thetas_l<2>(maxO, blocks, st, args...); break;
   }
 }
 
@@ -1558,18 +1617,23 @@ bool expand_scratch_fits(const ssrlcv_sift_plan* plan, int o, int pieces) {
 int stage_orientations(const ssrlcv_sift_plan* plan, char* ws, hipStream_t caller, svp::PlanAsync* as, bool polarDone) {
   OctaveState* states = (OctaveState*)(ws + plan->off_state);
   const uint32_t maxO = plan->params.maxOrientations;
-  uint32_t unitBlocks = 0;
-  OctaveSet set = make_set(plan, ws, &unitBlocks);
+  OctaveSet set = make_set(plan, ws);
   RangeTable* thetaRanges = theta_tab(plan, ws, 0);
   if (!polarDone) launch_polar(plan, ws, caller);
   // (Round 3 built this kernel with two and with four lanes per key point -- the 36 bins split between the lanes of a
   // group, each bin keeping its sequential chain, the samples' weights shared by DPP: bit-identical, and the same 0.58 ms
   // per 4096^2 image with 1, 2 or 4 lanes.  The kernel is bound by the gather of the polar tables: it reads all 2.2 GB of
   // them once, at the ~4 TB/s that 150-300-byte row segments reach.)
-  hipLaunchKernelGGL(k_build_ranges, dim3(1), dim3(1), 0, caller, states, thetaRanges, 6, 0xFFFFFu);
+  uint32_t thetaSel = 0xFFFFFu;
+#ifdef SSRLCV_INSTRUMENTED_BUILD
+  // timing only (results not valid): orientations of the selected (octave, blur segment) ranges alone -- bit o * 5 + seg
+  if (const char* e = svdev::env("SSRLCV_TIMING_THETAS_SEL")) thetaSel = (uint32_t)strtoul(e, nullptr, 16);
+#endif
+  const int lanesShift = thetas_lanes_shift();
+  hipLaunchKernelGGL(k_build_ranges, dim3(1), dim3(1), 0, caller, states, thetaRanges, 6 - lanesShift, thetaSel);
   SSRLCV_HIP_TRY(hipMemsetAsync(group_ctl(plan, ws, 0), 0, sizeof(GroupCtl) * svp::kOctaves, caller));
   const float lambdaO = plan->params.orientationContribWidth, othr = plan->params.orientationThreshold;
-  launch_thetas(maxO, unitBlocks, caller, (const OctaveState*)states, (const RangeTable*)thetaRanges, set, lambdaO, othr);
+  launch_thetas(maxO, lanesShift, thetas_grid(plan, 0, svp::kOctaves - 1, lanesShift), caller, (const OctaveState*)states, (const RangeTable*)thetaRanges, set, lambdaO, othr);
   // The four expansions are independent chains of ~30 us each (launch-bound on the short lists): octave 1's
   // runs on one side stream, those of octaves 2 and 3 on the other, beside octave 0's on the caller's stream.
   if (as) {
@@ -1610,7 +1674,7 @@ unsigned desc_blocks(const ssrlcv_sift_plan* plan, int oFirst, int oLast, unsign
 // fillDescriptors (src/SIFT_FeatureFactory.cu:131-166,475-549), all octaves in one launch (book_features first)
 int stage_descriptors(const ssrlcv_sift_plan* plan, char* ws, ssrlcv_sift_feature* features, hipStream_t caller) {
   OctaveState* states = (OctaveState*)(ws + plan->off_state);
-  OctaveSet set = make_set(plan, ws, nullptr);
+  OctaveSet set = make_set(plan, ws);
   RangeTable* descRanges = desc_tab(plan, ws, 0);
   uint32_t* featBase = (uint32_t*)(ws + plan->oct[0].off_featBase);
   unsigned maxBlocks = 1;
@@ -1636,16 +1700,16 @@ int stage_sampling_pipelined(const ssrlcv_sift_plan* plan, char* ws, ssrlcv_sift
   const float lambdaO = plan->params.orientationContribWidth, othr = plan->params.orientationThreshold;
   const float lambdaD = plan->params.descriptorContribWidth;
   uint32_t* featBase = (uint32_t*)(ws + plan->oct[0].off_featBase);
-  OctaveSet setT = make_set(plan, ws, nullptr);  // the lists as the chains left them: what k_thetas reads
+  OctaveSet setT = make_set(plan, ws);  // the lists as the chains left them: what k_thetas reads
   for (int o = 0; o < svp::kOctaves; ++o) plan->listInB[o] ^= 1;
-  OctaveSet setD = make_set(plan, ws, nullptr);  // the expanded lists
+  OctaveSet setD = make_set(plan, ws);  // the expanded lists
   for (int o = 0; o < svp::kOctaves; ++o) plan->listInB[o] ^= 1;  // (launch_expand reads the un-flipped state)
   const hipStream_t gs[svp::kSampleGroups] = {caller, as->chain, as->chain2, as->table};
+  const int lanesShift = thetas_lanes_shift();
   unsigned thetaBlocks[svp::kSampleGroups], descBlocks[svp::kSampleGroups], constBlocks[svp::kSampleGroups];
   for (int g = 0; g < svp::kSampleGroups; ++g) {
     const int oFirst = g < kOct0Groups ? 0 : 1, oLast = g < kOct0Groups ? 0 : svp::kOctaves - 1;
-    thetaBlocks[g] = 20;
-    for (int o = oFirst; o <= oLast; ++o) thetaBlocks[g] += (plan->oct[o].cap + 63) / 64;
+    thetaBlocks[g] = thetas_grid(plan, oFirst, oLast, lanesShift);
     unsigned mx = 1;
     descBlocks[g] = desc_blocks(plan, oFirst, oLast, &mx) * kWaveKernelOversubscription;
     constBlocks[g] = mx * (unsigned)(oLast - oFirst + 1);
@@ -1654,12 +1718,12 @@ int stage_sampling_pipelined(const ssrlcv_sift_plan* plan, char* ws, ssrlcv_sift
   SSRLCV_HIP_TRY(hipMemsetAsync(featBase, 0, 4 * svp::kOctaves, caller));  // octave 0's features start at 0, known now
   // (developer build: SSRLCV_SAMPLING_IRREGULAR=1 takes the fallback for blur indices that are not an ordered partition)
   static const bool forceIrregular = svdev::env("SSRLCV_SAMPLING_IRREGULAR") != nullptr;
-  hipLaunchKernelGGL(k_build_group_ranges, dim3(1), dim3(1), 0, caller, (const OctaveState*)states, theta_tab(plan, ws, 0), group_ctl(plan, ws, 0), 6,
+  hipLaunchKernelGGL(k_build_group_ranges, dim3(1), dim3(1), 0, caller, (const OctaveState*)states, theta_tab(plan, ws, 0), group_ctl(plan, ws, 0), 6 - lanesShift,
                      forceIrregular);
   SSRLCV_HIP_TRY(hipEventRecord(as->groupFork, caller));
   for (int g = 1; g < svp::kSampleGroups; ++g) SSRLCV_HIP_TRY(hipStreamWaitEvent(gs[g], as->groupFork, 0));
   for (int g = 0; g < svp::kSampleGroups; ++g)
-    launch_thetas(maxO, thetaBlocks[g], gs[g], (const OctaveState*)states, (const RangeTable*)theta_tab(plan, ws, g), setT, lambdaO, othr);
+    launch_thetas(maxO, lanesShift, thetaBlocks[g], gs[g], (const OctaveState*)states, (const RangeTable*)theta_tab(plan, ws, g), setT, lambdaO, othr);
   // octave 0: three pieces of one expansion, piece g behind piece g - 1
   for (int g = 0; g < kOct0Groups; ++g) {
     if (g > 0) SSRLCV_HIP_TRY(hipStreamWaitEvent(gs[g], as->groupExpanded[g - 1], 0));
