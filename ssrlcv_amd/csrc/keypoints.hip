@@ -486,9 +486,6 @@ __device__ __forceinline__ int round_coord(float v) {
 // independent, but not the reference's sum: thetas agreed to ~1e-6 and a handful of peak decisions per million key
 // points flipped.
 constexpr int kThetaChunk = 8;
-#ifndef SSRLCV_THETAS_DEPTH
-#define SSRLCV_THETAS_DEPTH 1  // chunks requested ahead of the one being evaluated (1 or 2; 2 measured in round 5: no faster)
-#endif
 
 // Work list of the two sampling kernels: the key points of ALL octaves in one launch.  Every octave's list is cut at
 // its blur-segment boundaries (a segment = one DoG level = one polar table = one class of window sizes: windows grow
@@ -669,8 +666,7 @@ __global__ __launch_bounds__(64) void k_thetas(const OctaveState* states, const 
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     // A cursor walks the window chunk by chunk in the reference's order (x += 1.0f CW times, then the next row); the
-    // chunk being evaluated is SSRLCV_THETAS_DEPTH chunks behind the one being requested.  The cursor is the same in
-    // every lane of a group.
+    // chunk being evaluated is one chunk behind the one being requested.  The cursor is the same in every lane of a group.
     struct Cursor { float x, y, ty2; unsigned rowoff; bool act; };
     Cursor cf;  // the next chunk to request
     cf.x = minx;
@@ -713,33 +709,20 @@ __global__ __launch_bounds__(64) void k_thetas(const OctaveState* states, const 
 #pragma unroll
       for (int j = 0; j < kThetaChunk / 2; ++j) into[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off + 16u * LANES * j), 0, 0);
     };
-    Chunk q0, q1;      // requested chunks, oldest first (q1 only at depth 2)
-    Cursor c0, c1;     // their cursors
+    // One chunk is requested ahead of the one being evaluated.  The loop is written out for two chunk buffers that trade
+    // places (the compiler's rotation of one pair cost 40 register moves per chunk); two chunks ahead was measured in
+    // round 5 and is no faster.
+    Chunk qa, qb;
+    Cursor ca, cb;
 #pragma unroll
-    for (int j = 0; j < kThetaChunk / 2; ++j) q0[j] = q1[j] = u32x4{0u, 0u, 0u, 0u};
-    c0 = cf;
-    fetch(cf, q0);
+    for (int j = 0; j < kThetaChunk / 2; ++j) qa[j] = qb[j] = u32x4{0u, 0u, 0u, 0u};
+    ca = cf;
+    fetch(cf, qa);
     advance(cf);
-    c1 = cf;
-    if (SSRLCV_THETAS_DEPTH == 2) {
-      fetch(cf, q1);
-      advance(cf);
-    }
-    while (__any(c0.act)) {
-      u32x4 cur[kThetaChunk / 2];
-#pragma unroll
-      for (int j = 0; j < kThetaChunk / 2; ++j) cur[j] = q0[j];
-      const Cursor cc = c0;
-      if (SSRLCV_THETAS_DEPTH == 2) {
-#pragma unroll
-        for (int j = 0; j < kThetaChunk / 2; ++j) q0[j] = q1[j];
-        c0 = c1;
-        c1 = cf;
-        fetch(cf, q1);
-      } else {
-        c0 = cf;
-        fetch(cf, q0);
-      }
+    cb = cf;
+    auto step = [&](Chunk& cur, const Cursor& cc, Chunk& nxt, Cursor& cn) __attribute__((always_inline)) {
+      cn = cf;
+      fetch(cf, nxt);
       advance(cf);
       // the chunk's coordinates (sample s of the chunk: x_0 `+= 1.0f` s times; see advance); this lane keeps those of its
       // eight samples s = 2 (j LANES + sub) + h
@@ -787,7 +770,7 @@ __global__ __launch_bounds__(64) void k_thetas(const OctaveState* states, const 
       // histogram: evaluated together they overlap their long dependent chains (the Horner steps, the divisions).
       // (2) The histogram updates, strictly in raster order, branch-free within a lane: a sample that does not count
       // (past the row's end, or bin 36 from an angle one ulp below 2 pi, which the reference's array has no slot for)
-      // adds fmaf(0, 0, h) = h to bin 0.
+      // adds fmaf(0, w, h) = h to bin 0.
       auto weigh = [&](float ang, float xi, float& wgt, int& bin) {
         const float angle = fmod_2pi_above(ang + (2.0f * pi), 2.0f * pi);
         bin = (int)floorf(sv::exact_div3(angle, rad10, inv10));
@@ -804,8 +787,7 @@ __global__ __launch_bounds__(64) void k_thetas(const OctaveState* states, const 
         weigh(__builtin_bit_cast(float, ua), xs[i], wg[i], bin);
         const bool counts = cact && xs[i] <= maxx && (unsigned)bin < 36u;
         slot[i] = &s_hist[counts ? bin : 0][col];
-        mg[i] = counts ? __builtin_bit_cast(float, um) : 0.0f;
-        wg[i] = counts ? wg[i] : 0.0f;
+        mg[i] = counts ? __builtin_bit_cast(float, um) : 0.0f;  // (the weight is finite: a zero magnitude is enough)
       }
 #pragma unroll
       for (int j = 0; j < kThetaChunk / 2; ++j) {
@@ -819,8 +801,18 @@ __global__ __launch_bounds__(64) void k_thetas(const OctaveState* states, const 
             *slot[2 * j] = n0;
             *slot[2 * j + 1] = n1;  // (LDS keeps a wave's stores in order: the same slot ends up holding n1)
           }
+          // The order of the phases is an order between LANES, which the language knows nothing about: to the compiler
+          // `if (sub == 0) X; if (sub == 1) X;` is X executed once by every thread, and it has merged the phases on that
+          // ground (two lanes, round 6: every lane voted at once).  A wave barrier -- no instruction, but convergent and
+          // with side effects -- keeps each phase a region of its own, in program order.
+          if (LANES > 1) __builtin_amdgcn_wave_barrier();
         }
       }
+    };
+    while (__any(ca.act)) {
+      step(qa, ca, qb, cb);
+      if (!__any(cb.act)) break;
+      step(qb, cb, qa, ca);
     }
   }
   uint32_t cnt = 0;
