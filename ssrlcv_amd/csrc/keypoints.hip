@@ -1210,8 +1210,9 @@ LevelSet make_levels(const ssrlcv_sift_plan* plan, char* ws, int o) {
   return L;
 }
 
-// the polar tables of all four octaves in one launch (the three small ones were each a launch of a few waves per CU)
-void launch_polar(const ssrlcv_sift_plan* plan, char* ws, hipStream_t st) {
+// the polar tables of the octaves oFirst..oLast in one launch (the three small ones were each a launch of a few waves per CU):
+// the octaves in front of the range own no block (start 0, like the first one of the range), those behind it start past the grid
+void launch_polar(const ssrlcv_sift_plan* plan, char* ws, hipStream_t st, int oFirst = 0, int oLast = svp::kOctaves - 1) {
   PolarJobs jobs;
   uint32_t pos = 0;
   for (int o = 0; o < svp::kOctaves; ++o) {
@@ -1220,7 +1221,7 @@ void launch_polar(const ssrlcv_sift_plan* plan, char* ws, hipStream_t st) {
     jobs.out[o] = (float2*)(ws + oc.off_polar);
     jobs.start[o] = pos;
     jobs.tilesX[o] = (oc.w + 255) / 256;
-    pos += jobs.tilesX[o] * ((oc.h + kPolRows - 1) / kPolRows);
+    if (o >= oFirst && o <= oLast) pos += jobs.tilesX[o] * ((oc.h + kPolRows - 1) / kPolRows);
   }
   jobs.start[svp::kOctaves] = pos;
   hipLaunchKernelGGL(k_polar, dim3(pos), dim3(256), 0, st, jobs);
@@ -1606,25 +1607,64 @@ bool expand_scratch_fits(const ssrlcv_sift_plan* plan, int o, int pieces) {
 
 // computeKeyPointOrientations (src/FeatureFactory.cu:540-632) for all octaves: gradient tables (unless the caller built
 // them on a side stream already), one orientation launch, the expansion of every key point into its orientations
-int stage_orientations(const ssrlcv_sift_plan* plan, char* ws, hipStream_t caller, svp::PlanAsync* as, bool polarDone) {
+// Round 6 experiment (SSRLCV_THETAS_SPLIT=1): the orientation kernel's run time is largely that of its longest windows (a
+// blur-3 key point alone takes 0.2 ms, whatever the octave), and octave 0's tables are three quarters of k_polar.  So
+// describe_impl builds the small octaves' tables first and queues their orientations and expansions on a side stream `st`
+// (behind their list chains and tables), beside octave 0's tables; octave 0's orientation launch follows its tables on the
+// caller's stream (stage_orientations, restInFlight).  The caller has zeroed the octaves' GroupCtl.  Exact, and no faster:
+// what runs beside the table kernel slows it by what it takes.
+int queue_rest_orientations(const ssrlcv_sift_plan* plan, char* ws, hipStream_t st, svp::PlanAsync* as) {
+  OctaveState* states = (OctaveState*)(ws + plan->off_state);
+  const uint32_t maxO = plan->params.maxOrientations;
+  OctaveSet set = make_set(plan, ws);
+  uint32_t thetaSel = 0xFFFFFu;
+#ifdef SSRLCV_INSTRUMENTED_BUILD
+  if (const char* e = svdev::env("SSRLCV_TIMING_THETAS_SEL")) thetaSel = (uint32_t)strtoul(e, nullptr, 16);
+#endif
+  const int lanesShift = thetas_lanes_shift();
+  RangeTable* restRanges = theta_tab(plan, ws, 1);
+  hipLaunchKernelGGL(k_build_ranges, dim3(1), dim3(1), 0, st, states, restRanges, 6 - lanesShift, 0xFFFFFu & ~0x1Fu & thetaSel);
+  launch_thetas(maxO, lanesShift, thetas_grid(plan, 1, svp::kOctaves - 1, lanesShift), st, (const OctaveState*)states, (const RangeTable*)restRanges,
+                set, plan->params.orientationContribWidth, plan->params.orientationThreshold);
+  for (int o = 1; o < svp::kOctaves; ++o) {
+    int rc = launch_expand(plan, ws, o, 0, 1, st);
+    if (rc) return rc;
+    plan->listInB[o] ^= 1;
+  }
+  SSRLCV_HIP_TRY(hipEventRecord(as->expandJoin[1], st));
+  return SSRLCV_OK;
+}
+
+int stage_orientations(const ssrlcv_sift_plan* plan, char* ws, hipStream_t caller, svp::PlanAsync* as, bool polarDone, bool restInFlight = false) {
   OctaveState* states = (OctaveState*)(ws + plan->off_state);
   const uint32_t maxO = plan->params.maxOrientations;
   OctaveSet set = make_set(plan, ws);
   RangeTable* thetaRanges = theta_tab(plan, ws, 0);
-  if (!polarDone) launch_polar(plan, ws, caller);
-  // (Round 3 built this kernel with two and with four lanes per key point -- the 36 bins split between the lanes of a
-  // group, each bin keeping its sequential chain, the samples' weights shared by DPP: bit-identical, and the same 0.58 ms
-  // per 4096^2 image with 1, 2 or 4 lanes.  The kernel is bound by the gather of the polar tables: it reads all 2.2 GB of
-  // them once, at the ~4 TB/s that 150-300-byte row segments reach.)
   uint32_t thetaSel = 0xFFFFFu;
 #ifdef SSRLCV_INSTRUMENTED_BUILD
   // timing only (results not valid): orientations of the selected (octave, blur segment) ranges alone -- bit o * 5 + seg
   if (const char* e = svdev::env("SSRLCV_TIMING_THETAS_SEL")) thetaSel = (uint32_t)strtoul(e, nullptr, 16);
 #endif
   const int lanesShift = thetas_lanes_shift();
-  hipLaunchKernelGGL(k_build_ranges, dim3(1), dim3(1), 0, caller, states, thetaRanges, 6 - lanesShift, thetaSel);
-  SSRLCV_HIP_TRY(hipMemsetAsync(group_ctl(plan, ws, 0), 0, sizeof(GroupCtl) * svp::kOctaves, caller));
   const float lambdaO = plan->params.orientationContribWidth, othr = plan->params.orientationThreshold;
+  // (Round 3 built this kernel with two and with four lanes per key point -- the 36 bins split between the lanes of a
+  // group, each bin keeping its sequential chain, the samples' weights shared by DPP: bit-identical, and the same 0.58 ms
+  // per 4096^2 image with 1, 2 or 4 lanes.  Round 6's form -- one histogram, the lanes taking turns -- is k_thetas' LPKS.)
+  if (restInFlight) {
+    // describe_impl has queued the small octaves' orientations and expansions on a side stream (queue_rest_orientations):
+    // octave 0's follow its tables here
+    hipLaunchKernelGGL(k_build_ranges, dim3(1), dim3(1), 0, caller, states, thetaRanges, 6 - lanesShift, 0x1Fu & thetaSel);
+    launch_thetas(maxO, lanesShift, thetas_grid(plan, 0, 0, lanesShift), caller, (const OctaveState*)states, (const RangeTable*)thetaRanges, set,
+                  lambdaO, othr);
+    int rc = launch_expand(plan, ws, 0, 0, 1, caller);
+    if (rc) return rc;
+    plan->listInB[0] ^= 1;
+    SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->expandJoin[1], 0));
+    return SSRLCV_OK;
+  }
+  SSRLCV_HIP_TRY(hipMemsetAsync(group_ctl(plan, ws, 0), 0, sizeof(GroupCtl) * svp::kOctaves, caller));
+  if (!polarDone) launch_polar(plan, ws, caller);
+  hipLaunchKernelGGL(k_build_ranges, dim3(1), dim3(1), 0, caller, states, thetaRanges, 6 - lanesShift, thetaSel);
   launch_thetas(maxO, lanesShift, thetas_grid(plan, 0, svp::kOctaves - 1, lanesShift), caller, (const OctaveState*)states, (const RangeTable*)thetaRanges, set, lambdaO, othr);
   // The four expansions are independent chains of ~30 us each (launch-bound on the short lists): octave 1's
   // runs on one side stream, those of octaves 2 and 3 on the other, beside octave 0's on the caller's stream.
@@ -1808,13 +1848,28 @@ static int describe_impl(const ssrlcv_sift_plan* plan, void* workspace, ssrlcv_s
   // caller's stream.
   svp::PlanAsync* as = svp::plan_async(plan);
   const hipStream_t caller = (hipStream_t)stream;
+  // Developer build, SSRLCV_THETAS_SPLIT=1 (round 6; exact, measured, NOT the default -- describe 3.09-3.11 ms per image either
+  // way, profiles/r06_kernel_ab.txt): the small octaves' tables first and their orientations beside octave 0's tables.
+  static const bool splitWanted = svdev::env("SSRLCV_THETAS_SPLIT") != nullptr;
+  static const bool pipelinedSampling = svdev::env("SSRLCV_SAMPLING_PIPELINED") != nullptr;
+  const bool splitRest = as && stop >= 6 && !plan->polarInFlight && splitWanted && !pipelinedSampling;
+  if (splitRest) SSRLCV_HIP_TRY(hipMemsetAsync(group_ctl(plan, ws, 0), 0, sizeof(GroupCtl) * svp::kOctaves, caller));
   if (as) {
     SSRLCV_HIP_TRY(hipEventRecord(as->fork, caller));
     SSRLCV_HIP_TRY(hipStreamWaitEvent(as->chain, as->fork, 0));
     SSRLCV_HIP_TRY(hipStreamWaitEvent(as->chain2, as->fork, 0));
     SSRLCV_HIP_TRY(hipStreamWaitEvent(as->table, as->fork, 0));
     if ((svp::stream_priority_mode() & 1)) SSRLCV_HIP_TRY(hipStreamWaitEvent(as->polar, as->fork, 0));
-    if (stop >= 6 && !plan->polarInFlight) launch_polar(plan, ws, (svp::stream_priority_mode() & 1) ? as->polar : as->table);
+    if (stop >= 6 && !plan->polarInFlight) {
+      const hipStream_t ps = (svp::stream_priority_mode() & 1) ? as->polar : as->table;
+      if (splitRest) {  // the small octaves' tables first: their orientations start behind them (below)
+        launch_polar(plan, ws, ps, 1, svp::kOctaves - 1);
+        SSRLCV_HIP_TRY(hipEventRecord(as->polarDone[1], ps));
+        launch_polar(plan, ws, ps, 0, 0);
+      } else {
+        launch_polar(plan, ws, ps);
+      }
+    }
   }
   // (Round 5 built the chains of all four octaves as five launches on one stream -- every partition one decoupled look-back
   // pass, its class totals counted by the launch before it, the bookkeeping in a thread of the launch that produced its inputs;
@@ -1838,6 +1893,12 @@ static int describe_impl(const ssrlcv_sift_plan* plan, void* workspace, ssrlcv_s
     }
   }
   plan->chain0InFlight = 0;
+  if (splitRest) {  // behind the chains of octaves 2-3 on their stream: octave 1's chain, the small octaves' tables, then their orientations
+    SSRLCV_HIP_TRY(hipStreamWaitEvent(as->chain2, as->join[1], 0));
+    SSRLCV_HIP_TRY(hipStreamWaitEvent(as->chain2, as->polarDone[1], 0));
+    const int rc = queue_rest_orientations(plan, ws, as->chain2, as);
+    if (rc) return rc;
+  }
   if (as) {  // the polar stream joins too (its tables are read by the sampling kernels below)
     SSRLCV_HIP_TRY(hipEventRecord(as->join[svp::kOctaves], (svp::stream_priority_mode() & 1) ? as->polar : as->table));
     SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->join[svp::kOctaves], 0));
@@ -1851,7 +1912,6 @@ static int describe_impl(const ssrlcv_sift_plan* plan, void* workspace, ssrlcv_s
   // default: the step took 10.29 ms with it against 10.19 without (profiles/r05_schedule_ab.txt) -- the resident one-wave
   // orientation blocks hold 9 KB of LDS each, 13 per CU, and the descriptor blocks beside them run at a quarter of their
   // occupancy; both kernels also draw on the same gather bandwidth of the polar tables.
-  static const bool pipelinedSampling = svdev::env("SSRLCV_SAMPLING_PIPELINED") != nullptr;
   if (stop >= 7 && as && pipelinedSampling && expand_scratch_fits(plan, 0, kOct0Groups)) {
     int rc = stage_sampling_pipelined(plan, ws, features, numFeatures, caller, as);
     if (rc) return rc;
@@ -1859,7 +1919,7 @@ static int describe_impl(const ssrlcv_sift_plan* plan, void* workspace, ssrlcv_s
     return SSRLCV_OK;
   }
   if (stop >= 6) {
-    int rc = stage_orientations(plan, ws, caller, as, as != nullptr);
+    int rc = stage_orientations(plan, ws, caller, as, as != nullptr, splitRest);
     if (rc) return rc;
   }
   book_features(plan, ws, numFeatures, caller);

@@ -398,6 +398,7 @@ print("FEATURES OK")
     {"SSRLCV_PHASED": "1"}, {"SSRLCV_PHASED": "2"},                        # build_dog: the octave chain on one stream, levels 4-5 + DoG passes beside it
     {"SSRLCV_THETAS_LANES": "1"}, {"SSRLCV_THETAS_LANES": "2"}, {"SSRLCV_THETAS_LANES": "4"},  # round 6: lanes that share a key point's orientation window
     {"SSRLCV_THETAS_LANES": "2", "SSRLCV_SAMPLING_PIPELINED": "1"},
+    {"SSRLCV_THETAS_SPLIT": "1"},                                          # ... the small octaves' tables first, their orientations beside octave 0's tables
 ], ids=lambda v: "+".join(k.replace("SSRLCV_", "") + "=" + x for k, x in v.items()))
 def test_every_sampling_schedule_is_bit_exact(variant):
     """Round 5's schedule experiments (developer build; exact, measured, not the defaults: profiles/r05_schedule_ab.txt): the
