@@ -195,10 +195,27 @@ struct ConvArgs {
   // k_gauss_mfma2 / k_gauss_tile: also emit the 2x2 bin of the output (S5, the next octave's input) from the accumulators
   float* binOut;  // (w/2) x (h/2), nullptr: no bin
   float wgt[33];  // taps are symmetric (w[k] == w[2R-k] bit for bit): only k = 0..R travel, in SGPRs
+  uint32_t xcdStrips;  // strip kernels: neighbouring strips on the same XCD (strip_block)
 #ifdef SSRLCV_STAMPS
   long long* stamps;  // tools/gauss_lab.hip: s_memtime stamps of one block, [wave][step][8]
 #endif
 };
+// Which strip (x) and row block (y) a workgroup of a strip kernel takes.  Workgroups go to the eight XCDs round-robin by their
+// linear id, so with the plain mapping the strips left and right of a strip -- which read the same 2R halo columns -- run on
+// other XCDs and every halo column is pulled through two L2s.  With a strip count that is a multiple of eight each XCD takes
+// gridDim.x / 8 neighbouring strips, all of their row blocks, in the launch order of its workgroups (row block by row block,
+// so that neighbours march down the image together).
+__device__ __forceinline__ void strip_block(bool xcdStrips, uint32_t& sx, uint32_t& by) {
+  sx = blockIdx.x;
+  by = blockIdx.y;
+  const uint32_t nx = gridDim.x;
+  if (xcdStrips && (nx & 7u) == 0u) {
+    const uint32_t p = by * nx + sx, per = nx >> 3, q = p >> 3;
+    sx = (p & 7u) * per + q % per;
+    by = q / per;
+  }
+}
+
 // Instrumentation (results unchanged): -DSSRLCV_STAMPS builds write s_memtime stamps of one block into a buffer of their own.
 // Only the tools/ lab programs build that way (csrc/dev_switch.h refuses the define in a library build).
 #ifdef SSRLCV_STAMPS
@@ -356,8 +373,10 @@ __global__ __launch_bounds__(kTX) void k_gauss_strip(ConvArgs a) {
   float* s_h = reinterpret_cast<float*>(&s_h4[0][0]);
 
   const int W = (int)a.w, H = (int)a.h;
-  const int x0 = blockIdx.x * kTX;  // host: x0 + kTX <= W
-  const int y0 = blockIdx.y * (int)a.rowsPerBlock;
+  uint32_t sbx, sby;
+  strip_block(a.xcdStrips != 0u, sbx, sby);
+  const int x0 = (int)sbx * kTX;  // host: x0 + kTX <= W
+  const int y0 = (int)sby * (int)a.rowsPerBlock;
   int nrows = (int)a.rowsPerBlock;
   if (y0 + nrows > H) nrows = H - y0;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -609,8 +628,10 @@ __global__ __launch_bounds__(kMfmaThreads) void k_gauss_mfma2(ConvArgs a) {
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) float s_mem[];
   const int W = (int)a.w, H = (int)a.h;
-  const int x0 = blockIdx.x * TW;
-  const int y0 = blockIdx.y * (int)a.rowsPerBlock;
+  uint32_t sbx, sby;
+  strip_block(a.xcdStrips != 0u, sbx, sby);
+  const int x0 = (int)sbx * TW;
+  const int y0 = (int)sby * (int)a.rowsPerBlock;
   int nrows = (int)a.rowsPerBlock;
   if (y0 + nrows > H) nrows = H - y0;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1668,6 +1689,8 @@ int launch_conv(const float* in, float* out, float* tmp, uint32_t w, uint32_t h,
   a.x0base = 0;
   a.rowsPerBlock = h;
   a.binOut = nullptr;
+  static const bool noXcdStrips = svdev::env("SSRLCV_NO_XCD_STRIPS") != nullptr;  // (developer build: the plain block order)
+  a.xcdStrips = noXcdStrips ? 0u : 1u;
   if (binned) *binned = false;
   static const bool noBinFold = svdev::env("SSRLCV_NO_BIN_FUSION") != nullptr;
   const bool canBin = binOut && !noBinFold && (w & 3) == 0 && (h & 1) == 0 && (reinterpret_cast<size_t>(binOut) & 7) == 0;
