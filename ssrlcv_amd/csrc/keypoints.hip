@@ -522,6 +522,17 @@ __device__ __forceinline__ void build_ranges(const OctaveState* st, RangeTable* 
   tab->total = pos;
 }
 __global__ void k_build_ranges(const OctaveState* st, RangeTable* tab, int unitShift, uint32_t sel) { build_ranges(st, tab, unitShift, sel); }
+// k_book_featbase + the descriptor work list of all octaves in one single-thread launch (two launches were ~10 us of gap)
+__global__ void k_book_and_desc_ranges(OctaveState* st, uint32_t* featBase, uint32_t* numFeatures, uint32_t maxFeatures, RangeTable* tab) {
+  uint32_t tot = 0;
+  for (int o = 0; o < svp::kOctaves; ++o) {
+    featBase[o] = tot;
+    tot += st[o].hasExtrema ? (uint32_t)st[o].n : 0u;
+  }
+  if (tot > maxFeatures) tot = maxFeatures;
+  *numFeatures = tot;
+  build_ranges(st, tab, 0, 0xFFFFFu);
+}
 
 // ---- the sampling kernels in groups (round 5) ---------------------------------------------------------------------------------
 // k_thetas is a latency chain per lane (VALU at a quarter of its issue rate), k_descriptors is bound by vector-instruction
@@ -1579,7 +1590,15 @@ void launch_thetas(uint32_t maxO, int shift, unsigned blocks, hipStream_t st, Ar
 
 // piece g of `pieces` of octave o's expansion (thrust::remove of the -FLT_MAX / -1 slots + expandKeyPoints, :594-611) on
 // stream es; the tile descriptors of piece g live in its own slice of the octave's partition scratch
-int launch_expand(const ssrlcv_sift_plan* plan, char* ws, int o, int g, int pieces, hipStream_t es) {
+// (scratchZeroed: expand_prepare has cleared the piece's tile descriptors on some stream `es` is ordered behind)
+int expand_prepare(const ssrlcv_sift_plan* plan, char* ws, int o, int g, hipStream_t st) {
+  const svp::OctavePlan& oc = plan->oct[o];
+  const uint32_t capTiles = (oc.cap * plan->params.maxOrientations + svs::kThreads * kExpandItems - 1) / (svs::kThreads * kExpandItems);
+  const size_t scanBytes = svs::workspace_bytes<1>(capTiles);
+  SSRLCV_HIP_TRY(hipMemsetAsync(ws + oc.off_part + (size_t)g * scanBytes, 0, scanBytes, st));
+  return SSRLCV_OK;
+}
+int launch_expand(const ssrlcv_sift_plan* plan, char* ws, int o, int g, int pieces, hipStream_t es, bool scratchZeroed = false) {
   const svp::OctavePlan& oc = plan->oct[o];
   const uint32_t maxO = plan->params.maxOrientations, cap = oc.cap;
   OctaveState* states = (OctaveState*)(ws + plan->off_state);
@@ -1588,7 +1607,7 @@ int launch_expand(const ssrlcv_sift_plan* plan, char* ws, int o, int g, int piec
   const uint32_t capTiles = (cap * maxO + svs::kThreads * kExpandItems - 1) / (svs::kThreads * kExpandItems);
   const size_t scanBytes = svs::workspace_bytes<1>(capTiles);
   char* part = ws + oc.off_part + (size_t)g * scanBytes;
-  SSRLCV_HIP_TRY(hipMemsetAsync(part, 0, scanBytes, es));
+  if (!scratchZeroed) SSRLCV_HIP_TRY(hipMemsetAsync(part, 0, scanBytes, es));
   // a grid for the usual list lengths (a tenth of the capacity), persistent over the tiles
   unsigned blocks = capTiles / 8 + 1;
   blocks = blocks > 1024u ? 1024u : blocks;
@@ -1635,7 +1654,34 @@ int queue_rest_orientations(const ssrlcv_sift_plan* plan, char* ws, hipStream_t 
   return SSRLCV_OK;
 }
 
-int stage_orientations(const ssrlcv_sift_plan* plan, char* ws, hipStream_t caller, svp::PlanAsync* as, bool polarDone, bool restInFlight = false) {
+// the stream octave o's expansion runs on
+inline hipStream_t expand_stream(svp::PlanAsync* as, hipStream_t caller, int o) {
+  return !as || o == 0 ? caller : (o == 1 ? as->chain : (o == 2 ? as->table : as->chain2));
+}
+// What the orientation stage can do before the gradient tables are complete (describe_impl calls it behind the list chains,
+// in front of its wait for the table stream; round 6): the control words, the orientation work list, and -- on the streams
+// the expansions will run on -- the clearing of their tile descriptors.
+int orientations_prologue(const ssrlcv_sift_plan* plan, char* ws, hipStream_t caller, svp::PlanAsync* as) {
+  OctaveState* states = (OctaveState*)(ws + plan->off_state);
+  uint32_t thetaSel = 0xFFFFFu;
+#ifdef SSRLCV_INSTRUMENTED_BUILD
+  if (const char* e = svdev::env("SSRLCV_TIMING_THETAS_SEL")) thetaSel = (uint32_t)strtoul(e, nullptr, 16);
+#endif
+  SSRLCV_HIP_TRY(hipMemsetAsync(group_ctl(plan, ws, 0), 0, sizeof(GroupCtl) * svp::kOctaves, caller));
+  hipLaunchKernelGGL(k_build_ranges, dim3(1), dim3(1), 0, caller, states, theta_tab(plan, ws, 0), 6 - thetas_lanes_shift(), thetaSel);
+  if (as) {
+    SSRLCV_HIP_TRY(hipEventRecord(as->expandFork, caller));
+    for (int o = 1; o < svp::kOctaves; ++o) SSRLCV_HIP_TRY(hipStreamWaitEvent(expand_stream(as, caller, o), as->expandFork, 0));
+  }
+  for (int o = 0; o < svp::kOctaves; ++o) {
+    const int rc = expand_prepare(plan, ws, o, 0, expand_stream(as, caller, o));
+    if (rc) return rc;
+  }
+  return SSRLCV_OK;
+}
+
+int stage_orientations(const ssrlcv_sift_plan* plan, char* ws, hipStream_t caller, svp::PlanAsync* as, bool polarDone, bool restInFlight = false,
+                       bool prologueDone = false) {
   OctaveState* states = (OctaveState*)(ws + plan->off_state);
   const uint32_t maxO = plan->params.maxOrientations;
   OctaveSet set = make_set(plan, ws);
@@ -1662,35 +1708,37 @@ int stage_orientations(const ssrlcv_sift_plan* plan, char* ws, hipStream_t calle
     SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->expandJoin[1], 0));
     return SSRLCV_OK;
   }
-  SSRLCV_HIP_TRY(hipMemsetAsync(group_ctl(plan, ws, 0), 0, sizeof(GroupCtl) * svp::kOctaves, caller));
+  if (!prologueDone) orientations_prologue(plan, ws, caller, as);
   if (!polarDone) launch_polar(plan, ws, caller);
-  hipLaunchKernelGGL(k_build_ranges, dim3(1), dim3(1), 0, caller, states, thetaRanges, 6 - lanesShift, thetaSel);
   launch_thetas(maxO, lanesShift, thetas_grid(plan, 0, svp::kOctaves - 1, lanesShift), caller, (const OctaveState*)states, (const RangeTable*)thetaRanges, set, lambdaO, othr);
-  // The four expansions are independent chains of ~30 us each (launch-bound on the short lists): octave 1's
-  // runs on one side stream, those of octaves 2 and 3 on the other, beside octave 0's on the caller's stream.
+  // The four expansions are independent chains of ~30 us each (launch-bound on the short lists): those of octaves 1-3 run on
+  // the three side streams beside octave 0's on the caller's stream (their tile descriptors were cleared by the prologue).
   if (as) {
-    SSRLCV_HIP_TRY(hipEventRecord(as->expandFork, caller));
-    SSRLCV_HIP_TRY(hipStreamWaitEvent(as->chain, as->expandFork, 0));
-    SSRLCV_HIP_TRY(hipStreamWaitEvent(as->table, as->expandFork, 0));
+    SSRLCV_HIP_TRY(hipEventRecord(as->groupFork, caller));
+    for (int o = 1; o < svp::kOctaves; ++o) SSRLCV_HIP_TRY(hipStreamWaitEvent(expand_stream(as, caller, o), as->groupFork, 0));
   }
   for (int o = 0; o < svp::kOctaves; ++o) {
-    const hipStream_t es = !as || o == 0 ? caller : (o == 1 ? as->chain : as->table);
-    int rc = launch_expand(plan, ws, o, 0, 1, es);
+    int rc = launch_expand(plan, ws, o, 0, 1, expand_stream(as, caller, o), true);
     if (rc) return rc;
     plan->listInB[o] ^= 1;
   }
   if (as) {
-    SSRLCV_HIP_TRY(hipEventRecord(as->expandJoin[0], as->chain));
-    SSRLCV_HIP_TRY(hipEventRecord(as->expandJoin[1], as->table));
-    SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->expandJoin[0], 0));
-    SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->expandJoin[1], 0));
+    for (int o = 1; o < svp::kOctaves; ++o) {
+      SSRLCV_HIP_TRY(hipEventRecord(as->groupExpanded[o - 1], expand_stream(as, caller, o)));
+      SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->groupExpanded[o - 1], 0));
+    }
   }
   return SSRLCV_OK;
 }
 
-void book_features(const ssrlcv_sift_plan* plan, char* ws, uint32_t* numFeatures, hipStream_t caller) {
-  hipLaunchKernelGGL(k_book_featbase, dim3(1), dim3(1), 0, caller, (OctaveState*)(ws + plan->off_state),
-                     (uint32_t*)(ws + plan->oct[0].off_featBase), numFeatures, plan->maxFeatures);
+// withDescRanges: also the descriptor work list of all octaves (what stage_descriptors would launch k_build_ranges for)
+void book_features(const ssrlcv_sift_plan* plan, char* ws, uint32_t* numFeatures, hipStream_t caller, bool withDescRanges = false) {
+  if (withDescRanges)
+    hipLaunchKernelGGL(k_book_and_desc_ranges, dim3(1), dim3(1), 0, caller, (OctaveState*)(ws + plan->off_state),
+                       (uint32_t*)(ws + plan->oct[0].off_featBase), numFeatures, plan->maxFeatures, desc_tab(plan, ws, 0));
+  else
+    hipLaunchKernelGGL(k_book_featbase, dim3(1), dim3(1), 0, caller, (OctaveState*)(ws + plan->off_state),
+                       (uint32_t*)(ws + plan->oct[0].off_featBase), numFeatures, plan->maxFeatures);
 }
 
 unsigned desc_blocks(const ssrlcv_sift_plan* plan, int oFirst, int oLast, unsigned* maxBlocks) {
@@ -1704,7 +1752,7 @@ unsigned desc_blocks(const ssrlcv_sift_plan* plan, int oFirst, int oLast, unsign
 }
 
 // fillDescriptors (src/SIFT_FeatureFactory.cu:131-166,475-549), all octaves in one launch (book_features first)
-int stage_descriptors(const ssrlcv_sift_plan* plan, char* ws, ssrlcv_sift_feature* features, hipStream_t caller) {
+int stage_descriptors(const ssrlcv_sift_plan* plan, char* ws, ssrlcv_sift_feature* features, hipStream_t caller, bool rangesBuilt = false) {
   OctaveState* states = (OctaveState*)(ws + plan->off_state);
   OctaveSet set = make_set(plan, ws);
   RangeTable* descRanges = desc_tab(plan, ws, 0);
@@ -1712,7 +1760,7 @@ int stage_descriptors(const ssrlcv_sift_plan* plan, char* ws, ssrlcv_sift_featur
   unsigned maxBlocks = 1;
   const unsigned descBlocks = desc_blocks(plan, 0, svp::kOctaves - 1, &maxBlocks);
   // one launch over every octave's key points, largest windows first (see RangeTable)
-  hipLaunchKernelGGL(k_build_ranges, dim3(1), dim3(1), 0, caller, states, descRanges, 0, 0xFFFFFu);
+  if (!rangesBuilt) hipLaunchKernelGGL(k_build_ranges, dim3(1), dim3(1), 0, caller, states, descRanges, 0, 0xFFFFFu);
   hipLaunchKernelGGL(k_desc_consts, dim3(maxBlocks * svp::kOctaves), dim3(256), 0, caller, (const RangeTable*)descRanges, set,
                      plan->params.descriptorContribWidth, (const OctaveState*)states, (const GroupCtl*)nullptr);
   hipLaunchKernelGGL(k_descriptors, dim3(descBlocks * kWaveKernelOversubscription), dim3(256), 0, caller, (const RangeTable*)descRanges, set,
@@ -1899,6 +1947,11 @@ static int describe_impl(const ssrlcv_sift_plan* plan, void* workspace, ssrlcv_s
     const int rc = queue_rest_orientations(plan, ws, as->chain2, as);
     if (rc) return rc;
   }
+  const bool earlyPrologue = as && stop >= 6 && !splitRest && !(stop >= 7 && pipelinedSampling && expand_scratch_fits(plan, 0, kOct0Groups));
+  if (earlyPrologue) {
+    const int rc = orientations_prologue(plan, ws, caller, as);
+    if (rc) return rc;
+  }
   if (as) {  // the polar stream joins too (its tables are read by the sampling kernels below)
     SSRLCV_HIP_TRY(hipEventRecord(as->join[svp::kOctaves], (svp::stream_priority_mode() & 1) ? as->polar : as->table));
     SSRLCV_HIP_TRY(hipStreamWaitEvent(caller, as->join[svp::kOctaves], 0));
@@ -1919,12 +1972,12 @@ static int describe_impl(const ssrlcv_sift_plan* plan, void* workspace, ssrlcv_s
     return SSRLCV_OK;
   }
   if (stop >= 6) {
-    int rc = stage_orientations(plan, ws, caller, as, as != nullptr, splitRest);
+    int rc = stage_orientations(plan, ws, caller, as, as != nullptr, splitRest, earlyPrologue);
     if (rc) return rc;
   }
-  book_features(plan, ws, numFeatures, caller);
+  book_features(plan, ws, numFeatures, caller, stop >= 7);
   if (stop >= 7) {
-    int rc = stage_descriptors(plan, ws, features, caller);
+    int rc = stage_descriptors(plan, ws, features, caller, true);
     if (rc) return rc;
   }
   SSRLCV_LAUNCH_CHECK();
