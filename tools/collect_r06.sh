@@ -1,9 +1,10 @@
 # Developer helper: every profile of round 6 in one call on the GPU box (from the repository root).
-# usage: bash tools/collect_r06.sh <commit>
+# usage: bash tools/collect_r06.sh <commit> [tag]
 set -e
 COMMIT=$1
 export TMPDIR=/tmp
-bash tools/collect_profiles.sh r06_v1 $COMMIT
+TAG=${2:-r06_v1}
+bash tools/collect_profiles.sh $TAG $COMMIT
 bash tools/collect_floor.sh r06_floor 4096
 python3 tools/pyramid_floor.py gpurun_out/r06_floor 4096 $COMMIT > gpurun_out/r06_floor/pyramid_floor.json
 # config[4]'s size: kernel statistics + traffic of the stages on one 8192^2 image (serial: clean per-kernel numbers)
@@ -24,4 +25,4 @@ for k in k_descriptors k_thetas k_polar; do python3 tools/pmcsum.py "$k" $OUT/pm
 unset SSRLCV_SIFT_SERIAL
 unset SSRLCV_DEV_BUILD
 rm -rf gpurun_out/r06_8192/serial gpurun_out/r06_desc/pmc
-ls -la gpurun_out/r06_v1 gpurun_out/r06_floor gpurun_out/r06_8192 gpurun_out/r06_desc
+ls -la gpurun_out/$TAG gpurun_out/r06_floor gpurun_out/r06_8192 gpurun_out/r06_desc
