@@ -470,18 +470,21 @@ __device__ __forceinline__ int round_coord(float v) {
 // The reference runs ONE THREAD per key point and accumulates its 36-bin histogram with a sequential float
 // multiply-add chain in raster order of the window (:1031-1047): that order is part of the result (float addition does
 // not associate), and the peak tests and the parabolic interpolation read the histogram's last bits.  So this kernel
-// keeps the reference's shape -- one lane per key point, its two float loop counters, one fmaf per sample in raster
-// order -- and spends its effort around that chain:
-//   - the histogram lives in LDS, one conflict-free column per lane (bin-major), not in scratch;
+// keeps the reference's sum -- its two float loop counters, one fmaf per sample and bin in raster order -- and spends its
+// effort around that chain:
+//   - the histogram lives in LDS, one column per key point (bin-major), not in scratch;
 //   - gradient magnitude / direction come from the per-pixel polar tables (k_polar) instead of 4 gathers + sqrtf +
 //     atan2f per sample;
-//   - a lane fetches its window row in chunks of 8 consecutive table entries (four 16-byte buffer loads, the next chunk
-//     requested before the current one is processed): with one 8-byte gather per sample every lane pulled a whole
-//     128-byte line per sample through L2 (1024 lane streams per CU against 256 lines of L1: 82 GB per 4096^2 image);
+//   - 1 << LPKS lanes share a key point (four since round 6): a chunk is 8 << LPKS consecutive samples of a window row,
+//     fetched as neighbouring 16-byte pieces (the next chunk requested before the current one is processed), every lane
+//     evaluates the Gaussian weight and the bin of eight of them -- the expensive part, which no order constrains -- and
+//     then the votes are added to the one histogram column lane after lane, in raster order.  With one lane per key point
+//     (rounds 2-5) the kernel took as long as ONE lane's chain over the largest window (3 481 samples, 0.4 ms) while
+//     the vector pipe sat at a quarter of its rate;
 //   - the divisions are the IEEE quotients by way of sv::exact_div3 / exact_div5 (reciprocals hoisted), the Gaussian is
 //     the shared expf;
-//   - one-wave blocks (9 KiB of LDS each): the windows of the key points of a wave differ in size and the wave runs as
-//     long as its largest; many small blocks let the dispatcher even that out.
+//   - one-wave blocks: the windows of the key points of a wave differ in size and the wave runs as long as its largest;
+//     many small blocks let the dispatcher even that out.
 // The first version of this file ran one WAVE per key point with exact 64-bit fixed-point LDS atomics -- order
 // independent, but not the reference's sum: thetas agreed to ~1e-6 and a handful of peak decisions per million key
 // points flipped.
