@@ -354,6 +354,8 @@ print("PYRAMID OK")
     {"SSRLCV_GAUSS_PAIR_MINPX": "0"},                               # round 6: levels 0 + 1 of octave 0 in one launch on the matrix pipe (1024 x 768: five strips, the last one partial; top, bottom, left and right mirrors)
     {"SSRLCV_GAUSS_PAIR_MINPX": "0", "SSRLCV_GAUSS_PAIR_FORM": "valu"},  # ... and its vector formulation
     {"SSRLCV_NO_GAUSS_PAIR": "1"},                                  # the two launches
+    {"SSRLCV_NO_XCD_STRIPS": "1"},                                  # strips in plain block order (the default gives an XCD neighbouring strips)
+    {"SSRLCV_NO_XCD_STRIPS": "1", "SSRLCV_GAUSS_TILE_MAXPX": "0", "SSRLCV_GAUSS_RM": "63", "SSRLCV_GAUSS_RM_MINPX": "0"},
 ], ids=lambda v: "+".join(k.replace("SSRLCV_", "") + "=" + x for k, x in v.items()))
 def test_every_pyramid_schedule_is_bit_exact(variant):
     """build_dog's developer switches (who makes the 2x2 bin, how the fused DoG / extrema pass is cut into launches, row
