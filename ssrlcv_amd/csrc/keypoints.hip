@@ -791,37 +791,52 @@ __global__ __launch_bounds__(64) void k_thetas(const OctaveState* states, const 
         const float tx = xi - kx;
         wgt = sv::expf_nonpos(sv::exact_div5(-((tx * tx) + cty2), weight, rweight));
       };
+      // The second half of a lane's samples (loads 2 and 3: the chunk's samples from 4 LANES on) lies past the row's end in every
+      // lane of the wave for the last chunk of many rows (a 45-sample row of a blur-2 window is a chunk of 32 and one of 13): then
+      // neither their weights nor their votes -- all of them fmaf(0, w, h) = h -- are formed.  (xs[4] is the lane's first sample of
+      // that half and the sub-0 lane's is the half's first.)
+      const bool upperHalf = __any(cact && xs[kThetaChunk / 2] <= maxx);
       float wg[kThetaChunk], mg[kThetaChunk];
       float* slot[kThetaChunk];
+      auto weigh_half = [&](auto hc) __attribute__((always_inline)) {
+        constexpr int i0 = decltype(hc)::value * (kThetaChunk / 2);
 #pragma unroll
-      for (int i = 0; i < kThetaChunk; ++i) {
-        // (element first, cast second: __builtin_bit_cast applied directly to a vector-element lvalue reads element 0)
-        const unsigned um = cur[i >> 1][(i & 1) * 2], ua = cur[i >> 1][(i & 1) * 2 + 1];
-        int bin;
-        weigh(__builtin_bit_cast(float, ua), xs[i], wg[i], bin);
-        const bool counts = cact && xs[i] <= maxx && (unsigned)bin < 36u;
-        slot[i] = &s_hist[counts ? bin : 0][col];
-        mg[i] = counts ? __builtin_bit_cast(float, um) : 0.0f;  // (the weight is finite: a zero magnitude is enough)
-      }
-#pragma unroll
-      for (int j = 0; j < kThetaChunk / 2; ++j) {
-#pragma unroll
-        for (int q = 0; q < LANES; ++q) {
-          if (LANES == 1 || sub == q) {
-            // two votes per LDS round trip: both slots are read first, the second takes the first's sum when it is the same slot
-            const float h0 = *slot[2 * j], h1 = *slot[2 * j + 1];
-            const float n0 = fmaf(mg[2 * j], wg[2 * j], h0);
-            const float n1 = fmaf(mg[2 * j + 1], wg[2 * j + 1], slot[2 * j + 1] == slot[2 * j] ? n0 : h1);
-            *slot[2 * j] = n0;
-            *slot[2 * j + 1] = n1;  // (LDS keeps a wave's stores in order: the same slot ends up holding n1)
-          }
-          // The order of the phases is an order between LANES, which the language knows nothing about: to the compiler
-          // `if (sub == 0) X; if (sub == 1) X;` is X executed once by every thread, and it has merged the phases on that
-          // ground (two lanes, round 6: every lane voted at once).  A wave barrier -- no instruction, but convergent and
-          // with side effects -- keeps each phase a region of its own, in program order.
-          if (LANES > 1) __builtin_amdgcn_wave_barrier();
+        for (int i = i0; i < i0 + kThetaChunk / 2; ++i) {
+          // (element first, cast second: __builtin_bit_cast applied directly to a vector-element lvalue reads element 0)
+          const unsigned um = cur[i >> 1][(i & 1) * 2], ua = cur[i >> 1][(i & 1) * 2 + 1];
+          int bin;
+          weigh(__builtin_bit_cast(float, ua), xs[i], wg[i], bin);
+          const bool counts = cact && xs[i] <= maxx && (unsigned)bin < 36u;
+          slot[i] = &s_hist[counts ? bin : 0][col];
+          mg[i] = counts ? __builtin_bit_cast(float, um) : 0.0f;  // (the weight is finite: a zero magnitude is enough)
         }
-      }
+      };
+      auto vote_half = [&](auto hc) __attribute__((always_inline)) {
+        constexpr int j0 = decltype(hc)::value * (kThetaChunk / 4);
+#pragma unroll
+        for (int j = j0; j < j0 + kThetaChunk / 4; ++j) {
+#pragma unroll
+          for (int q = 0; q < LANES; ++q) {
+            if (LANES == 1 || sub == q) {
+              // two votes per LDS round trip: both slots are read first, the second takes the first's sum when it is the same slot
+              const float h0 = *slot[2 * j], h1 = *slot[2 * j + 1];
+              const float n0 = fmaf(mg[2 * j], wg[2 * j], h0);
+              const float n1 = fmaf(mg[2 * j + 1], wg[2 * j + 1], slot[2 * j + 1] == slot[2 * j] ? n0 : h1);
+              *slot[2 * j] = n0;
+              *slot[2 * j + 1] = n1;  // (LDS keeps a wave's stores in order: the same slot ends up holding n1)
+            }
+            // The order of the phases is an order between LANES, which the language knows nothing about: to the compiler
+            // `if (sub == 0) X; if (sub == 1) X;` is X executed once by every thread, and it has merged the phases on that
+            // ground (two lanes, round 6: every lane voted at once).  A wave barrier -- no instruction, but convergent and
+            // with side effects -- keeps each phase a region of its own, in program order.
+            if (LANES > 1) __builtin_amdgcn_wave_barrier();
+          }
+        }
+      };
+      weigh_half(std::integral_constant<int, 0>{});
+      if (upperHalf) weigh_half(std::integral_constant<int, 1>{});
+      vote_half(std::integral_constant<int, 0>{});
+      if (upperHalf) vote_half(std::integral_constant<int, 1>{});
     };
     while (__any(ca.act)) {
       step(qa, ca, qb, cb);
