@@ -721,8 +721,17 @@ __global__ __launch_bounds__(64) void k_thetas(const OctaveState* states, const 
       if (!c.act) return;
       const unsigned off = (c.rowoff + (unsigned)round_pos(c.x)) * 8u + 16u * (unsigned)sub;  // byte offset, below 2^32
 #pragma unroll
-      for (int j = 0; j < kThetaChunk / 2; ++j) into[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off + 16u * LANES * j), 0, 0);
+      for (int j = 0; j < kThetaChunk / 4; ++j) into[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off + 16u * LANES * j), 0, 0);
     };
+    // the chunk's upper half (see `upperHalf` in the evaluation): requested only if some lane of the wave can use it.  One sample
+    // of slack covers the difference between this sum and the walked coordinate the evaluation tests: what it uses has been loaded.
+    auto fetch_upper = [&](const Cursor& c, Chunk& into) {
+      if (!c.act) return;
+      const unsigned off = (c.rowoff + (unsigned)round_pos(c.x)) * 8u + 16u * (unsigned)sub;
+#pragma unroll
+      for (int j = kThetaChunk / 4; j < kThetaChunk / 2; ++j) into[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off + 16u * LANES * j), 0, 0);
+    };
+    auto wants_upper = [&](const Cursor& c) { return __any(c.act && c.x + (float)(CW / 2 - 1) <= maxx); };
     // One chunk is requested ahead of the one being evaluated.  The loop is written out for two chunk buffers that trade
     // places (the compiler's rotation of one pair cost 40 register moves per chunk); two chunks ahead was measured in
     // round 5 and is no faster.
@@ -732,11 +741,13 @@ __global__ __launch_bounds__(64) void k_thetas(const OctaveState* states, const 
     for (int j = 0; j < kThetaChunk / 2; ++j) qa[j] = qb[j] = u32x4{0u, 0u, 0u, 0u};
     ca = cf;
     fetch(cf, qa);
+    if (wants_upper(cf)) fetch_upper(cf, qa);
     advance(cf);
     cb = cf;
     auto step = [&](Chunk& cur, const Cursor& cc, Chunk& nxt, Cursor& cn) __attribute__((always_inline)) {
       cn = cf;
       fetch(cf, nxt);
+      if (wants_upper(cf)) fetch_upper(cf, nxt);
       advance(cf);
       // the chunk's coordinates (sample s of the chunk: x_0 `+= 1.0f` s times; see advance); this lane keeps those of its
       // eight samples s = 2 (j LANES + sub) + h
